@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""bench.py — EOT-samples/sec of the DorPatch hot loop on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (reference attack.py:184-342, stage 0) over one batch of
+synthetic input: blend/L2-project -> sample masks -> fused occlude+normalise (dp_apply_fwd) ->
+frozen ResNetV2-50x1-BiT forward + input-gradient backward (fp32, MIOpen) -> CW loss ->
+S-reduction of the input gradients (dp_apply_bwd) -> structural / density / group-lasso terms ->
+bookkeeping -> signed update (dp_project_update).  Workload = BASELINE.json configs[1]:
+64 images x 32 sampled double-masks = 2048 EOT samples per step per GPU at 224x224.  With N > 1
+ranks the per-GPU work is fixed (weak scaling: S = 32*N masks per image, 32 per rank) and the ranks
+exchange one all-reduce of the (64,3,224,224) patch gradient per step (RCCL).
+
+Rank 0 prints ONE JSON line (contract in the task statement) including
+  "roofline":     dp_apply_fwd, algorithmic bytes (602 112 B/sample @224) / HIP-event time, vs 8 TB/s
+  "cpu_baseline": the CPU oracle (a port of the reference step) timed on this host's cores on a
+                  bounded sample (1 image x 16 masks per step), N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="images per step (config 2: 64)")
+    ap.add_argument("--samples", type=int, default=32, help="sampled masks per image per GPU (config 2: 32)")
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--micro-batch", type=int, default=256, help="EOT samples per backbone fwd/bwd")
+    ap.add_argument("--patch-budget", type=float, default=0.0204, help="32x32 px @224 (SURVEY §0)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage", type=int, default=0)
+    return ap.parse_args()
+
+
+def build_model(device):
+    from dorpatch_amd.resnetv2 import resnetv2_50x1_bit, seeded_init_
+    from dorpatch_amd.utils import NormModel, get_normalize
+    net = seeded_init_(resnetv2_50x1_bit(1000), seed=1234).fold_weight_standardization().freeze()
+    return NormModel(net, get_normalize("imagenet", "resnetv2")).to(device).eval()
+
+
+def cpu_baseline(size, n_masks=16, steps=2):
+    """The reference step restated on the CPU (oracle/restatement.py), weights left trainable as the
+    reference leaves them, all host cores, B = 1 (the only batch the reference supports)."""
+    from oracle import restatement as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = build_model("cpu")
+    for p in model.parameters():
+        p.requires_grad_(True)            # as-is: the reference never freezes the backbone
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand(1, 3, size, size, generator=g)
+    mask, pattern = torch.rand(1, 1, size, size, generator=g), torch.rand(1, 3, size, size, generator=g)
+    y = torch.randint(0, 1000, (1,), generator=g)
+    universe = R.mask_universe(size, 2)
+    rng = np.random.RandomState(1234)
+    lvx = R.local_variance(x)[0].mean(1)
+
+    def one():
+        keep = universe[torch.from_numpy(rng.choice(universe.shape[0], n_masks, replace=False))]
+        R.eot_step(model, x, mask, pattern, y, keep, stage=0, targeted=True, n_classes=1000, lr=0.01,
+                   local_var_x=lvx)
+        model.zero_grad(set_to_none=True)
+    one()                                  # warm-up (oneDNN primitive creation)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = time.perf_counter() - t0
+    return {"value": round(n_masks * steps / dt, 3), "unit": "EOT-samples/s", "cores": cores,
+            "kind": "port",
+            "sample": "oracle/restatement.eot_step (reference step, backbone weights trainable as in the "
+                      "reference), B=1 x %d masks x %d steps @%dx%d fp32, 1 warm-up step discarded"
+                      % (n_masks, steps, size, size)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (no CPU fallback for the product path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
+        pg = dist.group.WORLD
+
+    from dorpatch_amd.attack import DorPatch, HotLoop
+    torch.backends.cudnn.benchmark = True       # reference utils.py:17; MIOpen picks its fastest solver
+    B, S_local, H = args.batch, args.samples, args.size
+    S = S_local * world                          # weak scaling: fixed per-GPU work
+    torch.manual_seed(1234)
+    np.random.seed(1234)
+    model = build_model(dev)
+    x = torch.rand(B, 3, H, H, generator=torch.Generator().manual_seed(1234)).to(dev)
+    with torch.no_grad():
+        clean = torch.cat([model(x[i:i + 64]).argmax(-1) for i in range(0, B, 64)])
+    y = (clean + 1 + torch.randint(0, 998, (B,), generator=torch.Generator().manual_seed(7)).to(dev)) % 1000
+    owner = DorPatch(micro_batch=args.micro_batch, process_group=pg, verbose=False)
+    loop = HotLoop(owner, model, x, args.patch_budget, 1000, "bench_out/cfg/sub", 0, y, True, 1e-2, 1e-1,
+                   0, 1, 10 ** 9, 7, 'topk', 2, S, 1e-3, 1e-3, 4.0, False, {})
+    loop.stage = args.stage
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    i = 1                                        # i % 100 != 0: the periodic failure sweep is timed apart
+    for _ in range(args.warmup):
+        loop.step(i)
+        i += 1
+    loop.kernel_events = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loop.step(i)
+        i += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    events = loop.kernel_events
+    loop.kernel_events = None
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # the every-100-steps collect_failure sweep (2520 forward-only samples per image), timed apart
+    barrier()
+    t1 = time.perf_counter()
+    loop._refresh_failures()
+    barrier()
+    dt_sweep = time.perf_counter() - t1
+    loop.close()
+
+    if rank == 0:
+        P = H * H
+        apply_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+        algo_bytes = B * S_local * 3 * P * 4          # 3*P*4 B written per EOT sample
+        achieved = algo_bytes / (apply_ms * 1e-3) / 1e9
+        value = B * S * args.steps / dt
+        out = {
+            "metric": "EOT-samples/sec", "value": round(value, 2), "unit": "EOT-samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d images x %d sampled PatchCleanser double-masks per "
+                                   "image per GPU = %d EOT samples/step/GPU, %dx%d, ResNetV2-50x1-BiT "
+                                   "(seeded random weights, frozen, fp32), stage-%d step of DorPatch.generate, "
+                                   "patch_budget %.4f" % (B, S_local, B * S_local, H, H, args.stage, args.patch_budget),
+                       "images": B, "masks_per_image_per_gpu": S_local, "masks_per_image_total": S,
+                       "image_size": H, "micro_batch": args.micro_batch,
+                       "parallelism": "eot-sample sharding x%d, 1 all-reduce of the patch gradient per step" % world},
+            "roofline": {"kernel": "k_apply_fwd (dp_apply_fwd)", "bound": "hbm",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(apply_ms, 4)},
+            "collect_failure_sweep_ms": round(dt_sweep * 1e3, 1),
+            "value_with_sweep_amortised": round(B * S * 100 / (100 * dt / args.steps + dt_sweep), 2),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(H)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,58 @@
+"""Build libdorpatch_hip.so in-tree with hipcc for gfx950 (MI355X).
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build
+container; the resulting ``dorpatch_amd/lib/libdorpatch_hip.so`` is git-ignored
+but travels to the GPU box with the repo snapshot.
+"""
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(PKG_DIR)
+SRC = os.path.join(PKG_DIR, "csrc", "dorpatch_hip.hip")
+INCLUDE = os.path.join(REPO_ROOT, "include")
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libdorpatch_hip.so")
+
+# -ffp-contract=off: keep mul/add un-fused so results track the fp32 CPU
+# reference op for op (the kernels are HBM-bound; FMA buys nothing).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+               "-fPIC", "-shared", "-Wall"]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found (need ROCm >= 7.0 with gfx950 support)")
+    return exe
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [SRC, os.path.join(INCLUDE, "dorpatch_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_extension(force=False, verbose=False):
+    """Compile the HIP kernels + C ABI. Returns the path of the shared library."""
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE, SRC, "-o", tmp]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_extension(force=True, verbose=True))

@@ -1,0 +1,848 @@
+// dorpatch_hip.hip — hand-written gfx950 (MI355X, CDNA4) kernels for the
+// DorPatch EOT hot path, behind the C ABI declared in include/dorpatch_hip.h.
+//
+// Design notes (see DESIGN.md for the roofline of every kernel):
+//  * wave = 64 lanes, blocks = 256 threads (4 waves, one per SIMD);
+//  * all streaming kernels move 16 B per lane (float4) with lane-contiguous
+//    addresses -> 1 KiB per wave-instruction, fully coalesced;
+//  * occlusion masks are never read from memory: a mask is <= 4 axis-aligned
+//    windows fetched through the scalar unit (wave-uniform index), the per-pixel
+//    test is a handful of VALU compares that hide under the HBM stream;
+//  * every reduction has a fixed order (no float atomics): the optimiser takes
+//    sign(grad), so run-to-run reproducibility matters more than a few us;
+//  * neighbour (structural / TV-like) terms stage an image tile + 1-pixel halo
+//    in LDS; partial sums use wave shuffles then a 4-entry LDS exchange;
+//  * no fast-math: 0 * inf must stay NaN (group-lasso "frozen cell" semantics,
+//    reference attack.py:243-245) and sign(NaN) must be 0 like torch.sign.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dorpatch_hip.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBlock = 256;  // threads per workgroup: 4 waves of 64
+
+#define DP_REQUIRE(cond)                                \
+  do {                                                  \
+    if (!(cond)) return (int)hipErrorInvalidValue;      \
+  } while (0)
+
+inline int launch_status() { return (int)hipGetLastError(); }
+inline hipStream_t as_stream(dp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ----------------------------------------------------------------------------
+// reductions
+// ----------------------------------------------------------------------------
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // valid in lane 0
+}
+
+// Sum over the 256 threads of a block in a fixed order; result valid in thread 0.
+__device__ __forceinline__ float block_sum(float v, float *sm4) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) sm4[wid] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) r = (sm4[0] + sm4[1]) + (sm4[2] + sm4[3]);
+  return r;
+}
+
+__device__ __forceinline__ float sgn(float v) {
+  // torch.sign semantics: sign(NaN) == 0, sign(+-0) == 0
+  return (float)((v > 0.f) - (v < 0.f));
+}
+
+// ----------------------------------------------------------------------------
+// a-2: sumsq partials + blend
+// ----------------------------------------------------------------------------
+
+constexpr int kSumsqGroupsPerThread = 4;                                // float4 groups
+constexpr int kSumsqPixPerBlock = kBlock * kSumsqGroupsPerThread * 4;   // 4096 pixels
+
+__global__ __launch_bounds__(kBlock) void k_sumsq_partials(
+    const float *__restrict__ mask, const float *__restrict__ pattern,
+    const float *__restrict__ x, int P, int nchunk, float *__restrict__ partials) {
+  __shared__ float sm4[4];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int P4 = P >> 2;
+  const f4 *m4 = reinterpret_cast<const f4 *>(mask + (size_t)b * P);
+  const f4 *p4 = reinterpret_cast<const f4 *>(pattern + (size_t)b * 3 * P);
+  const f4 *x4 = reinterpret_cast<const f4 *>(x + (size_t)b * 3 * P);
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < kSumsqGroupsPerThread; ++k) {
+    const int g = (chunk * kSumsqGroupsPerThread + k) * kBlock + threadIdx.x;
+    if (g < P4) {
+      const f4 m = m4[g];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const f4 d = m * (p4[c * P4 + g] - x4[c * P4 + g]);
+        acc += d.x * d.x;
+        acc += d.y * d.y;
+        acc += d.z * d.z;
+        acc += d.w * d.w;
+      }
+    }
+  }
+  const float tot = block_sum(acc, sm4);
+  if (threadIdx.x == 0) partials[(size_t)b * nchunk + chunk] = tot;
+}
+
+__global__ __launch_bounds__(kBlock) void k_blend(
+    const float *__restrict__ mask, const float *__restrict__ pattern,
+    const float *__restrict__ x, const float *__restrict__ partials, int nchunk,
+    float eps, int P, int add_x, float *__restrict__ adv_x, float *__restrict__ scale_out,
+    float *__restrict__ l2_out) {
+  const int b = blockIdx.y;
+  // every block re-derives the per-image scale from the partials in a fixed order
+  float tot = 0.f;
+  for (int k = 0; k < nchunk; ++k) tot += partials[(size_t)b * nchunk + k];
+  const float l2 = sqrtf(tot);
+  const float s = fminf(eps / l2, 1.f);  // eps/0 = inf -> 1 (torch.clip(max=1))
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    scale_out[b] = s;
+    l2_out[b] = l2;
+  }
+  const int P4 = P >> 2;
+  const int g = blockIdx.x * kBlock + threadIdx.x;
+  if (g >= P4) return;
+  const f4 m = reinterpret_cast<const f4 *>(mask + (size_t)b * P)[g];
+  const f4 *p4 = reinterpret_cast<const f4 *>(pattern + (size_t)b * 3 * P);
+  const f4 *x4 = reinterpret_cast<const f4 *>(x + (size_t)b * 3 * P);
+  f4 *o4 = reinterpret_cast<f4 *>(adv_x + (size_t)b * 3 * P);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const f4 xv = x4[c * P4 + g];
+    const f4 d = m * (p4[c * P4 + g] - xv);
+    o4[c * P4 + g] = add_x ? d * s + xv : d * s;
+  }
+}
+
+// ----------------------------------------------------------------------------
+// a-4 / a-10: occlusion apply, forward and backward
+// ----------------------------------------------------------------------------
+
+// Bit j of the result is set iff pixel (h, w+j) lies inside any of the R windows
+// of table entry m.  The window coordinates are wave-uniform (scalar loads).
+__device__ __forceinline__ unsigned occluded4(const int32_t *__restrict__ table, int R,
+                                              int m, int h, int w) {
+  unsigned occ = 0u;
+  const int32_t *t = table + (size_t)m * R * 4;
+  for (int r = 0; r < R; ++r) {
+    const int r0 = t[4 * r + 0], r1 = t[4 * r + 1], c0 = t[4 * r + 2], c1 = t[4 * r + 3];
+    if (h >= r0 && h < r1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) occ |= (unsigned)((w + j >= c0) & (w + j < c1)) << j;
+    }
+  }
+  return occ;
+}
+
+__device__ __forceinline__ f4 select4(unsigned occ, f4 v, float fill) {
+  f4 o;
+  o.x = (occ & 1u) ? fill : v.x;
+  o.y = (occ & 2u) ? fill : v.y;
+  o.z = (occ & 4u) ? fill : v.z;
+  o.w = (occ & 8u) ? fill : v.w;
+  return o;
+}
+
+struct NormDev {
+  float mean[3], std[3], fill[3];
+  int enable;
+};
+
+inline NormDev make_norm(const dp_norm_t *n) {
+  NormDev d;
+  d.enable = n->enable;
+  for (int c = 0; c < 3; ++c) {
+    d.mean[c] = n->mean[c];
+    d.std[c] = n->std[c];
+    // occluded pixel value after the (optional) normalisation: (fill - mean) / std
+    d.fill[c] = n->enable ? (n->fill - n->mean[c]) / n->std[c] : n->fill;
+  }
+  return d;
+}
+
+// grid: x = float4-group tiles of the image plane, y = S-chunks, z = image.
+// Each thread owns 4 consecutive pixels of all 3 channels, reads them ONCE,
+// then streams `s_per_block` occluded copies (3 x 16 B stores per sample).
+__global__ __launch_bounds__(kBlock) void k_apply_fwd(
+    const float *__restrict__ adv_x, const int32_t *__restrict__ table, int R,
+    const int32_t *__restrict__ idx, const int32_t *__restrict__ idx2, int idx_bstride,
+    int S, int H, int W, int s_per_block, NormDev nd, float *__restrict__ out) {
+  const int P = H * W, P4 = P >> 2;
+  const int g = blockIdx.x * kBlock + threadIdx.x;
+  if (g >= P4) return;
+  const int b = blockIdx.z;
+  const int s_begin = blockIdx.y * s_per_block;
+  const int s_end = min(S, s_begin + s_per_block);
+  const int pix = g << 2;
+  const int h = pix / W, w = pix - h * W;
+
+  const f4 *src = reinterpret_cast<const f4 *>(adv_x + (size_t)b * 3 * P);
+  f4 v0 = src[g], v1 = src[P4 + g], v2 = src[2 * P4 + g];
+  if (nd.enable) {  // reference NormModel: (x - mean) / std, true division
+    v0 = (v0 - nd.mean[0]) / nd.std[0];
+    v1 = (v1 - nd.mean[1]) / nd.std[1];
+    v2 = (v2 - nd.mean[2]) / nd.std[2];
+  }
+  const int32_t *ib = idx + (size_t)b * idx_bstride;
+  const int32_t *ib2 = idx2 ? idx2 + (size_t)b * idx_bstride : nullptr;
+  f4 *dst = reinterpret_cast<f4 *>(out + ((size_t)b * S + s_begin) * 3 * P);
+  for (int s = s_begin; s < s_end; ++s) {
+    unsigned occ = occluded4(table, R, ib[s], h, w);
+    if (ib2) occ |= occluded4(table, R, ib2[s], h, w);
+    __builtin_nontemporal_store(select4(occ, v0, nd.fill[0]), dst + g);
+    __builtin_nontemporal_store(select4(occ, v1, nd.fill[1]), dst + P4 + g);
+    __builtin_nontemporal_store(select4(occ, v2, nd.fill[2]), dst + 2 * P4 + g);
+    dst += 3 * P4;
+  }
+}
+
+// grid: x = float4-group tiles, y = S-slab, z = image.  Reads G once, skips the
+// 16 B of fully occluded groups, reduces over the slab's samples in s order.
+__global__ __launch_bounds__(kBlock) void k_apply_bwd(
+    const float *__restrict__ G, const int32_t *__restrict__ table, int R,
+    const int32_t *__restrict__ idx, const int32_t *__restrict__ idx2, int idx_bstride,
+    int B, int S, int H, int W, int s_per_slab, NormDev nd, float *__restrict__ slabs) {
+  const int P = H * W, P4 = P >> 2;
+  const int g = blockIdx.x * kBlock + threadIdx.x;
+  if (g >= P4) return;
+  const int b = blockIdx.z, z = blockIdx.y;
+  const int s_begin = z * s_per_slab;
+  const int s_end = min(S, s_begin + s_per_slab);
+  const int pix = g << 2;
+  const int h = pix / W, w = pix - h * W;
+  const int32_t *ib = idx + (size_t)b * idx_bstride;
+  const int32_t *ib2 = idx2 ? idx2 + (size_t)b * idx_bstride : nullptr;
+  const f4 *src = reinterpret_cast<const f4 *>(G + ((size_t)b * S + s_begin) * 3 * P);
+  f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+#pragma unroll 4
+  for (int s = s_begin; s < s_end; ++s) {
+    unsigned occ = occluded4(table, R, ib[s], h, w);
+    if (ib2) occ |= occluded4(table, R, ib2[s], h, w);
+    if (occ != 0xFu) {
+      const f4 g0 = __builtin_nontemporal_load(src + g);
+      const f4 g1 = __builtin_nontemporal_load(src + P4 + g);
+      const f4 g2 = __builtin_nontemporal_load(src + 2 * P4 + g);
+      a0 += select4(occ, g0, 0.f);
+      a1 += select4(occ, g1, 0.f);
+      a2 += select4(occ, g2, 0.f);
+    }
+    src += 3 * P4;
+  }
+  if (nd.enable) {  // d/dx (x - mean)/std = 1/std  (autograd: grad / std)
+    a0 = a0 / nd.std[0];
+    a1 = a1 / nd.std[1];
+    a2 = a2 / nd.std[2];
+  }
+  f4 *dst = reinterpret_cast<f4 *>(slabs + ((size_t)z * B + b) * 3 * P);
+  dst[g] = a0;
+  dst[P4 + g] = a1;
+  dst[2 * P4 + g] = a2;
+}
+
+__global__ __launch_bounds__(kBlock) void k_sum_slabs(const float *__restrict__ slabs,
+                                                      int nslab, int64_t n4,
+                                                      float *__restrict__ out,
+                                                      int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n4) return;
+  const f4 *s4 = reinterpret_cast<const f4 *>(slabs);
+  f4 *o4 = reinterpret_cast<f4 *>(out);
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (accumulate) acc = o4[i];
+  for (int z = 0; z < nslab; ++z) acc += s4[(int64_t)z * n4 + i];
+  o4[i] = acc;
+}
+
+// ----------------------------------------------------------------------------
+// a-7: CW loss, its gradient, argmax — one wave per logits row
+// ----------------------------------------------------------------------------
+
+struct ArgMax {
+  float v;
+  int i;
+};
+
+__device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {
+  // larger value wins; on ties the smaller index wins (first occurrence)
+  const bool take_b = (b.v > a.v) || (b.v == a.v && b.i < a.i);
+  return take_b ? b : a;
+}
+
+__device__ __forceinline__ ArgMax wave_argmax(ArgMax a) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    ArgMax o;
+    o.v = __shfl_xor(a.v, off, 64);
+    o.i = __shfl_xor(a.i, off, 64);
+    a = better(a, o);
+  }
+  return a;  // valid in every lane
+}
+
+__global__ __launch_bounds__(kBlock) void k_cw_loss(
+    const float *__restrict__ logits, const int64_t *__restrict__ y,
+    const int32_t *__restrict__ targeted_b, int N, int C, int S, float confidence,
+    float upstream, float *__restrict__ loss,
+    float *__restrict__ dlogits, int32_t *__restrict__ pred) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float *row = logits + (size_t)n * C;
+  const int label = (int)y[n / S];
+  const bool targeted = targeted_b[n / S] != 0;
+  const int kIntMax = 0x7fffffff;
+  ArgMax all = {-INFINITY, kIntMax}, oth = {-INFINITY, kIntMax};
+  for (int k = lane; k < C; k += 64) {
+    const ArgMax cur = {row[k], k};
+    all = better(all, cur);
+    if (k != label) oth = better(oth, cur);
+  }
+  all = wave_argmax(all);
+  oth = wave_argmax(oth);
+  if (pred && lane == 0) pred[n] = all.i;
+  if (!loss) return;
+  const float real = row[label];
+  // reference: ((1-onehot)*logits - onehot*1e4).max(1): the label slot holds -1e4
+  float other = oth.v;
+  int kstar = oth.i;
+  if (!(other >= -1e4f)) {  // label slot is the max (or no other class): no grad path
+    other = -1e4f;
+    kstar = -1;
+  }
+  const float margin = targeted ? (confidence + other) - real : (confidence + real) - other;
+  const bool active = margin >= 0.f;  // clamp(min=0) backward passes grad where x >= 0
+  if (lane == 0) loss[n] = active ? margin : 0.f;
+  if (!dlogits) return;
+  const float g_real = active ? (targeted ? -upstream : upstream) : 0.f;
+  const float g_other = active ? (targeted ? upstream : -upstream) : 0.f;
+  float *drow = dlogits + (size_t)n * C;
+  for (int k = lane; k < C; k += 64) {
+    float gk = 0.f;
+    if (k == label) gk = g_real;
+    if (k == kstar) gk = g_other;
+    drow[k] = gk;
+  }
+}
+
+// ----------------------------------------------------------------------------
+// a-5: structural (TV-like) terms — LDS tile + 1-pixel halo
+// ----------------------------------------------------------------------------
+
+constexpr int TW = 32, TH = 8;          // tile = 8 rows x 32 cols = 256 threads
+constexpr int TWP = TW + 2, THP = TH + 2;
+
+struct Tile3 {
+  float v[3][THP][TWP];
+};
+
+// Cooperative load of a 3-channel tile whose interior origin is (h0, w0);
+// local index [ly][lx] <-> pixel (h0 + ly - 1, w0 + lx - 1).  Out of image -> 0.
+__device__ __forceinline__ void load_tile3(const float *__restrict__ img, int H, int W,
+                                           int h0, int w0, Tile3 &t) {
+  for (int i = threadIdx.x; i < 3 * THP * TWP; i += kBlock) {
+    const int c = i / (THP * TWP);
+    const int r = i - c * (THP * TWP);
+    const int ly = r / TWP, lx = r - ly * TWP;
+    const int h = h0 + ly - 1, w = w0 + lx - 1;
+    float val = 0.f;
+    if (h >= 0 && h < H && w >= 0 && w < W) val = img[((size_t)c * H + h) * W + w];
+    t.v[c][ly][lx] = val;
+  }
+}
+
+// reference attack.py:33-39: a = |x[j] - x[j+1]| along w (last column keeps raw x),
+// b likewise along h (last row keeps raw x).  (ly, lx) is the local index of (h, w).
+__device__ __forceinline__ void grad_pair(const Tile3 &t, int c, int ly, int lx, int h, int w,
+                                          int H, int W, float &a, float &b) {
+  const float v = t.v[c][ly][lx];
+  a = (w < W - 1) ? fabsf(v - t.v[c][ly][lx + 1]) : v;
+  b = (h < H - 1) ? fabsf(v - t.v[c][ly + 1][lx]) : v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_local_variance(const float *__restrict__ x, int H,
+                                                           int W, float *__restrict__ lv) {
+  __shared__ Tile3 t;
+  const int b = blockIdx.z;
+  const int h0 = blockIdx.y * TH, w0 = blockIdx.x * TW;
+  load_tile3(x + (size_t)b * 3 * H * W, H, W, h0, w0, t);
+  __syncthreads();
+  const int tx = threadIdx.x & (TW - 1), ty = threadIdx.x / TW;
+  const int h = h0 + ty, w = w0 + tx;
+  if (h >= H || w >= W) return;
+  float acc = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float a, bb;
+    grad_pair(t, c, ty + 1, tx + 1, h, w, H, W, a, bb);
+    acc += a + bb;
+  }
+  lv[((size_t)b * H + h) * W + w] = acc / 3.f;
+}
+
+__global__ __launch_bounds__(kBlock) void k_struct_loss(const float *__restrict__ adv_x,
+                                                        const float *__restrict__ lv_x, int H,
+                                                        int W, float *__restrict__ partials) {
+  __shared__ Tile3 t;
+  __shared__ float sm4[4];
+  const int b = blockIdx.z;
+  const int h0 = blockIdx.y * TH, w0 = blockIdx.x * TW;
+  load_tile3(adv_x + (size_t)b * 3 * H * W, H, W, h0, w0, t);
+  __syncthreads();
+  const int tx = threadIdx.x & (TW - 1), ty = threadIdx.x / TW;
+  const int h = h0 + ty, w = w0 + tx;
+  float contrib = 0.f;
+  if (h < H && w < W) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float a, bb;
+      grad_pair(t, c, ty + 1, tx + 1, h, w, H, W, a, bb);
+      // attack.py:45  local_var * where(gl > gu, gu, gl)
+      acc += (a + bb) * ((a > bb) ? bb : a);
+    }
+    contrib = (acc / 3.f) / (lv_x[((size_t)b * H + h) * W + w] + 1e-5f);
+  }
+  const float tot = block_sum(contrib, sm4);
+  if (threadIdx.x == 0) {
+    const int ntile = gridDim.x * gridDim.y;
+    partials[(size_t)b * ntile + blockIdx.y * gridDim.x + blockIdx.x] = tot;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_reduce_rows(const float *__restrict__ in, int B,
+                                                        int n, float scale,
+                                                        float *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float acc = 0.f;
+  for (int k = lane; k < n; k += 64) acc += in[(size_t)b * n + k];
+  acc = wave_sum(acc);
+  if (lane == 0) out[b] = acc * scale;
+}
+
+// ----------------------------------------------------------------------------
+// a-6: mask statistics (one block per image; the mask is 200 KB @224)
+// ----------------------------------------------------------------------------
+
+__global__ __launch_bounds__(kBlock) void k_mask_stats(
+    const float *__restrict__ mask, int H, int W, int unit, int win, int ncy, int ncx, int nwy,
+    int nwx, float *__restrict__ cell_sumsq, float *__restrict__ win_sum,
+    float *__restrict__ group_lasso, float *__restrict__ density) {
+  __shared__ float sm4[4];
+  __shared__ float s_win[256];
+  const int b = blockIdx.x;
+  const float *m = mask + (size_t)b * H * W;
+
+  // conv_group(mask**2): unit x unit cells, stride unit (attack.py:72-74, 243-244)
+  float gl_acc = 0.f;
+  const int ncell = ncy * ncx;
+  for (int cell = threadIdx.x; cell < ncell; cell += kBlock) {
+    const int cy = cell / ncx, cx = cell - cy * ncx;
+    float acc = 0.f;
+    for (int i = 0; i < unit; ++i) {
+      const float *rowp = m + (size_t)(cy * unit + i) * W + cx * unit;
+      for (int j = 0; j < unit; ++j) acc += rowp[j] * rowp[j];
+    }
+    cell_sumsq[(size_t)b * ncell + cell] = acc;
+    gl_acc += sqrtf(acc);
+  }
+  const float gl_tot = block_sum(gl_acc, sm4);
+  if (threadIdx.x == 0) group_lasso[b] = (float)unit * gl_tot;
+
+  // conv_density(mask): win x win windows, stride win (attack.py:77-80, 237)
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nwindow = nwy * nwx;
+  for (int k = wid; k < nwindow; k += kBlock / 64) {
+    const int ky = k / nwx, kx = k - ky * nwx;
+    float acc = 0.f;
+    for (int i = lane; i < win * win; i += 64) {
+      const int r = i / win, c = i - r * win;
+      acc += m[(size_t)(ky * win + r) * W + kx * win + c];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      win_sum[(size_t)b * nwindow + k] = acc;
+      s_win[k] = acc;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mean = 0.f;
+    for (int k = 0; k < nwindow; ++k) mean += s_win[k];
+    mean /= (float)nwindow;
+    float var = 0.f;
+    for (int k = 0; k < nwindow; ++k) {
+      const float d = s_win[k] - mean;
+      var += d * d;
+    }
+    density[b] = var / (float)(nwindow - 1);  // torch.var: unbiased
+  }
+}
+
+// ----------------------------------------------------------------------------
+// a-2 bwd + a-5 grad + a-6 grads + a-9 signed update: one fused tile kernel
+// ----------------------------------------------------------------------------
+
+struct UpdateArgs {
+  const float *x, *adv_x, *lv_x, *g_adv;
+  const float *scale, *structured, *coeff_gl, *lr;
+  const float *cell_sumsq, *win_sum;
+  const int32_t *save_best;
+  float *pattern, *mask, *best_pattern, *best_mask, *g_pattern_out, *g_mask_out;
+  int H, W, stage, unit, win, ncy, ncx, nwy, nwx, do_update;
+  float density, clip_min, clip_max;
+};
+
+__global__ __launch_bounds__(kBlock) void k_project_update(UpdateArgs A) {
+  __shared__ Tile3 t;
+  __shared__ float s_lv[TH + 1][TW + 1];  // [ly][lx] <-> pixel (h0 + ly - 1, w0 + lx - 1)
+  __shared__ float s_wmean;
+  const int H = A.H, W = A.W, P = H * W;
+  const int b = blockIdx.z;
+  const int h0 = blockIdx.y * TH, w0 = blockIdx.x * TW;
+  load_tile3(A.adv_x + (size_t)b * 3 * P, H, W, h0, w0, t);
+  for (int i = threadIdx.x; i < (TH + 1) * (TW + 1); i += kBlock) {
+    const int ly = i / (TW + 1), lx = i - ly * (TW + 1);
+    const int h = h0 + ly - 1, w = w0 + lx - 1;
+    float val = 0.f;
+    if (h >= 0 && h < H && w >= 0 && w < W) val = A.lv_x[((size_t)b * H + h) * W + w];
+    s_lv[ly][lx] = val;
+  }
+  const int nwindow = A.nwy * A.nwx;
+  if (A.stage == 0 && threadIdx.x == 0) {
+    float mean = 0.f;
+    for (int k = 0; k < nwindow; ++k) mean += A.win_sum[(size_t)b * nwindow + k];
+    s_wmean = mean / (float)nwindow;
+  }
+  __syncthreads();
+
+  const int tx = threadIdx.x & (TW - 1), ty = threadIdx.x / TW;
+  const int h = h0 + ty, w = w0 + tx;
+  if (h >= H || w >= W) return;
+  const int ly = ty + 1, lx = tx + 1;
+  const size_t pix = (size_t)h * W + w;
+
+  const float s = A.scale[b];
+  const float coef = A.structured[b];
+  // autograd chain of  loss += structured * mean_{h,w}( mean_c(L) / (lv + 1e-5) ):
+  // (structured / P) / (lv + 1e-5) / 3  at the position of L
+  const float base = coef / (float)P;
+  const float up_left = (w >= 1) ? (base / (s_lv[ly][lx - 1] + 1e-5f)) / 3.f : 0.f;
+  const float up_up = (h >= 1) ? (base / (s_lv[ly - 1][lx] + 1e-5f)) / 3.f : 0.f;
+
+  const float m = A.mask[(size_t)b * P + pix];
+  float gm = 0.f;
+  float gp[3], pv[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const size_t off = ((size_t)b * 3 + c) * P + pix;
+    float g = A.g_adv[off];
+    if (coef != 0.f) {
+      // gradient reaches adv_x[h,w] only as the *subtracted neighbour* of the
+      // pixel to its left and of the pixel above (attack.py:35-38: the minuend
+      // is a detached clone).
+      const float xc = t.v[c][ly][lx];
+      float gs = 0.f;
+      if (w >= 1) {
+        float a, bb;
+        grad_pair(t, c, ly, lx - 1, h, w - 1, H, W, a, bb);
+        const float mn = (a > bb) ? bb : a;
+        const float dLda = mn + ((a > bb) ? 0.f : (a + bb));
+        gs -= up_left * dLda * sgn(t.v[c][ly][lx - 1] - xc);
+      }
+      if (h >= 1) {
+        float a, bb;
+        grad_pair(t, c, ly - 1, lx, h - 1, w, H, W, a, bb);
+        const float mn = (a > bb) ? bb : a;
+        const float dLdb = mn + ((a > bb) ? (a + bb) : 0.f);
+        gs -= up_up * dLdb * sgn(t.v[c][ly - 1][lx] - xc);
+      }
+      g += gs;
+    }
+    // utils.clip backward (scale detached): d delta = g * s; d pattern = d delta * mask;
+    // d mask = sum_c d delta * (pattern - x)
+    const float p = A.pattern[off];
+    const float gd = g * s;
+    gp[c] = gd * m;
+    gm += gd * (p - A.x[off]);
+    pv[c] = p;
+  }
+
+  if (A.stage == 0) {
+    if (A.density != 0.f) {
+      const int ky = h / A.win, kx = w / A.win;
+      if (ky < A.nwy && kx < A.nwx) {
+        const float ck = A.win_sum[(size_t)b * nwindow + ky * A.nwx + kx];
+        // var backward: grad * 2/(n-1) * (c - mean)
+        gm += (2.f / (float)(nwindow - 1)) * A.density * (ck - s_wmean);
+      }
+    }
+    const int cy = h / A.unit, cx = w / A.unit;
+    if (cy < A.ncy && cx < A.ncx) {
+      const float cs = A.cell_sumsq[(size_t)b * A.ncy * A.ncx + cy * A.ncx + cx];
+      // (coeff * unit) / (2 sqrt(cs)) * (2 m): 0 * inf = NaN for an all-zero cell,
+      // which torch.sign maps to 0 => the cell is frozen (attack.py:243-245).
+      const float gsq = (A.coeff_gl[b] * (float)A.unit) / (2.f * sqrtf(cs));
+      gm += gsq * (2.f * m);
+    }
+  }
+
+  if (A.g_pattern_out) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) A.g_pattern_out[((size_t)b * 3 + c) * P + pix] = gp[c];
+  }
+  if (A.g_mask_out) A.g_mask_out[(size_t)b * P + pix] = (A.stage == 0) ? gm : 0.f;
+
+  const bool save = A.save_best && A.save_best[b] != 0;
+  if (save) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) A.best_pattern[((size_t)b * 3 + c) * P + pix] = pv[c];
+    if (A.stage == 0) A.best_mask[(size_t)b * P + pix] = m;
+  }
+  if (!A.do_update) return;
+  const float lr = A.lr[b];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float p = pv[c] - lr * sgn(gp[c]);
+    p = fminf(fmaxf(p, A.clip_min), A.clip_max);
+    A.pattern[((size_t)b * 3 + c) * P + pix] = p;
+  }
+  if (A.stage == 0) {
+    float mm = m - lr * sgn(gm);
+    mm = fminf(fmaxf(mm, A.clip_min), A.clip_max);
+    A.mask[(size_t)b * P + pix] = mm;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_argmax(const float *__restrict__ logits, int N,
+                                                   int C, int32_t *__restrict__ pred) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float *row = logits + (size_t)n * C;
+  ArgMax all = {-INFINITY, 0x7fffffff};
+  for (int k = lane; k < C; k += 64) all = better(all, ArgMax{row[k], k});
+  all = wave_argmax(all);
+  if (lane == 0) pred[n] = all.i;
+}
+
+}  // namespace
+
+// ============================================================================
+// C ABI
+// ============================================================================
+
+extern "C" {
+
+int dp_abi_version(void) { return DP_ABI_VERSION; }
+
+const char *dp_error_string(int err) { return hipGetErrorString((hipError_t)err); }
+
+int dp_sumsq_nchunk(int P) { return P > 0 ? cdiv(P, kSumsqPixPerBlock) : 0; }
+
+int dp_sumsq_partials(const float *mask, const float *pattern, const float *x, int B, int P,
+                      float *partials, dp_stream_t stream) {
+  DP_REQUIRE(mask && pattern && x && partials);
+  DP_REQUIRE(B > 0 && P > 0 && (P & 3) == 0);
+  DP_REQUIRE(aligned16(mask) && aligned16(pattern) && aligned16(x));
+  const int nchunk = dp_sumsq_nchunk(P);
+  hipLaunchKernelGGL(k_sumsq_partials, dim3(nchunk, B), dim3(kBlock), 0, as_stream(stream), mask,
+                     pattern, x, P, nchunk, partials);
+  return launch_status();
+}
+
+int dp_blend(const float *mask, const float *pattern, const float *x, const float *partials,
+             float eps, int B, int P, int add_x, float *adv_x, float *scale, float *l2,
+             dp_stream_t stream) {
+  DP_REQUIRE(mask && pattern && x && partials && adv_x && scale && l2);
+  DP_REQUIRE(B > 0 && P > 0 && (P & 3) == 0);
+  DP_REQUIRE(aligned16(mask) && aligned16(pattern) && aligned16(x) && aligned16(adv_x));
+  const int nchunk = dp_sumsq_nchunk(P);
+  hipLaunchKernelGGL(k_blend, dim3(cdiv(P >> 2, kBlock), B), dim3(kBlock), 0, as_stream(stream),
+                     mask, pattern, x, partials, nchunk, eps, P, add_x, adv_x, scale, l2);
+  return launch_status();
+}
+
+static int check_occlusion_args(const int32_t *table, int R, const int32_t *idx, int idx_bstride,
+                                int B, int S, int H, int W, const dp_norm_t *norm) {
+  DP_REQUIRE(table && idx && norm);
+  DP_REQUIRE(R >= 1 && R <= DP_MAX_RECTS);
+  DP_REQUIRE(B > 0 && B <= 65535 && S > 0 && H > 0 && W > 0 && (W & 3) == 0);
+  DP_REQUIRE(idx_bstride == 0 || idx_bstride >= S);
+  if (norm->enable) {
+    for (int c = 0; c < 3; ++c) DP_REQUIRE(norm->std[c] != 0.f);
+  }
+  return 0;
+}
+
+int dp_apply_fwd(const float *adv_x, const int32_t *table, int R, const int32_t *idx,
+                 const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
+                 const dp_norm_t *norm, float *out, dp_stream_t stream) {
+  DP_REQUIRE(adv_x && out && aligned16(adv_x) && aligned16(out));
+  const int rc = check_occlusion_args(table, R, idx, idx_bstride, B, S, H, W, norm);
+  if (rc) return rc;
+  const int P4 = (H * W) >> 2;
+  const int tiles = cdiv(P4, kBlock);
+  // >= ~2048 workgroups (8 per CU) so the store stream covers all 8 XCDs evenly
+  int nchunk = cdiv(2048, tiles * B);
+  if (nchunk < 1) nchunk = 1;
+  if (nchunk > S) nchunk = S;
+  const int s_per_block = cdiv(S, nchunk);
+  nchunk = cdiv(S, s_per_block);
+  DP_REQUIRE(nchunk <= 65535);
+  hipLaunchKernelGGL(k_apply_fwd, dim3(tiles, nchunk, B), dim3(kBlock), 0, as_stream(stream),
+                     adv_x, table, R, idx, idx2, idx_bstride, S, H, W, s_per_block,
+                     make_norm(norm), out);
+  return launch_status();
+}
+
+static int bwd_s_per_slab(int B, int S, int P) {
+  const int tiles = cdiv(P >> 2, kBlock);
+  int nslab = cdiv(1024, tiles * B);  // >= ~1024 workgroups
+  const int max_slab = S >= 8 ? S / 4 : 1;  // keep >= 4 samples per slab
+  if (nslab > max_slab) nslab = max_slab;
+  if (nslab < 1) nslab = 1;
+  return cdiv(S, nslab);
+}
+
+int dp_apply_bwd_nslab(int B, int S, int P) {
+  if (B <= 0 || S <= 0 || P <= 0) return 0;
+  return cdiv(S, bwd_s_per_slab(B, S, P));
+}
+
+int dp_apply_bwd(const float *G, const int32_t *table, int R, const int32_t *idx,
+                 const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
+                 const dp_norm_t *norm, float *slabs, dp_stream_t stream) {
+  DP_REQUIRE(G && slabs && aligned16(G) && aligned16(slabs));
+  const int rc = check_occlusion_args(table, R, idx, idx_bstride, B, S, H, W, norm);
+  if (rc) return rc;
+  const int P = H * W;
+  const int s_per_slab = bwd_s_per_slab(B, S, P);
+  const int nslab = cdiv(S, s_per_slab);
+  DP_REQUIRE(nslab <= 65535);
+  hipLaunchKernelGGL(k_apply_bwd, dim3(cdiv(P >> 2, kBlock), nslab, B), dim3(kBlock), 0,
+                     as_stream(stream), G, table, R, idx, idx2, idx_bstride, B, S, H, W,
+                     s_per_slab, make_norm(norm), slabs);
+  return launch_status();
+}
+
+int dp_sum_slabs(const float *slabs, int nslab, int64_t n, float *out, int accumulate,
+                 dp_stream_t stream) {
+  DP_REQUIRE(slabs && out && nslab >= 1 && n > 0 && (n & 3) == 0);
+  DP_REQUIRE(aligned16(slabs) && aligned16(out));
+  const int64_t n4 = n >> 2;
+  const int64_t blocks = (n4 + kBlock - 1) / kBlock;
+  DP_REQUIRE(blocks <= 0x7fffffff);
+  hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream),
+                     slabs, nslab, n4, out, accumulate);
+  return launch_status();
+}
+
+int dp_cw_loss(const float *logits, const int64_t *y, const int32_t *targeted, int N, int C,
+               int S, float confidence, float upstream, float *loss, float *dlogits,
+               int32_t *pred, dp_stream_t stream) {
+  DP_REQUIRE(logits && y && targeted && loss);
+  DP_REQUIRE(N > 0 && C > 1 && S > 0);
+  hipLaunchKernelGGL(k_cw_loss, dim3(cdiv(N, kBlock / 64)), dim3(kBlock), 0, as_stream(stream),
+                     logits, y, targeted, N, C, S, confidence, upstream, loss, dlogits, pred);
+  return launch_status();
+}
+
+int dp_local_variance(const float *x, int B, int H, int W, float *lv, dp_stream_t stream) {
+  DP_REQUIRE(x && lv && B > 0 && B <= 65535 && H > 0 && W > 0);
+  hipLaunchKernelGGL(k_local_variance, dim3(cdiv(W, TW), cdiv(H, TH), B), dim3(kBlock), 0,
+                     as_stream(stream), x, H, W, lv);
+  return launch_status();
+}
+
+int dp_struct_ntile(int H, int W) { return (H > 0 && W > 0) ? cdiv(W, TW) * cdiv(H, TH) : 0; }
+
+int dp_struct_loss(const float *adv_x, const float *lv_x, int B, int H, int W, float *partials,
+                   dp_stream_t stream) {
+  DP_REQUIRE(adv_x && lv_x && partials && B > 0 && B <= 65535 && H > 0 && W > 0);
+  hipLaunchKernelGGL(k_struct_loss, dim3(cdiv(W, TW), cdiv(H, TH), B), dim3(kBlock), 0,
+                     as_stream(stream), adv_x, lv_x, H, W, partials);
+  return launch_status();
+}
+
+int dp_reduce_rows(const float *in, int B, int n, float scale, float *out, dp_stream_t stream) {
+  DP_REQUIRE(in && out && B > 0 && n > 0);
+  hipLaunchKernelGGL(k_reduce_rows, dim3(cdiv(B, kBlock / 64)), dim3(kBlock), 0,
+                     as_stream(stream), in, B, n, scale, out);
+  return launch_status();
+}
+
+int dp_mask_stats(const float *mask, int B, int H, int W, int unit, int win, float *cell_sumsq,
+                  float *win_sum, float *group_lasso, float *density, dp_stream_t stream) {
+  DP_REQUIRE(mask && cell_sumsq && win_sum && group_lasso && density);
+  DP_REQUIRE(B > 0 && H > 0 && W > 0 && unit > 0 && win > 0 && unit <= H && unit <= W &&
+             win <= H && win <= W);
+  const int ncy = (H - unit) / unit + 1, ncx = (W - unit) / unit + 1;
+  const int nwy = (H - win) / win + 1, nwx = (W - win) / win + 1;
+  DP_REQUIRE(nwy * nwx >= 2 && nwy * nwx <= 256);
+  hipLaunchKernelGGL(k_mask_stats, dim3(B), dim3(kBlock), 0, as_stream(stream), mask, H, W, unit,
+                     win, ncy, ncx, nwy, nwx, cell_sumsq, win_sum, group_lasso, density);
+  return launch_status();
+}
+
+int dp_project_update(const dp_update_cfg_t *cfg, const float *x, const float *adv_x,
+                      const float *lv_x, const float *g_adv, const float *scale,
+                      const float *structured, const float *coeff_gl, const float *lr,
+                      const float *cell_sumsq, const float *win_sum, const int32_t *save_best,
+                      float *pattern, float *mask, float *best_pattern, float *best_mask,
+                      float *g_pattern_out, float *g_mask_out, dp_stream_t stream) {
+  DP_REQUIRE(cfg && x && adv_x && lv_x && g_adv && scale && structured && pattern && mask);
+  DP_REQUIRE(cfg->B > 0 && cfg->B <= 65535 && cfg->H > 0 && cfg->W > 0);
+  DP_REQUIRE(cfg->stage == 0 || cfg->stage == 1);
+  DP_REQUIRE(!cfg->do_update || lr);
+  DP_REQUIRE(!save_best || (best_pattern && (cfg->stage == 1 || best_mask)));
+  UpdateArgs A;
+  A.x = x; A.adv_x = adv_x; A.lv_x = lv_x; A.g_adv = g_adv;
+  A.scale = scale; A.structured = structured; A.coeff_gl = coeff_gl; A.lr = lr;
+  A.cell_sumsq = cell_sumsq; A.win_sum = win_sum; A.save_best = save_best;
+  A.pattern = pattern; A.mask = mask; A.best_pattern = best_pattern; A.best_mask = best_mask;
+  A.g_pattern_out = g_pattern_out; A.g_mask_out = g_mask_out;
+  A.H = cfg->H; A.W = cfg->W; A.stage = cfg->stage; A.unit = cfg->unit; A.win = cfg->win;
+  A.ncy = A.ncx = A.nwy = A.nwx = 1;
+  A.do_update = cfg->do_update; A.density = cfg->density;
+  A.clip_min = cfg->clip_min; A.clip_max = cfg->clip_max;
+  if (cfg->stage == 0) {
+    DP_REQUIRE(coeff_gl && cell_sumsq && win_sum);
+    DP_REQUIRE(cfg->unit > 0 && cfg->win > 0 && cfg->unit <= cfg->H && cfg->unit <= cfg->W &&
+               cfg->win <= cfg->H && cfg->win <= cfg->W);
+    A.ncy = (cfg->H - cfg->unit) / cfg->unit + 1;
+    A.ncx = (cfg->W - cfg->unit) / cfg->unit + 1;
+    A.nwy = (cfg->H - cfg->win) / cfg->win + 1;
+    A.nwx = (cfg->W - cfg->win) / cfg->win + 1;
+    DP_REQUIRE(A.nwy * A.nwx >= 2);
+  }
+  hipLaunchKernelGGL(k_project_update, dim3(cdiv(cfg->W, TW), cdiv(cfg->H, TH), cfg->B),
+                     dim3(kBlock), 0, as_stream(stream), A);
+  return launch_status();
+}
+
+int dp_argmax(const float *logits, int N, int C, int32_t *pred, dp_stream_t stream) {
+  DP_REQUIRE(logits && pred && N > 0 && C > 0);
+  hipLaunchKernelGGL(k_argmax, dim3(cdiv(N, kBlock / 64)), dim3(kBlock), 0, as_stream(stream),
+                     logits, N, C, pred);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,244 @@
+"""Python host wrappers over the C ABI (include/dorpatch_hip.h).
+
+Every function takes/returns ``torch`` CUDA(ROCm) tensors, launches on
+``torch.cuda.current_stream()`` and never synchronises.  PyTorch is used for
+device memory and streams only; all arithmetic runs in the HIP kernels of
+``csrc/dorpatch_hip.hip``.  Non-GPU tensors are rejected: there is no fallback.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DpNorm, DpUpdateCfg
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"dorpatch_amd.ops: `{name}` must be a GPU tensor "
+                           "(no CPU fallback exists; the CPU oracle lives under oracle/ for tests only)")
+    if t.dtype != dtype:
+        raise TypeError(f"`{name}` must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"`{name}` must be contiguous")
+    return t
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def make_norm(mean=None, std=None, fill=0.5):
+    """dp_norm_t: ``mean``/``std`` None -> raw output with ``fill`` on occluded pixels."""
+    n = DpNorm()
+    n.fill = float(fill)
+    if mean is None:
+        n.enable = 0
+        for c in range(3):
+            n.mean[c], n.std[c] = 0.0, 1.0
+    else:
+        n.enable = 1
+        mean = [float(v) for v in np.asarray(mean, dtype=np.float64).reshape(-1)]
+        std = [float(v) for v in np.asarray(std, dtype=np.float64).reshape(-1)]
+        if len(mean) == 1:
+            mean, std = mean * 3, std * 3
+        for c in range(3):
+            n.mean[c], n.std[c] = mean[c], std[c]
+    return n
+
+
+RAW_NORM = make_norm(None, None, 0.5)
+
+
+def upload_table(table, device):
+    """(n, R, 4) numpy int32 rectangle table -> device int32 tensor."""
+    t = np.ascontiguousarray(table, dtype=np.int32)
+    assert t.ndim == 3 and t.shape[2] == 4 and 1 <= t.shape[1] <= _lib.DP_MAX_RECTS
+    return torch.from_numpy(t).to(device)
+
+
+# ---------------------------------------------------------------- a-2
+def blend(mask, pattern, x, eps, add_x=True, out=None):
+    """``utils.clip`` (+ ``+ x``): returns (adv_x | delta, scale (B,), l2 (B,))."""
+    lib = _lib.load()
+    _chk(mask, torch.float32, "mask"), _chk(pattern, torch.float32, "pattern"), _chk(x, torch.float32, "x")
+    B, C, H, W = x.shape
+    assert C == 3 and mask.shape == (B, 1, H, W) and pattern.shape == x.shape
+    P = H * W
+    nchunk = lib.dp_sumsq_nchunk(P)
+    partials = torch.empty((B, nchunk), dtype=torch.float32, device=x.device)
+    _lib.check(lib.dp_sumsq_partials(_p(mask), _p(pattern), _p(x), B, P, _p(partials), _stream()),
+               "dp_sumsq_partials")
+    if out is None:
+        out = torch.empty_like(x)
+    scale = torch.empty((B,), dtype=torch.float32, device=x.device)
+    l2 = torch.empty((B,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.dp_blend(_p(mask), _p(pattern), _p(x), _p(partials), float(eps), B, P,
+                            1 if add_x else 0, _p(out), _p(scale), _p(l2), _stream()), "dp_blend")
+    return out, scale, l2
+
+
+# ---------------------------------------------------------------- a-4 / a-10
+def _idx_args(idx, idx2, B):
+    _chk(idx, torch.int32, "idx")
+    if idx.dim() == 1:
+        S, bstride = idx.shape[0], 0
+    else:
+        assert idx.dim() == 2 and idx.shape[0] == B
+        S, bstride = idx.shape[1], idx.shape[1]
+    if idx2 is not None:
+        _chk(idx2, torch.int32, "idx2")
+        assert idx2.shape == idx.shape
+    return S, bstride
+
+
+def apply_fwd(adv_x, table, idx, idx2=None, norm=RAW_NORM, out=None):
+    """Occlude (+ normalise) B images under S masks each -> (B*S, 3, H, W)."""
+    lib = _lib.load()
+    _chk(adv_x, torch.float32, "adv_x"), _chk(table, torch.int32, "table")
+    B, C, H, W = adv_x.shape
+    assert C == 3
+    S, bstride = _idx_args(idx, idx2, B)
+    if out is None:
+        out = torch.empty((B * S, 3, H, W), dtype=torch.float32, device=adv_x.device)
+    else:
+        _chk(out, torch.float32, "out")
+        assert out.numel() == B * S * 3 * H * W
+    _lib.check(lib.dp_apply_fwd(_p(adv_x), _p(table), table.shape[1], _p(idx), _p(idx2), bstride,
+                                B, S, H, W, ctypes.byref(norm), _p(out), _stream()), "dp_apply_fwd")
+    return out
+
+
+def apply_bwd(G, table, idx, idx2=None, norm=RAW_NORM, B=None, out=None, accumulate=False):
+    """Sum d loss/d out over the S samples of every image -> d loss/d adv_x (B,3,H,W)."""
+    lib = _lib.load()
+    _chk(G, torch.float32, "G"), _chk(table, torch.int32, "table")
+    N, C, H, W = G.shape
+    assert C == 3
+    if B is None:
+        B = idx.shape[0] if idx.dim() == 2 else None
+    assert B is not None, "B must be given when idx is shared across images"
+    S, bstride = _idx_args(idx, idx2, B)
+    assert N == B * S, (N, B, S)
+    P = H * W
+    nslab = lib.dp_apply_bwd_nslab(B, S, P)
+    if out is None:
+        assert not accumulate
+        out = torch.empty((B, 3, H, W), dtype=torch.float32, device=G.device)
+    direct = (nslab == 1 and not accumulate)
+    slabs = out if direct else torch.empty((nslab, B, 3, H, W), dtype=torch.float32, device=G.device)
+    _lib.check(lib.dp_apply_bwd(_p(G), _p(table), table.shape[1], _p(idx), _p(idx2), bstride,
+                                B, S, H, W, ctypes.byref(norm), _p(slabs), _stream()), "dp_apply_bwd")
+    if not direct:
+        _lib.check(lib.dp_sum_slabs(_p(slabs), nslab, B * 3 * P, _p(out), 1 if accumulate else 0,
+                                    _stream()), "dp_sum_slabs")
+    return out
+
+
+# ---------------------------------------------------------------- a-7
+def cw_loss(logits, y, targeted, S, confidence, upstream, loss_out=None, want_grad=True,
+            want_pred=True):
+    """CW margin loss per row, its gradient w.r.t. the logits, and the argmax."""
+    lib = _lib.load()
+    _chk(logits, torch.float32, "logits"), _chk(y, torch.int64, "y"), _chk(targeted, torch.int32, "targeted")
+    N, C = logits.shape
+    assert N % S == 0 and y.numel() * S >= N
+    loss = loss_out if loss_out is not None else torch.empty((N,), dtype=torch.float32, device=logits.device)
+    _chk(loss, torch.float32, "loss_out")
+    dlogits = torch.empty_like(logits) if want_grad else None
+    pred = torch.empty((N,), dtype=torch.int32, device=logits.device) if want_pred else None
+    _lib.check(lib.dp_cw_loss(_p(logits), _p(y), _p(targeted), N, C, S, float(confidence),
+                              float(upstream), _p(loss), _p(dlogits), _p(pred), _stream()), "dp_cw_loss")
+    return loss, dlogits, pred
+
+
+def argmax(logits):
+    lib = _lib.load()
+    _chk(logits, torch.float32, "logits")
+    N, C = logits.shape
+    pred = torch.empty((N,), dtype=torch.int32, device=logits.device)
+    _lib.check(lib.dp_argmax(_p(logits), N, C, _p(pred), _stream()), "dp_argmax")
+    return pred
+
+
+# ---------------------------------------------------------------- a-5
+def local_variance(x):
+    lib = _lib.load()
+    _chk(x, torch.float32, "x")
+    B, C, H, W = x.shape
+    assert C == 3
+    lv = torch.empty((B, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(lib.dp_local_variance(_p(x), B, H, W, _p(lv), _stream()), "dp_local_variance")
+    return lv
+
+
+def struct_loss(adv_x, lv_x, out=None):
+    """loss_struc (B,) = mean_{h,w}( mean_c(L(adv_x)) / (lv_x + 1e-5) )."""
+    lib = _lib.load()
+    _chk(adv_x, torch.float32, "adv_x"), _chk(lv_x, torch.float32, "lv_x")
+    B, C, H, W = adv_x.shape
+    ntile = lib.dp_struct_ntile(H, W)
+    partials = torch.empty((B, ntile), dtype=torch.float32, device=adv_x.device)
+    _lib.check(lib.dp_struct_loss(_p(adv_x), _p(lv_x), B, H, W, _p(partials), _stream()), "dp_struct_loss")
+    if out is None:
+        out = torch.empty((B,), dtype=torch.float32, device=adv_x.device)
+    _lib.check(lib.dp_reduce_rows(_p(partials), B, ntile, 1.0 / float(H * W), _p(out), _stream()),
+               "dp_reduce_rows")
+    return out
+
+
+# ---------------------------------------------------------------- a-6
+def mask_grid(H, W, unit, win):
+    return ((H - unit) // unit + 1, (W - unit) // unit + 1, (H - win) // win + 1, (W - win) // win + 1)
+
+
+def mask_stats(mask, unit, win, gl_out=None, dens_out=None):
+    """cell_sumsq (B,ncy,ncx), win_sum (B,nwy,nwx), group_lasso (B,), density (B,)."""
+    lib = _lib.load()
+    _chk(mask, torch.float32, "mask")
+    B, C, H, W = mask.shape
+    assert C == 1
+    ncy, ncx, nwy, nwx = mask_grid(H, W, unit, win)
+    dev = mask.device
+    cell = torch.empty((B, ncy, ncx), dtype=torch.float32, device=dev)
+    wsum = torch.empty((B, nwy, nwx), dtype=torch.float32, device=dev)
+    gl = gl_out if gl_out is not None else torch.empty((B,), dtype=torch.float32, device=dev)
+    dens = dens_out if dens_out is not None else torch.empty((B,), dtype=torch.float32, device=dev)
+    _lib.check(lib.dp_mask_stats(_p(mask), B, H, W, unit, win, _p(cell), _p(wsum), _p(gl), _p(dens),
+                                 _stream()), "dp_mask_stats")
+    return cell, wsum, gl, dens
+
+
+# ---------------------------------------------------------------- a-2 bwd, a-5/a-6 grads, a-9
+def project_update(x, adv_x, lv_x, g_adv, scale, structured, pattern, mask, *, stage, lr=None,
+                   coeff_gl=None, cell_sumsq=None, win_sum=None, unit=7, win=28, density=0.0,
+                   clip_min=0.0, clip_max=1.0, save_best=None, best_pattern=None, best_mask=None,
+                   do_update=True, want_grads=False):
+    """Fused chain rule + regulariser gradients + signed update (in place on pattern/mask)."""
+    lib = _lib.load()
+    for name, t in (("x", x), ("adv_x", adv_x), ("lv_x", lv_x), ("g_adv", g_adv), ("scale", scale),
+                    ("structured", structured), ("pattern", pattern), ("mask", mask)):
+        _chk(t, torch.float32, name)
+    B, C, H, W = x.shape
+    cfg = DpUpdateCfg(B=B, H=H, W=W, stage=int(stage), unit=int(unit), win=int(win),
+                      do_update=1 if do_update else 0, density=float(density),
+                      clip_min=float(clip_min), clip_max=float(clip_max))
+    for name, t in (("lr", lr), ("coeff_gl", coeff_gl), ("cell_sumsq", cell_sumsq),
+                    ("win_sum", win_sum), ("best_pattern", best_pattern), ("best_mask", best_mask)):
+        if t is not None:
+            _chk(t, torch.float32, name)
+    if save_best is not None:
+        _chk(save_best, torch.int32, "save_best")
+    gp = torch.empty_like(pattern) if want_grads else None
+    gm = torch.empty_like(mask) if want_grads else None
+    _lib.check(lib.dp_project_update(ctypes.byref(cfg), _p(x), _p(adv_x), _p(lv_x), _p(g_adv),
+                                     _p(scale), _p(structured), _p(coeff_gl), _p(lr),
+                                     _p(cell_sumsq), _p(win_sum), _p(save_best), _p(pattern),
+                                     _p(mask), _p(best_pattern), _p(best_mask), _p(gp), _p(gm),
+                                     _stream()), "dp_project_update")
+    return gp, gm

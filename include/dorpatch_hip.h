@@ -1,0 +1,187 @@
+/*
+ * dorpatch_hip.h — C ABI of libdorpatch_hip.so (gfx950 / MI355X).
+ *
+ * The DorPatch EOT hot path (reference attack.py:167-342) as hand-written HIP
+ * kernels behind plain-C entry points.  Conventions for EVERY entry point:
+ *
+ *   - all pointers are DEVICE pointers owned by the caller (PyTorch, or any
+ *     other HIP allocator); the library allocates nothing and keeps no state;
+ *   - tensors are dense, row-major, fp32 unless stated; images are NCHW;
+ *     "P" = H*W pixels, W % 4 == 0 (16-byte vector access never straddles a row);
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous and
+ *     ordered on that stream;
+ *   - the return value is a hipError_t as int: 0 = success, 1 =
+ *     hipErrorInvalidValue for bad arguments, anything else = launch failure.
+ *     dp_error_string() maps it to text.  The Python host raises RuntimeError.
+ *
+ * The reference has no FFI of its own (it is 4 Python files); each entry point
+ * below cites the reference Python lines it replaces.  INTEGRATION.md shows
+ * the ctypes binding a maintainer of the reference would add.
+ */
+#ifndef DORPATCH_HIP_H
+#define DORPATCH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DP_ABI_VERSION 1
+#define DP_MAX_RECTS 4 /* occlusion windows per mask-table entry */
+
+typedef void *dp_stream_t; /* hipStream_t */
+
+/* Per-channel input normalisation fused into the occlusion kernels
+ * (reference utils.py:66-78 NormModel: (x - mean) / std, mean = std = 0.5).
+ * enable == 0: emit raw [0,1] pixels and fill occluded pixels with `fill`
+ * (reference attack.py:206 / PatchCleanser.py:99-100 use 0.5). */
+typedef struct {
+  int enable;
+  float mean[3];
+  float std[3];
+  float fill;
+} dp_norm_t;
+
+int dp_abi_version(void);
+const char *dp_error_string(int err);
+
+/* ---- a-2  utils.clip (utils.py:105-110) + adv_x = delta + x (attack.py:184-185) ---- */
+
+/* Number of per-image partial sums dp_sumsq_partials writes for P pixels. */
+int dp_sumsq_nchunk(int P);
+
+/* partials[b*nchunk + k] = sum over chunk k of (mask*(pattern-x))^2
+ * (first pass of torch.norm(delta_x, p=2, dim=(1,2,3)), utils.py:107-108).
+ * mask (B,1,P) pattern,x (B,3,P); partials (B,nchunk). Deterministic. */
+int dp_sumsq_partials(const float *mask, const float *pattern, const float *x,
+                      int B, int P, float *partials, dp_stream_t stream);
+
+/* scale[b] = min(eps / sqrt(sum_k partials[b,k]), 1)   (utils.py:109, detached)
+ * adv_x    = x + (mask*(pattern-x)) * scale            (utils.py:110, attack.py:185)
+ *            (add_x = 0: only the perturbation delta_x * scale, i.e. utils.clip's
+ *             return value, for callers that add x themselves — main.py:140-141)
+ * l2[b]    = sqrt(sum)                                 (attack.py:323 log value, pre-scale)
+ * adv_x (B,3,P); scale,l2 (B). */
+int dp_blend(const float *mask, const float *pattern, const float *x,
+             const float *partials, float eps, int B, int P, int add_x,
+             float *adv_x, float *scale, float *l2, dp_stream_t stream);
+
+/* ---- a-4 / a-10  occlusion apply (attack.py:204-220, PatchCleanser.py:44-59,99-100) ----
+ *
+ * The reference materialises every mask as a (1,H,W) bool tensor (126 MB for
+ * the 2520-mask universe @224).  Here a mask is `R` axis-aligned windows
+ * table[m][r] = {row0,row1,col0,col1} (half-open, int32); a pixel is occluded
+ * iff it lies in any window.  idx (B,S) picks the mask of every EOT sample;
+ * idx_bstride = S for per-image draws, 0 to share one (S,) draw across images.
+ * idx2 (same shape, may be NULL) is the reference's `dual` second mask
+ * (attack.py:208-218).
+ *
+ * out[b,s,c,h,w] = occluded ? fill : adv_x[b,c,h,w], then optionally
+ * normalised (dp_norm_t).  out is (B,S,3,H,W) == (B*S,3,H,W).
+ * Algorithmic HBM traffic: B*S*3*P*4 bytes written, B*3*P*4 read.           */
+int dp_apply_fwd(const float *adv_x, const int32_t *table, int R,
+                 const int32_t *idx, const int32_t *idx2, int idx_bstride,
+                 int B, int S, int H, int W, const dp_norm_t *norm, float *out,
+                 dp_stream_t stream);
+
+/* Number of S-slabs dp_apply_bwd writes (so that B*slabs*tiles fills the chip
+ * while the S-reduction order stays fixed). */
+int dp_apply_bwd_nslab(int B, int S, int P);
+
+/* Backward of dp_apply_fwd w.r.t. adv_x (autograd of attack.py:206-220 +
+ * utils.py:77-78):  slabs[z,b,c,p] = sum_{s in slab z} keep(s,p) * G[b,s,c,p] / std_c
+ * G (B,S,3,P) is d loss / d out.  slabs (nslab,B,3,P).  The slab count comes
+ * from dp_apply_bwd_nslab(); follow with dp_sum_slabs.  Deterministic order. */
+int dp_apply_bwd(const float *G, const int32_t *table, int R,
+                 const int32_t *idx, const int32_t *idx2, int idx_bstride,
+                 int B, int S, int H, int W, const dp_norm_t *norm,
+                 float *slabs, dp_stream_t stream);
+
+/* out[i] = (accumulate ? out[i] : 0) + sum_{z<nslab} slabs[z*n + i], z ascending. */
+int dp_sum_slabs(const float *slabs, int nslab, int64_t n, float *out,
+                 int accumulate, dp_stream_t stream);
+
+/* ---- a-7  CW_loss.__call__ + its gradient (attack.py:16-23, 224-230, 247) ----
+ * logits (N,C); y (B,) int64 label and targeted (B,) int32 flag of image n / S
+ * (a batch is B independent single-image problems; each may have switched to a
+ * targeted criterion on its own — attack.py:106-122, 169-176).
+ * loss[n]    = max(conf + other - real, 0)  (targeted)  | max(conf + real - other, 0)
+ * dlogits    = upstream * d loss[n] / d logits[n,:]     (may be NULL: forward only)
+ * pred[n]    = argmax_k logits[n,k] (int32, may be NULL) */
+int dp_cw_loss(const float *logits, const int64_t *y, const int32_t *targeted,
+               int N, int C, int S, float confidence, float upstream,
+               float *loss, float *dlogits, int32_t *pred, dp_stream_t stream);
+
+/* ---- a-5  local_variance / min_var_weighted_variance (attack.py:33-45, 100, 227-228) ---- */
+
+/* lv[b,h,w] = mean_c( |x[h,w]-x[h,w+1]| + |x[h,w]-x[h+1,w]| ), last column /
+ * last row keep the raw pixel (attack.py:35-39 slice semantics).  x (B,3,H,W). */
+int dp_local_variance(const float *x, int B, int H, int W, float *lv,
+                      dp_stream_t stream);
+
+/* Number of per-image tile partials dp_struct_loss writes. */
+int dp_struct_ntile(int H, int W);
+
+/* partials[b,t] = sum over tile t of mean_c(L(adv_x)) / (lv_x + 1e-5)
+ * loss_struc[b] = sum_t partials[b,t] / P  via dp_reduce_rows(scale = 1/P). */
+int dp_struct_loss(const float *adv_x, const float *lv_x, int B, int H, int W,
+                   float *partials, dp_stream_t stream);
+
+/* out[b] = scale * sum_k in[b*n + k], k ascending (one wave per row). */
+int dp_reduce_rows(const float *in, int B, int n, float scale, float *out,
+                   dp_stream_t stream);
+
+/* ---- a-6  density + group-lasso statistics of the mask (attack.py:72-80, 237-245) ----
+ * cell_sumsq (B,ncy,ncx): sum of mask^2 per unit x unit cell (conv_group(mask**2))
+ * win_sum    (B,nwy,nwx): sum of mask per win x win window  (conv_density(mask))
+ * group_lasso[b] = unit * sum_cells sqrt(cell_sumsq)          (attack.py:243-244)
+ * density[b]     = unbiased variance of the window sums       (attack.py:237)
+ * ncy = (H-unit)/unit+1, nwy = (H-win)/win+1 (stride = kernel, no padding). */
+int dp_mask_stats(const float *mask, int B, int H, int W, int unit, int win,
+                  float *cell_sumsq, float *win_sum, float *group_lasso,
+                  float *density, dp_stream_t stream);
+
+/* ---- a-2 (backward) + a-5 (gradient) + a-6 (gradients) + a-9 (signed update) ----
+ * One fused pass over the B images (attack.py:227-247 backward, 333-342 update):
+ *
+ *   g      = g_adv + d(structured_b * loss_struc)/d adv_x        (a-5 gradient)
+ *   g_pat  = g * mask * scale_b                                  (utils.py:107-110 bwd)
+ *   g_mask = sum_c g * (pattern - x) * scale_b
+ *            + density * 2/(n_win-1) * (win_sum - mean)          (stage 0)
+ *            + coeff_gl_b * unit / (2 sqrt(cell_sumsq)) * 2 mask (stage 0; 0*inf = NaN kept)
+ *   if save_best[b]: best_pattern = pattern (, best_mask = mask in stage 0)   (attack.py:286-289)
+ *   pattern -= lr_b * sign(g_pat);  clamp      (sign(NaN) = 0, as torch.sign)
+ *   mask    -= lr_b * sign(g_mask); clamp      (stage 0 only)
+ *
+ * g_pattern_out / g_mask_out (may be NULL) receive the raw gradients for
+ * parity tests.  do_update = 0 leaves pattern/mask untouched.
+ * Per-image arrays (B,): scale, structured, coeff_gl, lr; save_best int32 (may be NULL). */
+typedef struct {
+  int B, H, W;
+  int stage;      /* 0: mask is learned; 1: mask frozen */
+  int unit, win;  /* group-lasso cell, density window (stage 0) */
+  int do_update;
+  float density;  /* coefficient (attack.py:239-240), 0 disables */
+  float clip_min, clip_max;
+} dp_update_cfg_t;
+
+int dp_project_update(const dp_update_cfg_t *cfg, const float *x,
+                      const float *adv_x, const float *lv_x, const float *g_adv,
+                      const float *scale, const float *structured,
+                      const float *coeff_gl, const float *lr,
+                      const float *cell_sumsq, const float *win_sum,
+                      const int32_t *save_best, float *pattern, float *mask,
+                      float *best_pattern, float *best_mask,
+                      float *g_pattern_out, float *g_mask_out,
+                      dp_stream_t stream);
+
+/* ---- next-1  collect_failure (attack.py:384-406) / PatchCleanser (PatchCleanser.py:68-112) ----
+ * pred[n] = argmax_k logits[n,k]  (first index on ties). */
+int dp_argmax(const float *logits, int N, int C, int32_t *pred,
+              dp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DORPATCH_HIP_H */

@@ -1,0 +1,240 @@
+"""TEST INFRASTRUCTURE — generate tests/golden/*.npz by running the UNMODIFIED reference.
+
+Run in the build container (needs /root/reference):
+
+    python -m oracle.gen_golden            # writes tests/golden/*.npz
+
+The reference has no tests and no golden vectors, so every fixture is
+produced by executing ``/root/reference/attack.py`` itself (through
+``oracle/ref_shim.py``) on seeded synthetic inputs and a tiny seeded backbone, and
+recording what its hot loop computes.  Internals are read without touching the
+reference: the backbone passed to ``generate`` is wrapped in a module that, on every
+forward call, looks up the calling ``generate`` frame and snapshots its locals
+(parameters, sampled indices, lr / coefficient schedules, failure list, and — one
+call later — the previous step's losses); gradients are caught by tensor hooks.
+
+Fixtures
+--------
+``steps_56.npz``   3 + 3 recorded steps (stage 0 / stage 1) at 56x56, S = 8, with all
+                   tensors: state before the step, sampled idx, loss_adv, loss_struc,
+                   group lasso, density, grad_pattern, grad_mask, state after.
+``steps_224.npz``  one stage-0 step at 224x224, S = 4 (the reference's real geometry).
+``trace_56.npz``   the scalar control trace of a full two-stage run (every step's
+                   loss_adv row, loss_target, idx, n_from_failure, lr, structured,
+                   coeff_group_lasso, failure-list length, not_decay, save flag) + the
+                   returned mask / pattern: pins the host bookkeeping (attack.py:249-316).
+``trace_56_fail.npz``  same with lr = 0.1 / a harder toy: stage 0 runs past iteration 1000, so the
+                   failure-biased sampling branch (attack.py:193-199) is exercised.
+``geometry.npz``   MaskWindow geometry for 56/224/384 and mask-universe checksums.
+"""
+import contextlib
+import io
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+from . import ref_shim, toy_models
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+class Capture(torch.nn.Module):
+    """Wraps the classifier handed to the reference and records the generate() frame."""
+
+    def __init__(self, model, keep_tensors_for=lambda stage, i: True):
+        super().__init__()
+        self.inner = model
+        self.records = []          # one dict per hot-loop model call
+        self.grads = {}            # (stage, i) -> dict(pattern=..., mask=...)
+        self._hooked = set()
+        self._stage_i = None
+        self.keep = keep_tensors_for
+
+    # reference's DataParallel-free path calls model(x) directly
+    def forward(self, inp):
+        frame = sys._getframe()
+        gen = None
+        while frame is not None:
+            name = frame.f_code.co_name
+            if name == "collect_failure":
+                gen = None
+                break
+            if name == "generate" and frame.f_code.co_filename.endswith("attack.py"):
+                gen = frame
+                break
+            frame = frame.f_back
+        if gen is not None and "sampling_idxs" in gen.f_locals and "i" in gen.f_locals \
+                and "adv_x_masked" in gen.f_locals and inp is gen.f_locals["adv_x_masked"]:
+            self._record(gen.f_locals)
+        return self.inner(inp)
+
+    def _record(self, L):
+        stage, i = int(L["stage"]), int(L["i"])
+        for key in ("adv_pattern", "adv_mask"):
+            t = L[key]
+            if t.requires_grad and id(t) not in self._hooked:
+                self._hooked.add(id(t))
+                t.register_hook(lambda g, key=key: self._on_grad(key, g))
+        self._stage_i = (stage, i)
+        rec = dict(stage=stage, i=i,
+                   idx=np.asarray(L["sampling_idxs"]).astype(np.int64).copy(),
+                   n_form_failure=int(L["n_form_failure"]),
+                   lr=float(L["lr_current"][0]), structured=float(L["structured"]),
+                   coeff_group_lasso=float(L["coeff_group_lasso"]),
+                   n_failed=len(L["failed_idxs"]),
+                   failed=np.asarray(L["failed_idxs"], dtype=np.int64).copy(),
+                   not_decay=int(L["not_decay"][0]), loss_best=float(L["loss_best"][0]),
+                   targeted=bool(L["targeted"]), y=int(L["y"][0]))
+        if self.keep(stage, i):
+            rec.update(mask=L["adv_mask"].detach().clone().numpy(),
+                       pattern=L["adv_pattern"].detach().clone().numpy(),
+                       adv_x=L["adv_x"].detach().clone().numpy())
+        # results of the PREVIOUS iteration are still in the frame
+        if self.records and self.records[-1]["stage"] == stage and self.records[-1]["i"] == i - 1:
+            prev = self.records[-1]
+            prev["loss_adv"] = L["loss_adv"].detach().numpy().reshape(-1).copy()
+            prev["loss_struc"] = float(L["loss_struc"].detach()[0])
+            prev["loss_target"] = float(L["loss_target"].detach()[0])
+            prev["save_best"] = bool(L["save_best"][0])
+            if stage == 0:
+                prev["group_lasso"] = float(L["group_lasso"].detach()[0])
+                prev["density"] = float(L["loss_density"].detach()[0])
+            prev["complete"] = True
+        self.records.append(rec)
+
+    def _on_grad(self, key, g):
+        if self._stage_i is not None and self.keep(*self._stage_i):
+            self.grads.setdefault(self._stage_i, {})[key] = g.detach().clone().numpy()
+
+
+def run_reference(model, x, y, *, sampling_size, max_iterations, eps=4.0, patch_budget=0.12,
+                  targeted=True, n_classes=10, seed=1234, keep=lambda s, i: True, **kw):
+    """Run the reference's DorPatch.generate under capture.  Returns (Capture, mask, pattern, stdout)."""
+    ref = ref_shim.load_reference()
+    cap = Capture(model, keep)
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp(prefix="dorpatch_golden_")
+    os.makedirs(os.path.join(tmp, "res", "cfg", "sub"))
+    os.chdir(tmp)
+    buf = io.StringIO()
+    try:
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        with contextlib.redirect_stdout(buf):
+            mask, pattern = ref.attack.DorPatch().generate(
+                cap, x, patch_budget, n_classes, "res/cfg/sub", 0, y=y, targeted=targeted,
+                sampling_size=sampling_size, max_iterations=max_iterations, eps=eps, **kw)
+    finally:
+        os.chdir(cwd)
+    return cap, mask.detach(), pattern.detach(), buf.getvalue()
+
+
+def toy_problem(H, seed_x=5, gain=1.0, n_classes=10):
+    net = toy_models.NormModel(toy_models.make_toy(n_classes=n_classes, gain=gain), toy_models.Normalize())
+    x = torch.rand(1, 3, H, H, generator=torch.Generator().manual_seed(seed_x))
+    with torch.no_grad():
+        y = net(x).topk(2)[1][:, 1].clone()        # target = runner-up class
+    return net, x, y
+
+
+def _pack_steps(cap, steps):
+    out = {}
+    recs = {(r["stage"], r["i"]): r for r in cap.records}
+    for n, key in enumerate(steps):
+        r, nxt = recs[key], recs[(key[0], key[1] + 1)]
+        g = cap.grads[key]
+        pre = "s%d_" % n
+        out[pre + "stage"], out[pre + "i"] = r["stage"], r["i"]
+        for k in ("idx", "mask", "pattern", "adv_x", "loss_adv"):
+            out[pre + k] = r[k]
+        for k in ("lr", "structured", "coeff_group_lasso", "loss_struc", "y"):
+            out[pre + k] = r[k]
+        if r["stage"] == 0:
+            out[pre + "group_lasso"], out[pre + "density"] = r["group_lasso"], r["density"]
+            out[pre + "grad_mask"] = g["adv_mask"]
+        out[pre + "grad_pattern"] = g["adv_pattern"]
+        out[pre + "new_mask"], out[pre + "new_pattern"] = nxt["mask"], nxt["pattern"]
+        out[pre + "lr_next"] = nxt["lr"]
+    out["n_steps"] = len(steps)
+    return out
+
+
+def make_steps_fixture(H, S, gain, path, n=3, eps=4.0):
+    net, x, y = toy_problem(H, gain=gain)
+    cap, mask, pattern, _ = run_reference(net, x, y, sampling_size=S, max_iterations=n + 1, eps=eps,
+                                          keep=lambda s, i: True)
+    steps = [(0, i) for i in range(n)] + ([(1, i) for i in range(n)] if H <= 64 else [])
+    data = _pack_steps(cap, steps)
+    data.update(x=x.numpy(), y0=y.numpy(), gain=gain, H=H, S=S, eps=eps, patch_budget=0.12,
+                final_mask=mask.numpy(), final_pattern=pattern.numpy())
+    np.savez_compressed(path, **data)
+    return data
+
+
+def make_trace_fixture(H, S, gain, path, max_iterations, eps=4.0, seed_x=5, lr=1e-2):
+    net, x, y = toy_problem(H, gain=gain, seed_x=seed_x)
+    cap, mask, pattern, log = run_reference(net, x, y, sampling_size=S, max_iterations=max_iterations,
+                                            eps=eps, keep=lambda s, i: False, lr=lr)
+    recs = [r for r in cap.records]
+    fields = dict(
+        stage=np.array([r["stage"] for r in recs]), i=np.array([r["i"] for r in recs]),
+        idx=np.stack([r["idx"] for r in recs]),
+        n_form_failure=np.array([r["n_form_failure"] for r in recs]),
+        lr=np.array([r["lr"] for r in recs], dtype=np.float32),
+        structured=np.array([r["structured"] for r in recs], dtype=np.float64),
+        coeff_group_lasso=np.array([r["coeff_group_lasso"] for r in recs], dtype=np.float64),
+        n_failed=np.array([r["n_failed"] for r in recs]),
+        not_decay=np.array([r["not_decay"] for r in recs]),
+        loss_best=np.array([r["loss_best"] for r in recs], dtype=np.float32),
+        complete=np.array([r.get("complete", False) for r in recs]),
+        loss_adv=np.stack([r.get("loss_adv", np.full(S, np.nan, np.float32)) for r in recs]).astype(np.float32),
+        loss_target=np.array([r.get("loss_target", np.nan) for r in recs], dtype=np.float32),
+        save_best=np.array([r.get("save_best", False) for r in recs]),
+    )
+    # failure lists as a ragged array (offsets + values)
+    fields["failed_offsets"] = np.cumsum([0] + [len(r["failed"]) for r in recs])
+    fields["failed_values"] = np.concatenate([r["failed"] for r in recs]) if recs else np.zeros(0, np.int64)
+    fields.update(x=x.numpy(), y0=y.numpy(), gain=gain, H=H, S=S, eps=eps, max_iterations=max_iterations, lr0=lr,
+                  final_mask=mask.numpy(), final_pattern=pattern.numpy(), log=np.array(log))
+    np.savez_compressed(path, **fields)
+    return fields
+
+
+def make_geometry_fixture(path):
+    ref = ref_shim.load_reference()
+    out = {}
+    for H in (56, 224, 384):
+        for r in (0.015, 0.03, 0.06, 0.12):
+            with contextlib.redirect_stdout(io.StringIO()):
+                mw = ref.PatchCleanser.MaskWindow(H, r)
+            tag = "%d_%s" % (H, str(r).replace(".", "p"))
+            out["params_" + tag] = np.array([mw.mask_size, mw.stride, mw.window_size])
+            if H <= 224:
+                # per-mask checksums: number of kept pixels and a position-weighted sum
+                w = torch.arange(H * H, dtype=torch.float64).view(1, 1, H, H) + 1.0
+                for name, ms in (("single", mw.mask_set), ("double", mw.double_mask_set)):
+                    out["%s_count_%s" % (name, tag)] = ms.sum((1, 2, 3)).numpy()
+                    out["%s_wsum_%s" % (name, tag)] = (ms * w).sum((1, 2, 3)).numpy()
+    np.savez_compressed(path, **out)
+    return out
+
+
+def main():
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    make_geometry_fixture(os.path.join(GOLDEN_DIR, "geometry.npz"))
+    make_steps_fixture(56, 8, 1.0, os.path.join(GOLDEN_DIR, "steps_56.npz"))
+    make_steps_fixture(224, 4, 1.0, os.path.join(GOLDEN_DIR, "steps_224.npz"), n=1)
+    make_trace_fixture(56, 8, 1.0, os.path.join(GOLDEN_DIR, "trace_56.npz"), max_iterations=2500)
+    # lr = 0.1 needs three decays to stop, so stage 0 runs past iteration 1000 and exercises the
+    # failure-biased sampling branch (attack.py:193-199)
+    make_trace_fixture(56, 8, 1.5, os.path.join(GOLDEN_DIR, "trace_56_fail.npz"), max_iterations=2500,
+                       seed_x=6, lr=0.1)
+    for f in sorted(os.listdir(GOLDEN_DIR)):
+        print(f, os.path.getsize(os.path.join(GOLDEN_DIR, f)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,71 @@
+"""Host control logic: replay the scalar trace of a full reference run
+(tests/golden/trace_*.npz) through the product's per-image state machine and sampling code
+and demand EXACT agreement with what the reference decided at every step."""
+import numpy as np
+
+from dorpatch_amd.attack import _ImageState, draw_indices
+
+
+def _failed(trace, k):
+    o = trace["failed_offsets"]
+    return trace["failed_values"][o[k]:o[k + 1]].tolist()
+
+
+def test_state_machine_replays_reference(golden_trace):
+    t = golden_trace
+    S = int(t["S"])
+    n = len(t["i"])
+    stages = t["stage"]
+    checked = 0
+    for stage in (0, 1):
+        rows = np.nonzero(stages == stage)[0]
+        st = _ImageState(float(t["lr0"]) if "lr0" in t.files else 1e-2,
+                         t["structured"][rows[0]], t["coeff_group_lasso"][rows[0]], True, int(t["y0"][0]))
+        st.failed_idxs = _failed(t, rows[0])
+        for k in rows:
+            i = int(t["i"][k])
+            # state the reference held when it sampled for step i
+            assert np.float32(st.lr_current) == t["lr"][k], (stage, i)
+            assert st.structured == t["structured"][k], (stage, i)
+            assert st.coeff_group_lasso == t["coeff_group_lasso"][k], (stage, i)
+            if i % 100 == 0:            # collect_failure refreshed the list (attack.py:187-190)
+                st.failed_idxs = _failed(t, k)
+            assert list(st.failed_idxs) == _failed(t, k), (stage, i)
+            assert st.not_decay == t["not_decay"][k]
+            assert st.n_from_failure(i, S, 1000) == t["n_form_failure"][k]
+            if not t["complete"][k]:
+                continue                # last recorded step of the stage: results not observable
+            save, stop = st.step(i, stage, t["loss_adv"][k], t["loss_target"][k], t["idx"][k],
+                                 int(t["n_form_failure"][k]))
+            assert save == bool(t["save_best"][k]), (stage, i)
+            assert not stop
+            checked += 1
+    assert checked > 800
+
+
+def test_sampling_reproduces_reference_rng(golden_trace):
+    """np.random.seed(1234) + the product's draw_indices == the reference's sampled indices,
+    including the failure-biased phase (i >= 1000)."""
+    t = golden_trace
+    S = int(t["S"])
+    np.random.seed(1234)
+    choices = np.arange(2520)
+    for k in range(len(t["i"])):
+        n_fail = int(t["n_form_failure"][k])
+        idx = draw_indices(np.random, _failed(t, k), n_fail, S, choices)
+        assert np.array_equal(idx, t["idx"][k]), (int(t["stage"][k]), int(t["i"][k]))
+
+
+def test_lr_floor_and_stop_rule():
+    """lr 0.01 -> 0.001 is NOT < 1e-3 in fp32; a second decay is needed."""
+    st = _ImageState(1e-2, 1e-3, 1e-5, True, 0)
+    st.failed_idxs = []
+    loss = np.full(4, 0.5, np.float32)      # never successful, never improving after the first save
+    stops = []
+    for i in range(500):
+        _, stop = st.step(i, 1, loss, 1.0, np.arange(4), 0)
+        stops.append(stop)
+        if stop:
+            break
+    assert stops.index(True) == 402           # 1 improving step + 2 x 201 patience windows
+    assert st.lr_current < np.float32(1e-3)

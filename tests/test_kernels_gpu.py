@@ -1,0 +1,219 @@
+"""GPU parity of every HIP kernel (called through the C ABI) against the CPU oracle.
+
+Tolerances: occlusion apply / argmax / sign bookkeeping are exact; fp32 arithmetic is compared
+at rtol 1e-5 (+ small atol) — only summation order differs from the CPU reference."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from dorpatch_amd import masks, ops  # noqa: E402
+from oracle import restatement as R  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _rand(*shape, seed=0):
+    return torch.rand(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+@pytest.mark.parametrize("B,H", [(1, 56), (3, 224), (2, 384)])
+@pytest.mark.parametrize("eps", [4.0, 1e4])
+def test_blend_matches_clip(B, H, eps):
+    x, p, m = _rand(B, 3, H, H, seed=1), _rand(B, 3, H, H, seed=2), _rand(B, 1, H, H, seed=3)
+    want = R.clip(m, p, x, eps)
+    adv, scale, l2 = ops.blend(m.to(DEV), p.to(DEV), x.to(DEV), eps)
+    delta, _, _ = ops.blend(m.to(DEV), p.to(DEV), x.to(DEV), eps, add_x=False)
+    l2_want = (m * (p - x)).flatten(1).norm(dim=1)
+    np.testing.assert_allclose(l2.cpu().numpy(), l2_want.numpy(), rtol=2e-6)
+    np.testing.assert_allclose(scale.cpu().numpy(), (eps / l2_want).clamp(max=1).numpy(), rtol=2e-6)
+    np.testing.assert_allclose(delta.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(adv.cpu().numpy(), (want + x).numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_blend_zero_delta_gives_unit_scale():
+    x = _rand(2, 3, 56, 56)
+    m = torch.zeros(2, 1, 56, 56)
+    adv, scale, l2 = ops.blend(m.to(DEV), x.clone().to(DEV), x.to(DEV), 4.0)
+    assert torch.equal(adv.cpu(), x) and (scale.cpu() == 1).all() and (l2.cpu() == 0).all()
+
+
+@pytest.mark.parametrize("H,dropout", [(56, 2), (224, 2), (384, 2), (56, 1)])
+@pytest.mark.parametrize("normalize", [False, True])
+def test_apply_fwd_exact(H, dropout, normalize):
+    B, S = 2, 9
+    table_np = masks.universe_rects(H, dropout)
+    table = ops.upload_table(table_np, DEV)
+    rng = np.random.RandomState(H + dropout)
+    idx = rng.randint(0, table_np.shape[0], size=(B, S))
+    adv = _rand(B, 3, H, H, seed=4)
+    keep = masks.rects_to_bool(table_np, H)
+    norm = ops.make_norm([0.5] * 3, [0.5] * 3, 0.5) if normalize else ops.RAW_NORM
+    out = ops.apply_fwd(adv.to(DEV), table, torch.from_numpy(idx).int().to(DEV), None, norm).cpu()
+    out = out.view(B, S, 3, H, H)
+    for b in range(B):
+        want = R.occlude(adv[b:b + 1], keep[torch.from_numpy(idx[b])])[0]
+        if normalize:
+            want = (want - 0.5) / 0.5
+        assert torch.equal(out[b], want), (b, (out[b] - want).abs().max())
+
+
+def test_apply_fwd_dual_and_shared_idx():
+    H, B, S = 56, 3, 5
+    table_np = masks.universe_rects(H, 2)
+    table = ops.upload_table(table_np, DEV)
+    keep = masks.rects_to_bool(table_np, H)
+    rng = np.random.RandomState(0)
+    i1, i2 = rng.randint(0, 2520, S), rng.randint(0, 2520, S)
+    adv = _rand(B, 3, H, H, seed=5)
+    out = ops.apply_fwd(adv.to(DEV), table, torch.from_numpy(i1).int().to(DEV),
+                        torch.from_numpy(i2).int().to(DEV)).cpu().view(B, S, 3, H, H)
+    k1, k2 = keep[torch.from_numpy(i1)], keep[torch.from_numpy(i2)]
+    want = R.occlude(adv, k1)
+    want = want * k2 + 0.5 * ~k2                    # attack.py:218
+    assert torch.equal(out, want)
+
+
+@pytest.mark.parametrize("B,S,H", [(1, 128, 56), (4, 8, 224), (1, 64, 384), (64, 4, 56)])
+@pytest.mark.parametrize("normalize", [False, True])
+def test_apply_bwd_matches_autograd(B, S, H, normalize):
+    table_np = masks.universe_rects(H, 2)
+    table = ops.upload_table(table_np, DEV)
+    rng = np.random.RandomState(B * S)
+    idx = torch.from_numpy(rng.randint(0, 2520, size=(B, S)))
+    G = torch.randn(B * S, 3, H, H, generator=torch.Generator().manual_seed(6))
+    # oracle: autograd of occlude (+ normalise) w.r.t. adv_x
+    keep = masks.rects_to_bool(table_np, H)
+    want = torch.empty(B, 3, H, H)
+    for b in range(B):
+        a = torch.zeros(1, 3, H, H, requires_grad=True)
+        o = R.occlude(a, keep[idx[b]])
+        if normalize:
+            o = (o - 0.5) / 0.5
+        o.backward(G[b * S:(b + 1) * S].view(1, S, 3, H, H))
+        want[b] = a.grad[0]
+    norm = ops.make_norm([0.5] * 3, [0.5] * 3, 0.5) if normalize else ops.RAW_NORM
+    got = ops.apply_bwd(G.to(DEV), table, idx.int().to(DEV), None, norm, B=B).cpu()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+    # accumulate path
+    acc = torch.ones(B, 3, H, H, device=DEV)
+    ops.apply_bwd(G.to(DEV), table, idx.int().to(DEV), None, norm, B=B, out=acc, accumulate=True)
+    np.testing.assert_allclose(acc.cpu().numpy(), want.numpy() + 1, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("C", [10, 1000])
+def test_cw_loss_grad_pred(C):
+    B, S = 3, 7
+    N = B * S
+    logits = torch.randn(N, C, generator=torch.Generator().manual_seed(7)) * 2
+    logits[0, 3] = 9.0          # satisfied margin for a targeted row with y = 3
+    y = torch.tensor([3, 1, 5])
+    flags = [True, False, True]
+    conf, up = 0.1, 1.0 / S
+    lg = logits.clone().requires_grad_(True)
+    rows = [R.cw_loss(lg[b * S:(b + 1) * S], y[b].repeat(S), C, flags[b], conf) for b in range(B)]
+    want = torch.cat(rows)
+    (want.sum() * up).backward()
+    loss, dl, pred = ops.cw_loss(logits.to(DEV), y.to(DEV), torch.tensor(flags).int().to(DEV), S, conf, up)
+    np.testing.assert_allclose(loss.cpu().numpy(), want.detach().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(dl.cpu().numpy(), lg.grad.numpy(), rtol=1e-6, atol=0)
+    assert torch.equal(pred.cpu().long(), logits.argmax(-1))
+    assert torch.equal(ops.argmax(logits.to(DEV)).cpu().long(), logits.argmax(-1))
+    assert (want == 0).any() and (want > 0).any()
+
+
+@pytest.mark.parametrize("B,H", [(2, 56), (1, 224), (1, 384), (2, 40)])
+def test_local_variance_and_struct_loss(B, H):
+    x, a = _rand(B, 3, H, H, seed=8), _rand(B, 3, H, H, seed=9)
+    lv_want = R.local_variance(x)[0].mean(1)
+    lv = ops.local_variance(x.to(DEV))
+    np.testing.assert_allclose(lv.cpu().numpy(), lv_want.numpy(), rtol=1e-6, atol=1e-7)
+    want = R.struct_loss(a, lv_want)
+    got = ops.struct_loss(a.to(DEV), lv)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-5)
+
+
+@pytest.mark.parametrize("B,H", [(2, 56), (1, 224), (1, 384)])
+def test_mask_stats(B, H):
+    m = _rand(B, 1, H, H, seed=10)
+    m[0, 0, 7:14, 14:21] = 0.0          # an all-zero group-lasso cell
+    cell, wsum, gl, dens = ops.mask_stats(m.to(DEV), 7, H // 8)
+    import torch.nn.functional as F
+    cell_want = F.conv2d(m ** 2, torch.ones(1, 1, 7, 7), stride=7)[:, 0]
+    wsum_want = F.conv2d(m, torch.ones(1, 1, H // 8, H // 8), stride=H // 8)[:, 0]
+    np.testing.assert_allclose(cell.cpu().numpy(), cell_want.numpy(), rtol=1e-5)
+    assert cell.cpu()[0, 1, 2] == 0
+    np.testing.assert_allclose(wsum.cpu().numpy(), wsum_want.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(gl.cpu().numpy(), R.group_lasso(m).numpy(), rtol=1e-5)
+    np.testing.assert_allclose(dens.cpu().numpy(), R.density_loss(m).numpy(), rtol=1e-4)
+
+
+def _grads_case(B, H, stage, seed):
+    """Full gradient chain of one step: oracle autograd vs dp_project_update."""
+    from oracle import toy_models
+    net = toy_models.NormModel(toy_models.make_toy(gain=1.0), toy_models.Normalize())
+    S = 6
+    x, p, m = _rand(B, 3, H, H, seed=seed), _rand(B, 3, H, H, seed=seed + 1), _rand(B, 1, H, H, seed=seed + 2)
+    if stage == 0:
+        m[0, 0, 0:7, 0:7] = 0.0         # frozen cell -> NaN gradient
+    else:
+        m = (m > 0.8).float()
+    y = torch.arange(B) % 10
+    universe = R.mask_universe(H, 2)
+    idx = torch.from_numpy(np.random.RandomState(seed).randint(0, 2520, size=(B, S)))
+    keep = universe[idx]                # (B,S,1,H,H)
+    structured = [1e-3 * (b + 1) for b in range(B)]
+    coeff = [1e-5 * (b + 2) for b in range(B)]
+    lr = [0.01 * (b + 1) for b in range(B)]
+    o = R.eot_step(net, x, m, p, y, keep, stage=stage, targeted=True, n_classes=10, structured=structured,
+                   coeff_group_lasso=coeff, eps=4.0, lr=lr)
+    # d loss_adv.mean / d adv_x from the oracle -> g_adv input of the fused kernel
+    adv = o["adv_x"].clone().requires_grad_(True)
+    masked = (adv[:, None] * keep + 0.5 * ~keep).reshape(-1, 3, H, H)
+    lg = net(masked)
+    la = torch.stack([R.cw_loss(lg[b * S:(b + 1) * S], y[b].repeat(S), 10, True, 0.1) for b in range(B)])
+    la.mean(1).sum().backward()
+    return dict(x=x, p=p, m=m, y=y, idx=idx, o=o, g_adv=adv.grad, structured=structured, coeff=coeff, lr=lr)
+
+
+@pytest.mark.parametrize("stage", [0, 1])
+@pytest.mark.parametrize("B,H", [(2, 56), (1, 224)])
+def test_project_update_grads_and_update(stage, B, H):
+    c = _grads_case(B, H, stage, seed=20 + stage)
+    d = lambda t: t.to(DEV).contiguous()
+    x, p, m = d(c["x"]), d(c["p"]), d(c["m"])
+    adv, scale, _ = ops.blend(m, p, x, 4.0)
+    lv = ops.local_variance(x)
+    cell, wsum, gl, dens = ops.mask_stats(m, 7, H // 8)
+    f32 = lambda v: torch.tensor(v, dtype=torch.float32, device=DEV)
+    kw = dict(stage=stage, coeff_gl=f32(c["coeff"]), cell_sumsq=cell, win_sum=wsum, unit=7, win=H // 8,
+              density=1e-3)
+    gp, gm = ops.project_update(x, adv, lv, d(c["g_adv"]), scale, f32(c["structured"]), p, m,
+                                do_update=False, want_grads=True, **kw)
+    o = c["o"]
+    gp_want, gm_want = o["grad_pattern"].numpy(), o["grad_mask"].numpy()
+    scale_g = np.abs(gp_want).max()
+    np.testing.assert_allclose(gp.cpu().numpy(), gp_want, rtol=1e-4, atol=1e-6 * scale_g)
+    assert np.array_equal(np.isnan(gm.cpu().numpy()), np.isnan(gm_want))
+    if stage == 0:
+        assert np.isnan(gm_want).sum() == 49
+        np.testing.assert_allclose(np.nan_to_num(gm.cpu().numpy()), np.nan_to_num(gm_want), rtol=1e-4,
+                                   atol=1e-6 * np.nanmax(np.abs(gm_want)))
+    assert torch.equal(p.cpu(), c["p"]) and torch.equal(m.cpu(), c["m"])       # do_update=False
+    # now the signed update + best-copy
+    best_p, best_m = torch.zeros_like(p), torch.zeros_like(m)
+    save = torch.tensor([1] + [0] * (B - 1), dtype=torch.int32, device=DEV)
+    p0, m0 = p.clone(), m.clone()
+    ops.project_update(x, adv, lv, d(c["g_adv"]), scale, f32(c["structured"]), p, m, lr=f32(c["lr"]),
+                       save_best=save, best_pattern=best_p, best_mask=best_m, do_update=True, **kw)
+    assert torch.equal(best_p[0], p0[0]) and (best_p[1:] == 0).all()
+    if stage == 0:
+        assert torch.equal(best_m[0], m0[0])
+    else:
+        assert torch.equal(m, m0) and (best_m == 0).all()          # mask frozen in stage 1
+    for got, want in ((p.cpu().numpy(), o["new_pattern"].numpy()), (m.cpu().numpy(), o["new_mask"].numpy())):
+        flips = np.abs(got - want) > 1e-6
+        assert flips.mean() < 2e-3, flips.mean()     # sign(ulp-noise) pixels only
+        assert np.abs(got - want).max() <= 2 * max(c["lr"]) + 1e-6
+    assert p.min() >= 0 and p.max() <= 1
