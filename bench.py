@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--micro-batch", type=int, default=256, help="EOT samples per backbone fwd/bwd")
     ap.add_argument("--patch-budget", type=float, default=0.0204, help="32x32 px @224 (SURVEY §0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the separately-timed collect_failure sweep")
     ap.add_argument("--stage", type=int, default=0)
     return ap.parse_args()
 
@@ -91,6 +92,14 @@ def cpu_baseline(size, n_masks=16, steps=2):
                       % (n_masks, steps, size, size)}
 
 
+def note(msg):
+    """Progress on stderr (stdout carries exactly one JSON line)."""
+    print("[bench %7.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,10 +139,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    note("model + loop ready (B=%d S=%d H=%d world=%d)" % (B, S, H, world))
     i = 1                                        # i % 100 != 0: the periodic failure sweep is timed apart
     for _ in range(args.warmup):
         loop.step(i)
         i += 1
+    note("warm-up done")
     loop.kernel_events = []
     barrier()
     t0 = time.perf_counter()
@@ -142,6 +153,7 @@ def main():
         i += 1
     barrier()
     dt = time.perf_counter() - t0
+    note("timed region done: %.3f s for %d steps" % (dt, args.steps))
     events = loop.kernel_events
     loop.kernel_events = None
     if world > 1:
@@ -151,11 +163,14 @@ def main():
         dt = float(t.item())
 
     # the every-100-steps collect_failure sweep (2520 forward-only samples per image), timed apart
-    barrier()
-    t1 = time.perf_counter()
-    loop._refresh_failures()
-    barrier()
-    dt_sweep = time.perf_counter() - t1
+    dt_sweep = None
+    if not args.no_sweep:
+        barrier()
+        t1 = time.perf_counter()
+        loop._refresh_failures()
+        barrier()
+        dt_sweep = time.perf_counter() - t1
+        note("collect_failure sweep done: %.3f s" % dt_sweep)
     loop.close()
 
     if rank == 0:
@@ -180,9 +195,10 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(apply_ms, 4)},
-            "collect_failure_sweep_ms": round(dt_sweep * 1e3, 1),
-            "value_with_sweep_amortised": round(B * S * 100 / (100 * dt / args.steps + dt_sweep), 2),
         }
+        if dt_sweep is not None:
+            out["collect_failure_sweep_ms"] = round(dt_sweep * 1e3, 1)
+            out["value_with_sweep_amortised"] = round(B * S * 100 / (100 * dt / args.steps + dt_sweep), 2)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H)
         print(json.dumps(out))

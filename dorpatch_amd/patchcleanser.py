@@ -1,0 +1,237 @@
+"""PatchCleanser defence + certifier on the rectangle-table occlusion kernel
+(reference ``defenses/PatchCleanser.py:6-134``).
+
+The reference materialises ``(36,1,H,W)`` / ``(630,1,H,W)`` bool mask tensors and
+multiplies them into the image (``PatchCleanser.py:99-100``); here ``MaskWindow``
+holds ``(n, R, 4)`` int32 window tables and every masked batch is produced by
+``dp_apply_fwd`` (normalisation of a wrapped ``NormModel`` fused in), every argmax
+by ``dp_argmax``.  Bool tensors are still available (lazily) under the reference's
+attribute names for code that wants them.
+
+``PatchCleanserRecord`` / ``PatchCleanserResult`` keep the reference's attribute
+names and pickle under the module path ``defenses.PatchCleanser`` — the path the
+reference's ``adv_PC_{i}.pt`` files carry (``main.py:144-153``).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import masks, ops
+
+
+class MaskWindow(object):
+    """Rect-table twin of the reference ``MaskWindow`` (``PatchCleanser.py:6-59``).
+
+    ``rects``: table of ``mask_set``; ``double_rects``: table of ``double_mask_set``.
+    n_patch = 1: 36 single windows / 630 window pairs.  n_patch = 2: 630 pairs /
+    36 x 630 triples (the reference's ``combined_mask[None] * basic_mask[:, None]``,
+    index ``i * 630 + k`` = single window i with pair k)."""
+
+    def __init__(self, img_size, patch_ratio=0.03, n_patch=1, device=None):
+        self.img_size = img_size
+        self.mask_size, self.stride, self.window_size = masks.window_params(img_size, patch_ratio, n_patch)
+        self.num_mask_per_axis = masks.NUM_MASK_PER_AXIS
+        self.n_patch = n_patch
+        self.patch_ratio = patch_ratio
+        single = masks.single_rects(img_size, patch_ratio, n_patch)        # (36,1,4)
+        double = masks.double_rects(img_size, patch_ratio, n_patch)        # (630,2,4)
+        if n_patch == 1:
+            self.rects, self.double_rects = single, double
+        elif n_patch == 2:
+            n1, n2 = single.shape[0], double.shape[0]
+            triple = np.concatenate([np.repeat(single, n2, axis=0),
+                                     np.tile(double, (n1, 1, 1))], axis=1)   # (36*630, 3, 4)
+            self.rects, self.double_rects = double, triple.astype(np.int32)
+        else:
+            raise NotImplementedError
+        self._device = device
+        self._cache = {}
+        print("mask size: %d, window size: %d, stride: %d" % (self.mask_size, self.window_size, self.stride))
+
+    # ---- device tables (uploaded once per device)
+    def table(self, device, double=False):
+        key = (str(device), bool(double))
+        if key not in self._cache:
+            self._cache[key] = ops.upload_table(self.double_rects if double else self.rects, device)
+        return self._cache[key]
+
+    # ---- the reference's bool tensors, on demand (True = keep)
+    def _bool(self, name, rects):
+        if name not in self._cache:
+            dev = self._device if self._device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
+            self._cache[name] = masks.rects_to_bool(rects, self.img_size, device=dev)
+        return self._cache[name]
+
+    @property
+    def mask_set(self):
+        return self._bool("mask_set", self.rects)
+
+    @property
+    def double_mask_set(self):
+        return self._bool("double_mask_set", self.double_rects)
+
+    @property
+    def reverse_mask_set(self):
+        return ~self.mask_set
+
+
+class PatchCleanserRecord(object):
+    """``PatchCleanser.py:120-125``."""
+
+    def __init__(self, pred, certifiable, preds_1, preds_2):
+        self.prediction = pred          # robust prediction
+        self.certification = certifiable
+        self.preds_1 = preds_1          # one-masked predictions
+        self.preds_2 = preds_2          # two-masked predictions
+
+
+class PatchCleanserResult(object):
+    """``PatchCleanser.py:128-133``."""
+
+    def __init__(self, records):
+        self.predictions = np.stack([r.prediction for r in records])
+        self.certifications = np.stack([r.certification for r in records])
+        self.predictions_1 = np.stack([r.preds_1 for r in records])
+        self.predictions_2 = [r.preds_2 for r in records]
+
+
+# pickles written by either implementation name the reference's module path
+for _cls in (PatchCleanserRecord, PatchCleanserResult):
+    _cls.__module__ = "defenses.PatchCleanser"
+
+
+def _unwrap(model):
+    from .attack import _unwrap_model, _dp_norm
+    net, norm = _unwrap_model(model)
+    return net, _dp_norm(norm)
+
+
+class PatchCleanser(object):
+    """Drop-in for the reference ``PatchCleanser`` (``PatchCleanser.py:62-117``).
+
+    ``robust_predict(img, certify)`` keeps the single-image contract ``main.py:150-151``
+    uses; ``robust_predict_batch`` runs many images through the same two rounds with the
+    mask sweeps batched (one ``dp_apply_fwd`` launch per chunk of masked images)."""
+
+    def __init__(self, mask_window, model, result=None, max_batch=1024):
+        self.mask_window = mask_window
+        self.model = model
+        self.result = result
+        self.max_batch = int(max_batch)
+
+    # ---- PatchCleanser.py:99-100 (compat; the sweeps below never materialise masks)
+    def mask(self, img, msk):
+        return img * msk + 0.5 * ~msk
+
+    @torch.no_grad()
+    def _sweep(self, imgs, table, idx, idx2=None):
+        """argmax of model(occlude(imgs[b], idx[.., s])) -> (B, S) int32 device tensor.
+        idx (S,) shared by all images or (B,S)."""
+        net, dn = _unwrap(self.model)
+        B = imgs.shape[0]
+        S = idx.shape[-1]
+        per = max(1, self.max_batch // B)
+        outs = []
+        for s0 in range(0, S, per):
+            sl = slice(s0, min(S, s0 + per))
+            i1 = idx[..., sl].contiguous()
+            i2 = None if idx2 is None else idx2[..., sl].contiguous()
+            inp = ops.apply_fwd(imgs, table, i1, i2, dn)
+            outs.append(ops.argmax(net(inp).float().contiguous()).view(B, -1))
+        return torch.cat(outs, dim=1)
+
+    def _prep(self, img):
+        if not (isinstance(img, torch.Tensor) and img.is_cuda):
+            raise RuntimeError("PatchCleanser needs GPU tensors: the HIP occlusion kernel is the only "
+                               "implementation (no CPU fallback)")
+        if img.dim() == 3:
+            img = img[None]
+        return img.detach().contiguous().float()
+
+    def robustness_certificate(self, img, label, batch_size=64):
+        """``PatchCleanser.py:102-112``: all two-mask predictions equal ``label``?
+        ``batch_size`` is accepted for signature parity; the sweep is chunked by ``max_batch``."""
+        imgs = self._prep(img)
+        dev = imgs.device
+        table = self.mask_window.table(dev, double=True)
+        idx = torch.arange(table.shape[0], dtype=torch.int32, device=dev)
+        preds = self._sweep(imgs, table, idx)[0]
+        consistent = preds == int(label)
+        return bool(consistent.all().item()), consistent
+
+    def robust_predict(self, img, certify=False):
+        """``PatchCleanser.py:68-97`` for one image (3,H,W) or (1,3,H,W)."""
+        return self.robust_predict_batch(self._prep(img), certify)[0]
+
+    @torch.no_grad()
+    def robust_predict_batch(self, imgs, certify=False):
+        imgs = self._prep(imgs)
+        dev, B = imgs.device, imgs.shape[0]
+        mw = self.mask_window
+        t1 = mw.table(dev, double=False)
+        n1 = t1.shape[0]
+        idx1 = torch.arange(n1, dtype=torch.int32, device=dev)
+        preds_1_all = self._sweep(imgs, t1, idx1).cpu().numpy()            # first-round masking (:70-72)
+        need2 = []          # images whose two-mask sweep is needed
+        majority = []
+        for b in range(B):
+            labels, counts = np.unique(preds_1_all[b], return_counts=True)   # sorted, like torch.unique on GPU
+            majority.append(int(labels[counts.argmax()]))
+            if len(labels) == 1 or certify:
+                need2.append(b)
+        preds_2_all = {}
+        if need2:
+            t2 = mw.table(dev, double=True)
+            idx2 = torch.arange(t2.shape[0], dtype=torch.int32, device=dev)
+            p2 = self._sweep(imgs[need2].contiguous(), t2, idx2).cpu().numpy()
+            preds_2_all = {b: p2[k] for k, b in enumerate(need2)}
+        records = []
+        for b in range(B):
+            preds_1 = preds_1_all[b]
+            labels = np.unique(preds_1)
+            label_majority = majority[b]
+            pred = label_majority
+            preds_2 = None
+            if len(labels) == 1:                                            # :77-78
+                consistent = preds_2_all[b] == pred
+                certifiable, preds_2 = bool(consistent.all()), consistent
+            else:                                                           # :79-90 second-round masking
+                certifiable = False
+                minority = np.nonzero(preds_1 != label_majority)[0]
+                # masked image k (first-round window k) re-masked by every window j
+                i_first = torch.as_tensor(np.repeat(minority, n1), dtype=torch.int32, device=dev)
+                i_second = torch.as_tensor(np.tile(np.arange(n1), len(minority)), dtype=torch.int32, device=dev)
+                p12 = self._sweep(imgs[b:b + 1], t1, i_first, i_second)[0].cpu().numpy().reshape(len(minority), n1)
+                for label in labels:                                        # ascending, later labels override
+                    if label == label_majority:
+                        continue
+                    for row, k in enumerate(minority):
+                        if preds_1[k] == label and (p12[row] == label).all():
+                            pred = int(label)
+            if certify and preds_2 is None:                                 # :93-94
+                preds_2 = preds_2_all[b] == label_majority
+            records.append(PatchCleanserRecord(pred, certifiable, preds_1.astype(np.int64),
+                                               None if preds_2 is None else np.asarray(preds_2)))
+        return records
+
+    def reset(self):
+        self.result = None
+
+    def collect(self, records):
+        self.result = PatchCleanserResult(records)
+
+
+def certified_metrics(records, y, target=None):
+    """The metric block of ``main.py:168-184`` for one defence: ``records`` a list of
+    ``PatchCleanserRecord``, ``y`` true labels, ``target`` attack targets (targeted) or None.
+    Returns percentages: acc@PC, certified_ACC@PC, certified_ASR@PC."""
+    res = PatchCleanserResult(records)
+    y = np.asarray(y)
+    p, c = res.predictions, res.certifications
+    out = {"acc_PC": float((p == y).mean() * 100), "certified_acc_PC": float(((p == y) & c).mean() * 100)}
+    if target is not None:
+        out["certified_asr_PC"] = float(((p == np.asarray(target)) & c).mean() * 100)
+    else:
+        out["certified_asr_PC"] = float(((p != y) & c).mean() * 100)
+    return out

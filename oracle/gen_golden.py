@@ -25,6 +25,8 @@ Fixtures
                    returned mask / pattern: pins the host bookkeeping (attack.py:249-316).
 ``trace_56_fail.npz``  same with lr = 0.1 / a harder toy: stage 0 runs past iteration 1000, so the
                    failure-biased sampling branch (attack.py:193-199) is exercised.
+``patchcleanser_56.npz``  records of the reference PatchCleanser.robust_predict(certify=True) on a
+                   location-sensitive toy net (all four decision branches) + n_patch=2 mask checksums.
 ``geometry.npz``   MaskWindow geometry for 56/224/384 and mask-universe checksums.
 """
 import contextlib
@@ -222,8 +224,41 @@ def make_geometry_fixture(path):
     return out
 
 
+PC_CASES = [(0, 0.03), (2, 0.03), (2, 0.12), (3, 0.12), (5, 0.03), (5, 0.12), (11, 0.03), (12, 0.03),
+            (15, 0.12), (21, 0.12), (24, 0.03), (27, 0.12)]
+
+
+def make_patchcleanser_fixture(path, H=56):
+    """Records of the UNMODIFIED reference PatchCleanser.robust_predict(img, certify=True)
+    (PatchCleanser.py:68-97) on seeded blob images and the location-sensitive PeakNet:
+    covers unanimous+certified, unanimous+uncertified, disagreement and second-round correction.
+    Also the n_patch = 2 mask-set checksums (PatchCleanser.py:35-38)."""
+    ref = ref_shim.load_reference()
+    net = toy_models.NormModel(toy_models.make_peaky(), toy_models.Normalize())
+    out = {"H": H, "cases": np.array(PC_CASES, dtype=np.float64)}
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        for k, (seed, r) in enumerate(PC_CASES):
+            img = toy_models.blob_image(H, int(seed))
+            pc = ref.PatchCleanser.PatchCleanser(ref.PatchCleanser.MaskWindow(H, r, 1), net)
+            rec = pc.robust_predict(img, True)
+            out["c%d_pred" % k] = np.int64(rec.prediction)
+            out["c%d_cert" % k] = np.bool_(rec.certification)
+            out["c%d_preds_1" % k] = rec.preds_1
+            out["c%d_preds_2" % k] = rec.preds_2
+            out["c%d_logits" % k] = net(img[None]).numpy()
+        mw2 = ref.PatchCleanser.MaskWindow(H, 0.06, 2)
+    w = torch.arange(H * H, dtype=torch.float64).view(1, 1, H, H) + 1.0
+    for name, ms in (("np2_single", mw2.mask_set), ("np2_double", mw2.double_mask_set)):
+        out[name + "_count"] = ms.sum((1, 2, 3)).numpy()
+        out[name + "_wsum"] = (ms * w).sum((1, 2, 3)).numpy()
+    out["np2_params"] = np.array([mw2.mask_size, mw2.stride, mw2.window_size])
+    np.savez_compressed(path, **out)
+    return out
+
+
 def main():
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    make_patchcleanser_fixture(os.path.join(GOLDEN_DIR, "patchcleanser_56.npz"))
     make_geometry_fixture(os.path.join(GOLDEN_DIR, "geometry.npz"))
     make_steps_fixture(56, 8, 1.0, os.path.join(GOLDEN_DIR, "steps_56.npz"))
     make_steps_fixture(224, 4, 1.0, os.path.join(GOLDEN_DIR, "steps_224.npz"), n=1)

@@ -207,3 +207,41 @@ def collect_failure(model, adv_x, y, universe, targeted, batch_size=128):
         bad = ~hit if targeted else hit
         failed.extend((bad.nonzero().view(-1) + j0).tolist())
     return failed
+
+
+# ----------------------------------------------------------------------------- next-2
+@torch.no_grad()
+def patchcleanser_predict(model, img, single, double, certify=False, batch_size=64):
+    """PatchCleanser.robust_predict (PatchCleanser.py:68-97) + robustness_certificate (:102-112)
+    for one image (3,H,W); ``single`` (36,1,H,W) / ``double`` (630,1,H,W) bool keep-masks.
+    Returns (prediction, certifiable, preds_1, preds_2) like PatchCleanserRecord's fields."""
+    def mask(im, msk):                                                      # :99-100
+        return im * msk + 0.5 * ~msk
+
+    def certificate(label):                                                 # :102-112
+        preds = []
+        for i in range(math.ceil(len(double) / batch_size)):
+            preds.append(model(mask(img, double[i * batch_size:(i + 1) * batch_size])).argmax(1))
+        consistent = torch.cat(preds) == label
+        return bool(consistent.all().item()), consistent
+
+    masked = mask(img, single)                                              # :70-71
+    preds_1 = model(masked).argmax(1)                                       # :72
+    preds_2 = None
+    labels, counts = preds_1.unique(sorted=True, return_counts=True)        # :74 (GPU unique sorts)
+    label_majority = labels[counts.argmax()].item()                         # :75
+    pred = label_majority
+    if len(labels) == 1:                                                    # :78-79
+        certifiable, preds_2 = certificate(pred)
+    else:
+        certifiable = False
+        for label in labels:                                                # :82-90
+            if label == label_majority:
+                continue
+            for masked_img in masked[preds_1 == label]:
+                preds_1_2 = model(mask(masked_img, single)).argmax(-1)
+                if (preds_1_2 == label).all():
+                    pred = label.item()
+    if certify and preds_2 is None:                                         # :93-94
+        preds_2 = certificate(label_majority)[1]
+    return pred, certifiable, preds_1.numpy(), None if preds_2 is None else preds_2.numpy()

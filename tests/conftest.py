@@ -57,3 +57,8 @@ def golden_geometry():
 @pytest.fixture(scope="session", params=["trace_56.npz", "trace_56_fail.npz"])
 def golden_trace(request):
     return load_golden(request.param)
+
+
+@pytest.fixture(scope="session")
+def golden_patchcleanser():
+    return load_golden("patchcleanser_56.npz")

@@ -1,0 +1,357 @@
+"""GPU parity of the whole hot loop (DorPatch.generate / HotLoop.step, through the C ABI)
+against (1) fixtures recorded from the UNMODIFIED reference (tests/golden) and (2) the CPU oracle.
+
+fp32 tolerances: forward values rtol 1e-5..1e-4 (summation order only); gradients
+rtol 1e-3 of the gradient scale; the signed update may flip where |grad| ~ ulp, so updated
+parameters are compared by the fraction of differing pixels (SURVEY §7 "sign() amplifies ulp noise")."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from dorpatch_amd import masks, ops  # noqa: E402
+from dorpatch_amd.attack import DorPatch, HotLoop  # noqa: E402
+from dorpatch_amd.patchcleanser import MaskWindow, PatchCleanser  # noqa: E402
+from oracle import restatement as R  # noqa: E402
+from oracle import toy_models  # noqa: E402
+
+DEV = "cuda:0"
+
+
+class FixedDraw(object):
+    """Feeds recorded mask indices to the product's sampler (np.random.choice signature)."""
+
+    def __init__(self, rows):
+        self.rows = list(rows)
+
+    def choice(self, a, n, replace=False):
+        return np.asarray(self.rows.pop(0)).copy()
+
+
+def _toy(gain=1.0, dev=DEV):
+    return toy_models.NormModel(toy_models.make_toy(gain=gain), toy_models.Normalize()).to(dev)
+
+
+def _loop(model, x, y, S, extras, *, budget=0.12, targeted=True, lr=1e-2, eps=4.0, tmp="t/cfg/sub", mb=256,
+          dual=False):
+    return HotLoop(DorPatch(micro_batch=mb, verbose=False), model, x, budget, 10, tmp, 0, y, targeted, lr, 1e-1,
+                   0, 1, 10 ** 6, 7, 'topk', 2, S, 1e-3, 1e-3, eps, dual, dict(failure_refresh=10 ** 9, **extras))
+
+
+def _grab(store):
+    def hook(d):
+        store.clear()
+        store.update({k: (v.detach().cpu().clone() if torch.is_tensor(v) else v) for k, v in d.items()})
+    return hook
+
+
+def _replay_golden_steps(g, rtol_g):
+    H, S = int(g["H"]), int(g["S"])
+    model = _toy(float(g["gain"]))
+    x = torch.from_numpy(g["x"]).to(DEV)
+    for n in range(int(g["n_steps"])):
+        p = "s%d_" % n
+        got = {}
+        loop = _loop(model, x, torch.tensor([int(g[p + "y"])], device=DEV), S,
+                     dict(init_mask=torch.from_numpy(g[p + "mask"]), init_pattern=torch.from_numpy(g[p + "pattern"]),
+                          rngs=[FixedDraw([g[p + "idx"]])], step_hook=_grab(got)), eps=float(g["eps"]))
+        loop.stage = int(g[p + "stage"])
+        st = loop.img[0]
+        st.structured, st.coeff_group_lasso = float(g[p + "structured"]), float(g[p + "coeff_group_lasso"])
+        st.lr_current = np.float32(g[p + "lr"])
+        st.loss_best = np.float32(-1e30)       # never "improves": lr stays what the reference used next
+        st.not_decay = 0
+        loop.step(max(1, int(g[p + "i"])))
+        torch.cuda.synchronize()
+        loop.close()
+        np.testing.assert_allclose(got["adv_x"].numpy(), g[p + "adv_x"], atol=1e-6, rtol=0)
+        np.testing.assert_allclose(got["loss_adv"].reshape(-1), g[p + "loss_adv"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(got["loss_struc"][0], g[p + "loss_struc"], rtol=2e-5)
+        gp, want = got["grad_pattern"].numpy(), g[p + "grad_pattern"]
+        np.testing.assert_allclose(gp, want, rtol=rtol_g, atol=rtol_g * np.abs(want).max())
+        if loop.stage == 0:
+            np.testing.assert_allclose(got["group_lasso"][0], g[p + "group_lasso"], rtol=2e-5)
+            np.testing.assert_allclose(got["density"][0], g[p + "density"], rtol=1e-4)
+            gm, want = got["grad_mask"].numpy(), g[p + "grad_mask"]
+            assert np.array_equal(np.isnan(gm), np.isnan(want))
+            np.testing.assert_allclose(np.nan_to_num(gm), np.nan_to_num(want), rtol=rtol_g,
+                                       atol=rtol_g * np.nanmax(np.abs(want)))
+        if float(g[p + "lr_next"]) == float(g[p + "lr"]):
+            for name, new in (("new_pattern", loop.adv_pattern), ("new_mask", loop.adv_mask)):
+                diff = np.abs(new.cpu().numpy() - g[p + name])
+                assert (diff > 1e-6).mean() < 2e-3, (name, n, (diff > 1e-6).mean())
+
+
+def test_hot_loop_replays_reference_steps_56(golden_steps_56):
+    _replay_golden_steps(golden_steps_56, 1e-3)
+
+
+def test_hot_loop_replays_reference_steps_224(golden_steps_224):
+    _replay_golden_steps(golden_steps_224, 1e-3)
+
+
+def test_generate_trajectory_tracks_reference(golden_trace, tmp_path, monkeypatch):
+    """Full DorPatch.generate on the GPU, same seeds as the recorded reference run: the
+    sampled indices must be IDENTICAL at every step (same RNG consumption), the control trace
+    (lr, failure counts) must track the reference while the trajectories are still numerically
+    close, and the returned mask must be a valid binary cell mask within budget."""
+    t = golden_trace
+    H, S = int(t["H"]), int(t["S"])
+    monkeypatch.chdir(tmp_path)
+    model = _toy(float(t["gain"]))
+    x = torch.from_numpy(t["x"]).to(DEV)
+    y = torch.from_numpy(t["y0"]).to(DEV)
+    n_check = 60
+    seen = []
+
+    def hook(d):
+        if len(seen) < n_check:
+            seen.append((d["stage"], d["i"], d["idx"][0].copy(), d["loss_adv"][0].copy(), float(d["lr"][0])))
+
+    torch.manual_seed(1234)
+    np.random.seed(1234)
+    atk = DorPatch(verbose=False)
+    mask, pattern = atk.generate(model, x, 0.12, 10, "res/cfg/sub", 0, y=y, targeted=True, lr=float(t["lr0"]),
+                                 sampling_size=S, eps=float(t["eps"]), max_iterations=int(t["max_iterations"]),
+                                 step_hook=hook)
+    for k, (stage, i, idx, la, lr) in enumerate(seen):
+        assert (stage, i) == (int(t["stage"][k]), int(t["i"][k]))
+        assert np.array_equal(idx, t["idx"][k]), k          # identical RNG stream
+        assert np.float32(lr) == t["lr"][k]
+    # early steps: losses agree tightly before sign-flip noise can compound
+    for k in range(5):
+        np.testing.assert_allclose(seen[k][3], t["loss_adv"][k], rtol=5e-3, atol=5e-4)
+    m = mask.cpu().numpy()
+    assert mask.shape == (1, 1, H, H) and pattern.shape == (1, 3, H, H) and mask.is_cuda
+    assert set(np.unique(m)) <= {0.0, 1.0}
+    cells = m.reshape(1, 1, H // 7, 7, H // 7, 7)
+    assert (cells.min(axis=(3, 5)) == cells.max(axis=(3, 5))).all()
+    assert m.sum() <= np.floor(H * H * 0.12 / 49) * 49
+    assert 0.0 <= float(pattern.min()) and float(pattern.max()) <= 1.0
+    # stage-0 cache written where the reference writes it (attack.py:351-356)
+    assert os.path.exists("res/cfg/adv_mask_0.pt") and os.path.exists("res/cfg/adv_pattern_0.pt")
+    # end metric: the attack reaches the reference's outcome on the full mask universe
+    adv = x + ops.blend(mask, pattern, x, float(t["eps"]), add_x=False)[0]
+    fails = atk.collect_failure(adv, y, ops.upload_table(masks.universe_rects(H, 2), DEV), True, model)
+    adv_ref = torch.from_numpy(t["x"]) + R.clip(torch.from_numpy(t["final_mask"]), torch.from_numpy(t["final_pattern"]),
+                                                torch.from_numpy(t["x"]), float(t["eps"]))
+    fails_ref = R.collect_failure(_toy(float(t["gain"]), "cpu"), adv_ref, torch.from_numpy(t["y0"]),
+                                  R.mask_universe(H, 2), True)
+    assert abs(len(fails) - len(fails_ref)) <= 0.1 * 2520, (len(fails), len(fails_ref))
+
+
+def test_stage0_cache_is_reused(tmp_path, monkeypatch):
+    """attack.py:134-141: an existing stage-0 cache skips stage 0 entirely."""
+    monkeypatch.chdir(tmp_path)
+    H = 56
+    model = _toy()
+    x = torch.rand(1, 3, H, H, generator=torch.Generator().manual_seed(3)).to(DEV)
+    os.makedirs("res/cfg", exist_ok=True)
+    m0 = torch.rand(1, 1, H, H, generator=torch.Generator().manual_seed(4))
+    p0 = torch.rand(1, 3, H, H, generator=torch.Generator().manual_seed(5))
+    torch.save(m0.to(DEV), "res/cfg/adv_mask_7.pt")
+    torch.save(p0.to(DEV), "res/cfg/adv_pattern_7.pt")
+    stages = []
+    mask, _ = DorPatch(verbose=False).generate(model, x, 0.12, 10, "res/cfg/sub", 7, y=torch.tensor([3], device=DEV),
+                                               targeted=True, sampling_size=4, max_iterations=3,
+                                               step_hook=lambda d: stages.append(d["stage"]))
+    assert stages == [1, 1, 1]
+    want = R.patch_selection(m0, 0.12)
+    assert torch.equal(mask.cpu(), want)
+
+
+def test_batch_is_independent_single_image_problems():
+    """A B-image batch == B separate B = 1 problems (same draws, own state): per-image
+    quantities agree to fp32 round-off (the backbone's batch size differs, nothing else)."""
+    H, S, B = 56, 8, 3
+    model = _toy(2.0)
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(B, 3, H, H, generator=g)
+    m0, p0 = torch.rand(B, 1, H, H, generator=g), torch.rand(B, 3, H, H, generator=g)
+    y = torch.tensor([1, 4, 7])
+    rows = [np.random.RandomState(5 + b).choice(2520, S, replace=False) for b in range(B)]
+    got_b = {}
+    loop = _loop(model, x.to(DEV), y.to(DEV), S, dict(init_mask=m0, init_pattern=p0, step_hook=_grab(got_b),
+                                                      rngs=[FixedDraw([rows[b]]) for b in range(B)]))
+    loop.step(1)
+    pat_b, mask_b = loop.adv_pattern.cpu(), loop.adv_mask.cpu()
+    loop.close()
+    for b in range(B):
+        got = {}
+        l1 = _loop(model, x[b:b + 1].to(DEV), y[b:b + 1].to(DEV), S,
+                   dict(init_mask=m0[b:b + 1], init_pattern=p0[b:b + 1], step_hook=_grab(got),
+                        rngs=[FixedDraw([rows[b]])]))
+        l1.step(1)
+        np.testing.assert_allclose(got_b["loss_adv"][b], got["loss_adv"][0], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(got_b["grad_pattern"][b].numpy(), got["grad_pattern"][0].numpy(), rtol=1e-4,
+                                   atol=1e-5 * float(got["grad_pattern"].abs().max()))
+        assert ((pat_b[b] - l1.adv_pattern.cpu()[0]).abs() > 1e-6).float().mean() < 2e-3
+        assert ((mask_b[b] - l1.adv_mask.cpu()[0]).abs() > 1e-6).float().mean() < 2e-3
+        l1.close()
+
+
+@pytest.mark.parametrize("mb", [3, 8, 256])
+def test_micro_batching_does_not_change_the_step(mb):
+    """Gradient accumulation over micro-batches of the S samples / of images keeps the result."""
+    H, S, B = 56, 8, 2
+    model = _toy(2.0)
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(B, 3, H, H, generator=g)
+    m0, p0 = torch.rand(B, 1, H, H, generator=g), torch.rand(B, 3, H, H, generator=g)
+    rows = [np.random.RandomState(b).choice(2520, S, replace=False) for b in range(B)]
+    outs = []
+    for micro in (mb, 10 ** 6):
+        got = {}
+        loop = _loop(model, x.to(DEV), torch.tensor([2, 3], device=DEV), S,
+                     dict(init_mask=m0, init_pattern=p0, step_hook=_grab(got),
+                          rngs=[FixedDraw([rows[b]]) for b in range(B)]), mb=micro)
+        loop.step(1)
+        loop.close()
+        outs.append(got)
+    np.testing.assert_allclose(outs[0]["loss_adv"], outs[1]["loss_adv"], rtol=1e-5, atol=1e-6)
+    scale = float(outs[1]["g_adv"].abs().max())
+    np.testing.assert_allclose(outs[0]["g_adv"].numpy(), outs[1]["g_adv"].numpy(), rtol=1e-4, atol=1e-5 * scale)
+
+
+def test_dual_masks_match_oracle():
+    """attack.py:208-218 (`dual=True`): two sampled masks per EOT sample."""
+    H, S = 56, 6
+    model = _toy(2.0)
+    g = torch.Generator().manual_seed(13)
+    x, m0, p0 = torch.rand(1, 3, H, H, generator=g), torch.rand(1, 1, H, H, generator=g), torch.rand(1, 3, H, H, generator=g)
+    i1, i2 = np.random.RandomState(1).choice(2520, S, False), np.random.RandomState(2).choice(2520, S, False)
+    got = {}
+    loop = _loop(model, x.to(DEV), torch.tensor([3], device=DEV), S,
+                 dict(init_mask=m0, init_pattern=p0, step_hook=_grab(got), rngs=[FixedDraw([i1, i2])]), dual=True)
+    loop.step(1)
+    loop.close()
+    uni = R.mask_universe(H, 2)
+    want = R.eot_step(_toy(2.0, "cpu"), x, m0, p0, torch.tensor([3]), uni[torch.from_numpy(i1)], stage=0,
+                      targeted=True, n_classes=10, keep_dual=uni[torch.from_numpy(i2)])
+    np.testing.assert_allclose(got["loss_adv"][0], want["loss_adv"][0].numpy(), rtol=1e-4, atol=1e-5)
+    gw = want["grad_pattern"].numpy()
+    np.testing.assert_allclose(got["grad_pattern"].numpy(), gw, rtol=1e-3, atol=1e-3 * np.abs(gw).max())
+
+
+def test_untargeted_switches_to_targeted_at_iteration_500():
+    """attack.py:169-182 with the evidently intended set_target(preds_adv, y) (the reference's
+    call is missing an argument — SURVEY §0): label := majority wrong class, criterion targeted."""
+    H, S = 56, 8
+    model = _toy(4.0)
+    x = torch.rand(1, 3, H, H, generator=torch.Generator().manual_seed(21)).to(DEV)
+    loop = _loop(model, x, None, S, dict(switch_iteration=3), targeted=False, lr=0.05)
+    y0 = loop.img[0].y
+    loop.step(1)
+    loop.step(2)
+    preds = loop._gather_pred().reshape(-1)
+    wrong = preds[preds != y0]
+    loop.step(3)
+    st = loop.img[0]
+    assert st.flag_targeted
+    if wrong.size:
+        vals, counts = np.unique(wrong, return_counts=True)
+        assert st.crit_targeted and st.y == int(vals[np.argmax(counts)])
+        assert int(loop.y[0]) == st.y
+    else:
+        assert not st.crit_targeted and st.y == y0
+    loop.close()
+
+
+def test_collect_failure_matches_oracle():
+    """attack.py:384-406 on the rectangle table, B = 2 images with different labels / modes."""
+    H = 56
+    model = _toy(3.0)
+    cpu = _toy(3.0, "cpu")
+    adv = torch.rand(2, 3, H, H, generator=torch.Generator().manual_seed(31))
+    with torch.no_grad():
+        clean = cpu(adv).argmax(-1)
+    table = ops.upload_table(masks.universe_rects(H, 2), DEV)
+    from dorpatch_amd.attack import _collect_failure, _unwrap_model
+    net, norm = _unwrap_model(model)
+    y = torch.stack([clean[0], (clean[1] + 1) % 10])
+    lists = _collect_failure(net, norm, adv.to(DEV), y.to(DEV), table, np.array([False, True]), 128)
+    uni = R.mask_universe(H, 2)
+    for b, targeted in enumerate((False, True)):
+        want = R.collect_failure(cpu, adv[b:b + 1], y[b:b + 1], uni, targeted)
+        diff = set(lists[b]) ^ set(want)
+        assert len(diff) <= 2, (b, len(diff))       # argmax near-ties under fp32 reordering only
+    single = DorPatch(verbose=False).collect_failure(adv[:1].to(DEV), y[:1].to(DEV), table, False, model)
+    assert single == lists[0]
+
+
+def test_patchcleanser_matches_reference_records(golden_patchcleanser):
+    """defenses/PatchCleanser.py:68-112 through dp_apply_fwd + dp_argmax: records identical to the
+    UNMODIFIED reference's on the pinned cases (all four decision branches)."""
+    g = golden_patchcleanser
+    H = int(g["H"])
+    net = toy_models.NormModel(toy_models.make_peaky(), toy_models.Normalize()).to(DEV)
+    by_ratio = {}
+    for k, (seed, r) in enumerate([(int(s), float(r)) for s, r in g["cases"]]):
+        img = toy_models.blob_image(H, seed).to(DEV)
+        pc = by_ratio.setdefault(r, PatchCleanser(MaskWindow(H, r, 1), net))
+        rec = pc.robust_predict(img, True)
+        assert rec.prediction == int(g["c%d_pred" % k]) and rec.certification == bool(g["c%d_cert" % k]), (seed, r)
+        assert np.array_equal(rec.preds_1, g["c%d_preds_1" % k]) and np.array_equal(rec.preds_2, g["c%d_preds_2" % k])
+        rec_nc = pc.robust_predict(img[None], False)
+        assert rec_nc.prediction == rec.prediction and rec_nc.certification == rec.certification
+        if len(np.unique(rec.preds_1)) > 1:
+            assert rec_nc.preds_2 is None
+    # batched sweep == one-by-one
+    r = 0.03
+    seeds = [s for s, rr in [(int(s), float(rr)) for s, rr in g["cases"]] if rr == r]
+    imgs = torch.stack([toy_models.blob_image(H, s) for s in seeds]).to(DEV)
+    recs = by_ratio[r].robust_predict_batch(imgs, True)
+    for s, rec in zip(seeds, recs):
+        one = by_ratio[r].robust_predict(toy_models.blob_image(H, s).to(DEV), True)
+        assert rec.prediction == one.prediction and rec.certification == one.certification
+        assert np.array_equal(rec.preds_1, one.preds_1) and np.array_equal(rec.preds_2, one.preds_2)
+    cert, cons = by_ratio[r].robustness_certificate(imgs[0], recs[0].prediction)
+    assert cons.shape == (630,) and isinstance(cert, bool)
+
+
+# ---------------------------------------------------------------- full-size, size-independent properties
+def test_config2_size_properties():
+    """BASELINE configs[1] geometry (64 images x 32 masks @224, 1.23 GB of masked images): the oracle
+    cannot run this in seconds, so check size-independent properties of the occlusion kernels:
+      * every output pixel is either the (normalised) source pixel or exactly the fill value 0,
+        and the occluded count equals the analytic window-union area;
+      * backward is the adjoint of forward: <apply_fwd(x), G> == <x, apply_bwd(G)> (linearity);
+      * apply_bwd of an all-ones G counts, per pixel, the samples that keep it."""
+    B, S, H = 64, 32, 224
+    table_np = masks.universe_rects(H, 2)
+    table = ops.upload_table(table_np, DEV)
+    rng = np.random.RandomState(0)
+    idx_np = np.stack([rng.choice(2520, S, replace=False) for _ in range(B)])
+    idx = torch.from_numpy(idx_np).int().to(DEV)
+    x = torch.rand(B, 3, H, H, device=DEV) * 0.98 + 0.01
+    norm = ops.make_norm([0.5] * 3, [0.5] * 3, 0.5)
+    out = ops.apply_fwd(x, table, idx, None, norm).view(B, S, 3, H, H)
+    src = ((x - 0.5) / 0.5)[:, None]
+    occluded = out == 0
+    assert bool(((out == src) | occluded).all())
+    # analytic union area of the two windows of every sampled mask
+    t = table_np[idx_np].astype(np.int64)                                     # (B,S,2,4)
+    area = lambda q: np.clip(q[..., 1] - q[..., 0], 0, None) * np.clip(q[..., 3] - q[..., 2], 0, None)
+    inter = np.stack([np.maximum(t[..., 0, 0], t[..., 1, 0]), np.minimum(t[..., 0, 1], t[..., 1, 1]),
+                      np.maximum(t[..., 0, 2], t[..., 1, 2]), np.minimum(t[..., 0, 3], t[..., 1, 3])], -1)
+    union = area(t[..., 0, :]) + area(t[..., 1, :]) - area(inter)
+    got = occluded[:, :, 0].sum((2, 3)).cpu().numpy()
+    assert np.array_equal(got, union)
+    del occluded, src
+    G = torch.randn(B * S, 3, H, H, device=DEV)
+    gx = ops.apply_bwd(G, table, idx, None, norm, B=B)
+    lhs = (out.view(-1).double() * G.view(-1).double()).sum().item()
+    # forward is affine in x: out = A(x - 0.5)/0.5 on kept pixels, 0 elsewhere => <out, G> = <x - 0.5, A^T G / 0.5>
+    rhs = ((x - 0.5).double() * gx.double()).sum().item()
+    # |lhs| ~ 1e4 (3e8 random terms); fp32 round-off of the S-sums contributes ~1e-2
+    assert abs(lhs - rhs) <= 1.0 + 1e-6 * abs(lhs), (lhs, rhs)
+    del out, G
+    ones = torch.ones(B * S, 3, H, H, device=DEV)
+    cnt = ops.apply_bwd(ones, table, idx, None, ops.RAW_NORM, B=B)
+    keep = masks.rects_to_bool(table_np, H, device=DEV)                       # (2520,1,H,W)
+    want = torch.stack([keep[torch.from_numpy(idx_np[b]).to(DEV)].sum(0) for b in range(B)]).float()
+    assert torch.equal(cnt, want.expand(B, 3, H, H))

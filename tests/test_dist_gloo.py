@@ -1,0 +1,107 @@
+"""Multi-rank EOT sharding protocol on CPU: world_size 2 and 4 over `gloo`.
+
+The HIP kernels need a GPU, so each rank's per-shard compute is done here by the CPU oracle;
+what is under test is the product's sharding/collective layer (`dorpatch_amd.dist`) and the
+arithmetic contract HotLoop relies on: with upstream = 1/S_total, the all-reduced sum of the
+per-shard input gradients equals the unsharded gradient, regularisers are added once after the
+reduce, the gathered loss columns land in sample order, and the failure bitmap OR-reduces."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dorpatch_amd import dist as dp_dist
+from oracle import restatement as R
+from oracle import toy_models
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _problem():
+    H, S, B = 56, 8, 2
+    g = torch.Generator().manual_seed(3)
+    x, m, p = torch.rand(B, 3, H, H, generator=g), torch.rand(B, 1, H, H, generator=g), torch.rand(B, 3, H, H, generator=g)
+    y = torch.tensor([2, 7])
+    idx = np.random.RandomState(0).choice(2520, S, replace=False)
+    net = toy_models.NormModel(toy_models.make_toy(gain=3.0), toy_models.Normalize())
+    return H, S, B, x, m, p, y, idx, net
+
+
+def _shard_grad(net, adv_x, y, keep, S_total):
+    """d/d adv_x of sum_b sum_{s in shard} loss_adv[b,s] / S_total, and the loss columns."""
+    B = adv_x.shape[0]
+    a = adv_x.detach().clone().requires_grad_(True)
+    masked = R.occlude(a, keep)
+    logits = net(masked.reshape((-1,) + masked.shape[2:]))
+    Sl = keep.shape[0]
+    loss = torch.stack([R.cw_loss(logits[b * Sl:(b + 1) * Sl], y[b].repeat(Sl), 10, True, 0.1) for b in range(B)])
+    (loss.sum() / S_total).backward()
+    return a.grad.detach(), loss.detach()
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pg = dist.group.WORLD
+        assert dp_dist.world_rank(pg) == (world, rank)
+        H, S, B, x, m, p, y, idx, net = _problem()
+        adv_x = (R.clip(m, p, x, 4.0) + x).detach()
+        # every rank occludes with rank 0's draw (HotLoop.step broadcasts idx)
+        idx_t = torch.from_numpy(idx.copy() if rank == 0 else np.zeros_like(idx)).int()
+        dp_dist.broadcast_(idx_t, pg)
+        assert np.array_equal(idx_t.numpy(), idx)
+        lo, hi = dp_dist.shard_bounds(S, world, rank)
+        keep = R.mask_universe(H, 2)[torch.from_numpy(idx[lo:hi])]
+        g_local, loss_local = _shard_grad(net, adv_x, y, keep, S)
+        g = dp_dist.allreduce_sum_(g_local.clone(), pg)              # THE data-path collective
+        loss = dp_dist.gather_columns(loss_local, pg)                # (B, S) in sample order
+        # failure bitmap: each rank sweeps its slice of the universe, OR-reduce
+        n_mask = 2520
+        mlo, mhi = dp_dist.mask_bounds(n_mask, world, rank)
+        bitmap = torch.zeros((B, n_mask), dtype=torch.int32)
+        bitmap[:, mlo:mhi] = (torch.arange(mlo, mhi) % 7 == 0).int()
+        dp_dist.allreduce_max_(bitmap, pg)
+        torch.save(dict(g=g, loss=loss, bitmap=bitmap), os.path.join(out_dir, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_step_equals_unsharded(world, tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    H, S, B, x, m, p, y, idx, net = _problem()
+    adv_x = (R.clip(m, p, x, 4.0) + x).detach()
+    g_want, loss_want = _shard_grad(net, adv_x, y, R.mask_universe(H, 2)[torch.from_numpy(idx)], S)
+    outs = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(world)]
+    scale = float(g_want.abs().max())
+    for o in outs:
+        np.testing.assert_allclose(o["g"].numpy(), g_want.numpy(), rtol=1e-4, atol=1e-6 * scale)
+        np.testing.assert_allclose(o["loss"].numpy(), loss_want.numpy(), rtol=1e-5, atol=1e-6)
+        assert torch.equal(o["bitmap"], (torch.arange(2520) % 7 == 0).int().expand(B, 2520))
+    # all ranks hold bit-identical reduced tensors => identical signed updates everywhere
+    for o in outs[1:]:
+        assert torch.equal(o["g"], outs[0]["g"]) and torch.equal(o["loss"], outs[0]["loss"])
+
+
+def test_shard_bounds_and_mask_bounds():
+    assert [dp_dist.shard_bounds(32, 4, r) for r in range(4)] == [(0, 8), (8, 16), (16, 24), (24, 32)]
+    with pytest.raises(ValueError):
+        dp_dist.shard_bounds(30, 4, 0)
+    spans = [dp_dist.mask_bounds(2520, 8, r) for r in range(8)]
+    assert spans[0] == (0, 315) and spans[-1] == (2205, 2520)
+    assert sum(b - a for a, b in spans) == 2520
+    assert dp_dist.world_rank(None) == (1, 0)
+    t = torch.ones(3)
+    assert dp_dist.allreduce_sum_(t, None) is t and dp_dist.gather_columns(t, None) is t
