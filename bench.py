@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the separately-timed collect_failure sweep")
     ap.add_argument("--stage", type=int, default=0)
+    ap.add_argument("--find", type=int, default=0,
+                    help="1: torch.backends.cudnn.benchmark=True (MIOpen exhaustive find: minutes on a fresh box); "
+                         "0: MIOpen immediate mode")
+    ap.add_argument("--no-fused-gn", action="store_true", help="eager GroupNorm+ReLU instead of dp_gn_relu_*")
     return ap.parse_args()
 
 
@@ -117,7 +121,10 @@ def main():
         pg = dist.group.WORLD
 
     from dorpatch_amd.attack import DorPatch, HotLoop
-    torch.backends.cudnn.benchmark = True       # reference utils.py:17; MIOpen picks its fastest solver
+    torch.backends.cudnn.benchmark = bool(args.find)   # reference utils.py:17 sets True (MIOpen find)
+    if args.no_fused_gn:
+        from dorpatch_amd.resnetv2 import GroupNormAct
+        GroupNormAct.fused = False
     B, S_local, H = args.batch, args.samples, args.size
     S = S_local * world                          # weak scaling: fixed per-GPU work
     torch.manual_seed(1234)
@@ -189,7 +196,8 @@ def main():
                                    "(seeded random weights, frozen, fp32), stage-%d step of DorPatch.generate, "
                                    "patch_budget %.4f" % (B, S_local, B * S_local, H, H, args.stage, args.patch_budget),
                        "images": B, "masks_per_image_per_gpu": S_local, "masks_per_image_total": S,
-                       "image_size": H, "micro_batch": args.micro_batch,
+                       "image_size": H, "micro_batch": args.micro_batch, "miopen_find": bool(args.find),
+                       "fused_gn_relu": not args.no_fused_gn,
                        "parallelism": "eot-sample sharding x%d, 1 all-reduce of the patch gradient per step" % world},
             "roofline": {"kernel": "k_apply_fwd (dp_apply_fwd)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -495,8 +495,11 @@ class HotLoop(object):
 
     # ---------------------------------------------------------------- one optimisation step
     def _refresh_failures(self):
+        # masks per forward chosen so that B * chunk ~ the training micro-batch: same conv shapes as the
+        # hot loop (no extra MIOpen solver searches), bounded activation memory
+        chunk = max(1, self.o.micro_batch // self.B)
         lists = _collect_failure(self.net, self.norm, self.adv_x, self.y, self.table,
-                                 self._flags("flag_targeted"), max(self.S, 1), pg=self.o.pg)
+                                 self._flags("flag_targeted"), chunk, pg=self.o.pg)
         for st, l in zip(self.img, lists):
             if st.active:
                 st.failed_idxs = l

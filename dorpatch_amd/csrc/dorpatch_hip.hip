@@ -176,38 +176,60 @@ inline NormDev make_norm(const dp_norm_t *n) {
   return d;
 }
 
-// grid: x = float4-group tiles of the image plane, y = S-chunks, z = image.
-// Each thread owns 4 consecutive pixels of all 3 channels, reads them ONCE,
-// then streams `s_per_block` occluded copies (3 x 16 B stores per sample).
+// grid: x = tiles of kBlock*G float4 groups of the image plane, y = S-chunks, z = image.
+// Each thread owns G float4 groups (4 consecutive pixels each, kBlock groups apart so that
+// every wave-instruction still covers 1 KiB of contiguous addresses) of all 3 channels,
+// reads + normalises them ONCE, then streams `s_per_block` occluded copies (3*G 16-byte
+// stores per sample).  NT selects non-temporal stores (the output is consumed by another
+// kernel much later, never re-read by this one).
+template <int G, bool NT>
 __global__ __launch_bounds__(kBlock) void k_apply_fwd(
     const float *__restrict__ adv_x, const int32_t *__restrict__ table, int R,
     const int32_t *__restrict__ idx, const int32_t *__restrict__ idx2, int idx_bstride,
     int S, int H, int W, int s_per_block, NormDev nd, float *__restrict__ out) {
   const int P = H * W, P4 = P >> 2;
-  const int g = blockIdx.x * kBlock + threadIdx.x;
-  if (g >= P4) return;
+  const int g0 = blockIdx.x * (kBlock * G) + threadIdx.x;
   const int b = blockIdx.z;
   const int s_begin = blockIdx.y * s_per_block;
   const int s_end = min(S, s_begin + s_per_block);
-  const int pix = g << 2;
-  const int h = pix / W, w = pix - h * W;
 
   const f4 *src = reinterpret_cast<const f4 *>(adv_x + (size_t)b * 3 * P);
-  f4 v0 = src[g], v1 = src[P4 + g], v2 = src[2 * P4 + g];
-  if (nd.enable) {  // reference NormModel: (x - mean) / std, true division
-    v0 = (v0 - nd.mean[0]) / nd.std[0];
-    v1 = (v1 - nd.mean[1]) / nd.std[1];
-    v2 = (v2 - nd.mean[2]) / nd.std[2];
+  f4 v[G][3];
+  int hh[G], ww[G];
+#pragma unroll
+  for (int k = 0; k < G; ++k) {
+    const int g = g0 + k * kBlock;
+    const int gc = g < P4 ? g : P4 - 1;  // clamp: tail lanes load a valid group, never store
+    const int pix = gc << 2;
+    hh[k] = pix / W;
+    ww[k] = pix - hh[k] * W;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      f4 t = src[c * P4 + gc];
+      if (nd.enable) t = (t - nd.mean[c]) / nd.std[c];  // reference NormModel: true division
+      v[k][c] = t;
+    }
   }
   const int32_t *ib = idx + (size_t)b * idx_bstride;
   const int32_t *ib2 = idx2 ? idx2 + (size_t)b * idx_bstride : nullptr;
   f4 *dst = reinterpret_cast<f4 *>(out + ((size_t)b * S + s_begin) * 3 * P);
   for (int s = s_begin; s < s_end; ++s) {
-    unsigned occ = occluded4(table, R, ib[s], h, w);
-    if (ib2) occ |= occluded4(table, R, ib2[s], h, w);
-    __builtin_nontemporal_store(select4(occ, v0, nd.fill[0]), dst + g);
-    __builtin_nontemporal_store(select4(occ, v1, nd.fill[1]), dst + P4 + g);
-    __builtin_nontemporal_store(select4(occ, v2, nd.fill[2]), dst + 2 * P4 + g);
+    const int m1 = ib[s];
+    const int m2 = ib2 ? ib2[s] : -1;
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const int g = g0 + k * kBlock;
+      if (g < P4) {
+        unsigned occ = occluded4(table, R, m1, hh[k], ww[k]);
+        if (m2 >= 0) occ |= occluded4(table, R, m2, hh[k], ww[k]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const f4 o = select4(occ, v[k][c], nd.fill[c]);
+          if (NT) __builtin_nontemporal_store(o, dst + c * P4 + g);
+          else dst[c * P4 + g] = o;
+        }
+      }
+    }
     dst += 3 * P4;
   }
 }
@@ -643,6 +665,323 @@ __global__ __launch_bounds__(kBlock) void k_argmax(const float *__restrict__ log
   if (lane == 0) pred[n] = all.i;
 }
 
+
+// ----------------------------------------------------------------------------
+// a-8 (backbone, HBM-bound part): GroupNorm + ReLU fused, forward and input-gradient
+// backward.  ResNetV2-50x1-BiT applies GroupNorm(32)+ReLU 49 times per forward
+// (timm 0.6.7 GroupNormAct; reference call sites utils.py:51-63, attack.py:222, 247).
+// Eager PyTorch spends 3 reads + 2 writes of the activation on the forward and
+// 6 reads + 2 writes on the backward; a group of one sample is at most 25 088 floats
+// at 224x224, so a workgroup keeps it in registers: forward = 1 read + 1 write,
+// backward = 2 reads + 1 write.  Frozen backbone: no gamma/beta gradients.
+// ----------------------------------------------------------------------------
+
+template <int T>
+__device__ __forceinline__ float block_allsum(float v, float *sm /* T/64 floats */) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  constexpr int NW = T / 64;
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) r += sm[w];  // same order in every thread: bit-identical total
+  return r;
+}
+
+struct GnArgs {
+  const float *x, *gamma, *beta;
+  int C, HW, Cg;      // channels, pixels per channel, channels per group
+  float eps, inv_hw;  // inv_hw = 1 / HW
+};
+
+// channel (within the group) of flat element e of the group; exact for e < 2^20, HW >= 1
+__device__ __forceinline__ int chan_of(int e, float inv_hw) {
+  return (int)(((float)e + 0.5f) * inv_hw);
+}
+
+// affine + relu of one float4 whose first element is group-element e
+__device__ __forceinline__ void gn_coeffs(const GnArgs &A, int cbase, int e, bool uniform, float mean,
+                                          float rstd, float a[4], float b[4]) {
+  if (uniform) {  // HW % 4 == 0: the 4 lanes of a float4 share one channel
+    const int c = cbase + chan_of(e, A.inv_hw);
+    const float aa = rstd * A.gamma[c];
+    const float bb = A.beta[c] - mean * aa;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = aa; b[j] = bb; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = cbase + chan_of(e + j, A.inv_hw);
+      a[j] = rstd * A.gamma[c];
+      b[j] = A.beta[c] - mean * a[j];
+    }
+  }
+}
+
+// One workgroup per (sample, group); the group (L = Cg*HW floats, L % 4 == 0) lives in
+// registers: V float4 per thread, T threads, V*T*4 >= L.
+template <int V, int T>
+__global__ __launch_bounds__(T) void k_gn_relu_fwd(GnArgs A, float *__restrict__ y,
+                                                   float *__restrict__ mean_out,
+                                                   float *__restrict__ rstd_out) {
+  __shared__ float sm1[T / 64], sm2[T / 64];
+  const int ng = blockIdx.x;
+  const int G = A.C / A.Cg;
+  const int cbase = (ng % G) * A.Cg;
+  const int L = A.Cg * A.HW, L4 = L >> 2;
+  const f4 *x4 = reinterpret_cast<const f4 *>(A.x + (size_t)ng * L);
+  f4 *y4 = reinterpret_cast<f4 *>(y + (size_t)ng * L);
+  f4 v[V];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    const int i = threadIdx.x + k * T;
+    if (i < L4) {
+      v[k] = x4[i];
+      s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+  }
+  const float mean = block_allsum<T>(s, sm1) / (float)L;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    const int i = threadIdx.x + k * T;
+    if (i < L4) {
+      const f4 d = v[k] - mean;
+      q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+  }
+  const float var = block_allsum<T>(q, sm2) / (float)L;  // biased, exact two-pass
+  const float rstd = 1.f / sqrtf(var + A.eps);
+  if (threadIdx.x == 0) {
+    mean_out[ng] = mean;
+    rstd_out[ng] = rstd;
+  }
+  const bool uniform = (A.HW & 3) == 0;
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    const int i = threadIdx.x + k * T;
+    if (i < L4) {
+      float a[4], b[4];
+      gn_coeffs(A, cbase, i << 2, uniform, mean, rstd, a, b);
+      f4 o;
+      o.x = fmaxf(v[k].x * a[0] + b[0], 0.f);
+      o.y = fmaxf(v[k].y * a[1] + b[1], 0.f);
+      o.z = fmaxf(v[k].z * a[2] + b[2], 0.f);
+      o.w = fmaxf(v[k].w * a[3] + b[3], 0.f);
+      y4[i] = o;
+    }
+  }
+}
+
+// dx = rstd * (dxh - mean_L(dxh) - xh * mean_L(dxh * xh)),  dxh = dy * [z > 0] * gamma,
+// xh = (x - mean) * rstd,  z = x * a + b (the forward's own expression, so the gate is
+// bit-consistent with the y the forward wrote).
+template <int V, int T>
+__global__ __launch_bounds__(T) void k_gn_relu_bwd(GnArgs A, const float *__restrict__ dy,
+                                                   const float *__restrict__ mean_in,
+                                                   const float *__restrict__ rstd_in,
+                                                   float *__restrict__ dx) {
+  __shared__ float sm1[T / 64], sm2[T / 64];
+  const int ng = blockIdx.x;
+  const int G = A.C / A.Cg;
+  const int cbase = (ng % G) * A.Cg;
+  const int L = A.Cg * A.HW, L4 = L >> 2;
+  const f4 *x4 = reinterpret_cast<const f4 *>(A.x + (size_t)ng * L);
+  const f4 *g4 = reinterpret_cast<const f4 *>(dy + (size_t)ng * L);
+  f4 *o4 = reinterpret_cast<f4 *>(dx + (size_t)ng * L);
+  const float mean = mean_in[ng], rstd = rstd_in[ng];
+  const bool uniform = (A.HW & 3) == 0;
+  f4 xh[V], dh[V];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    const int i = threadIdx.x + k * T;
+    if (i < L4) {
+      const f4 xv = x4[i];
+      const f4 gv = g4[i];
+      float a[4], b[4];
+      gn_coeffs(A, cbase, i << 2, uniform, mean, rstd, a, b);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+      const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+      float xo[4], go[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float z = xs[j] * a[j] + b[j];
+        xo[j] = (xs[j] - mean) * rstd;
+        // a = rstd * gamma  =>  dz * gamma = dz * a / rstd; keep gamma explicit via a * (1/rstd)
+        go[j] = (z > 0.f) ? gs[j] * a[j] : 0.f;  // = dxh * rstd
+        s1 += go[j];
+        s2 += go[j] * xo[j];
+      }
+      xh[k] = f4{xo[0], xo[1], xo[2], xo[3]};
+      dh[k] = f4{go[0], go[1], go[2], go[3]};
+    }
+  }
+  const float m1 = block_allsum<T>(s1, sm1) / (float)L;
+  const float m2 = block_allsum<T>(s2, sm2) / (float)L;
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    const int i = threadIdx.x + k * T;
+    if (i < L4) o4[i] = (dh[k] - m1) - xh[k] * m2;  // rstd already folded into dh (a = rstd*gamma)
+  }
+}
+
+// Streaming variants for groups too large for registers (e.g. 384x384 inputs): the group is
+// re-read from L2/HBM instead (forward 3 reads + 1 write, backward 4 reads + 1 write).
+constexpr int kGnStreamT = 1024;
+
+__global__ __launch_bounds__(kGnStreamT) void k_gn_relu_fwd_stream(GnArgs A, float *__restrict__ y,
+                                                                   float *__restrict__ mean_out,
+                                                                   float *__restrict__ rstd_out) {
+  constexpr int T = kGnStreamT;
+  __shared__ float sm1[T / 64], sm2[T / 64];
+  const int ng = blockIdx.x;
+  const int G = A.C / A.Cg;
+  const int cbase = (ng % G) * A.Cg;
+  const int L = A.Cg * A.HW, L4 = L >> 2;
+  const f4 *x4 = reinterpret_cast<const f4 *>(A.x + (size_t)ng * L);
+  f4 *y4 = reinterpret_cast<f4 *>(y + (size_t)ng * L);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < L4; i += T) {
+    const f4 v = x4[i];
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  const float mean = block_allsum<T>(s, sm1) / (float)L;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < L4; i += T) {
+    const f4 d = x4[i] - mean;
+    q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+  }
+  const float var = block_allsum<T>(q, sm2) / (float)L;
+  const float rstd = 1.f / sqrtf(var + A.eps);
+  if (threadIdx.x == 0) {
+    mean_out[ng] = mean;
+    rstd_out[ng] = rstd;
+  }
+  const bool uniform = (A.HW & 3) == 0;
+  for (int i = threadIdx.x; i < L4; i += T) {
+    const f4 v = x4[i];
+    float a[4], b[4];
+    gn_coeffs(A, cbase, i << 2, uniform, mean, rstd, a, b);
+    f4 o;
+    o.x = fmaxf(v.x * a[0] + b[0], 0.f);
+    o.y = fmaxf(v.y * a[1] + b[1], 0.f);
+    o.z = fmaxf(v.z * a[2] + b[2], 0.f);
+    o.w = fmaxf(v.w * a[3] + b[3], 0.f);
+    y4[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(kGnStreamT) void k_gn_relu_bwd_stream(
+    GnArgs A, const float *__restrict__ dy, const float *__restrict__ mean_in,
+    const float *__restrict__ rstd_in, float *__restrict__ dx) {
+  constexpr int T = kGnStreamT;
+  __shared__ float sm1[T / 64], sm2[T / 64];
+  const int ng = blockIdx.x;
+  const int G = A.C / A.Cg;
+  const int cbase = (ng % G) * A.Cg;
+  const int L = A.Cg * A.HW, L4 = L >> 2;
+  const f4 *x4 = reinterpret_cast<const f4 *>(A.x + (size_t)ng * L);
+  const f4 *g4 = reinterpret_cast<const f4 *>(dy + (size_t)ng * L);
+  f4 *o4 = reinterpret_cast<f4 *>(dx + (size_t)ng * L);
+  const float mean = mean_in[ng], rstd = rstd_in[ng];
+  const bool uniform = (A.HW & 3) == 0;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < L4; i += T) {
+    const f4 xv = x4[i], gv = g4[i];
+    float a[4], b[4];
+    gn_coeffs(A, cbase, i << 2, uniform, mean, rstd, a, b);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float z = xs[j] * a[j] + b[j];
+      const float go = (z > 0.f) ? gs[j] * a[j] : 0.f;
+      s1 += go;
+      s2 += go * ((xs[j] - mean) * rstd);
+    }
+  }
+  const float m1 = block_allsum<T>(s1, sm1) / (float)L;
+  const float m2 = block_allsum<T>(s2, sm2) / (float)L;
+  for (int i = threadIdx.x; i < L4; i += T) {
+    const f4 xv = x4[i], gv = g4[i];
+    float a[4], b[4];
+    gn_coeffs(A, cbase, i << 2, uniform, mean, rstd, a, b);
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float z = xs[j] * a[j] + b[j];
+      const float go = (z > 0.f) ? gs[j] * a[j] : 0.f;
+      o[j] = (go - m1) - ((xs[j] - mean) * rstd) * m2;
+    }
+    o4[i] = f4{o[0], o[1], o[2], o[3]};
+  }
+}
+
+// (V float4 per thread, T threads) combinations that are instantiated, smallest first; the
+// group must fit: V*T >= L4.  V = 7 only with T = 1024 (launch bounds cap it at 128 VGPRs; at
+// T = 256/512 the compiler spends > 160 VGPRs on V = 7).  V = 0 => streaming kernel.
+inline void gn_pick(int L4, int &V, int &T) {
+  static const int combos[6][2] = {{1, 256}, {2, 256}, {4, 256}, {4, 512}, {4, 1024}, {7, 1024}};
+  for (const auto &c : combos)
+    if (c[0] * c[1] >= L4) {
+      V = c[0];
+      T = c[1];
+      return;
+    }
+  V = 0;
+  T = kGnStreamT;
+}
+
+#define DP_GN_DISPATCH(KERNEL, V_, T_, ...)                                                        \
+  do {                                                                                             \
+    if (T_ == 256 && V_ == 1) hipLaunchKernelGGL((KERNEL<1, 256>), grid, dim3(256), 0, st, __VA_ARGS__);      \
+    else if (T_ == 256 && V_ == 2) hipLaunchKernelGGL((KERNEL<2, 256>), grid, dim3(256), 0, st, __VA_ARGS__); \
+    else if (T_ == 256) hipLaunchKernelGGL((KERNEL<4, 256>), grid, dim3(256), 0, st, __VA_ARGS__);            \
+    else if (T_ == 512) hipLaunchKernelGGL((KERNEL<4, 512>), grid, dim3(512), 0, st, __VA_ARGS__);            \
+    else if (V_ == 4) hipLaunchKernelGGL((KERNEL<4, 1024>), grid, dim3(1024), 0, st, __VA_ARGS__);            \
+    else hipLaunchKernelGGL((KERNEL<7, 1024>), grid, dim3(1024), 0, st, __VA_ARGS__);                         \
+  } while (0)
+
+// Variant = G (float4 groups per thread: 1, 2 or 4) + 8 * NT (non-temporal stores).
+// dp_apply_fwd uses kApplyFwdDefaultVariant; tools/kbench.cpp sweeps the others.
+constexpr int kApplyFwdDefaultVariant = 1 + 8;
+
+int launch_apply_fwd(int variant, const float *adv_x, const int32_t *table, int R,
+                     const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H,
+                     int W, const dp_norm_t *norm, float *out, dp_stream_t stream) {
+  const int G = variant & 7;
+  const bool nt = (variant & 8) != 0;
+  DP_REQUIRE(G == 1 || G == 2 || G == 4);
+  const int P4 = (H * W) >> 2;
+  const int tiles = cdiv(P4, kBlock * G);
+  // >= ~2048 workgroups (8 per CU) so the store stream covers all 8 XCDs evenly
+  int nchunk = cdiv(2048, tiles * B);
+  if (nchunk < 1) nchunk = 1;
+  if (nchunk > S) nchunk = S;
+  const int s_per_block = cdiv(S, nchunk);
+  nchunk = cdiv(S, s_per_block);
+  DP_REQUIRE(nchunk <= 65535);
+  const dim3 grid(tiles, nchunk, B), block(kBlock);
+  const NormDev nd = make_norm(norm);
+  hipStream_t st = as_stream(stream);
+#define DP_LAUNCH_FWD(G_, NT_)                                                                    \
+  hipLaunchKernelGGL((k_apply_fwd<G_, NT_>), grid, block, 0, st, adv_x, table, R, idx, idx2,       \
+                     idx_bstride, S, H, W, s_per_block, nd, out)
+  if (G == 1 && nt) DP_LAUNCH_FWD(1, true);
+  else if (G == 1) DP_LAUNCH_FWD(1, false);
+  else if (G == 2 && nt) DP_LAUNCH_FWD(2, true);
+  else if (G == 2) DP_LAUNCH_FWD(2, false);
+  else if (nt) DP_LAUNCH_FWD(4, true);
+  else DP_LAUNCH_FWD(4, false);
+#undef DP_LAUNCH_FWD
+  return launch_status();
+}
+
 }  // namespace
 
 // ============================================================================
@@ -698,19 +1037,8 @@ int dp_apply_fwd(const float *adv_x, const int32_t *table, int R, const int32_t 
   DP_REQUIRE(adv_x && out && aligned16(adv_x) && aligned16(out));
   const int rc = check_occlusion_args(table, R, idx, idx_bstride, B, S, H, W, norm);
   if (rc) return rc;
-  const int P4 = (H * W) >> 2;
-  const int tiles = cdiv(P4, kBlock);
-  // >= ~2048 workgroups (8 per CU) so the store stream covers all 8 XCDs evenly
-  int nchunk = cdiv(2048, tiles * B);
-  if (nchunk < 1) nchunk = 1;
-  if (nchunk > S) nchunk = S;
-  const int s_per_block = cdiv(S, nchunk);
-  nchunk = cdiv(S, s_per_block);
-  DP_REQUIRE(nchunk <= 65535);
-  hipLaunchKernelGGL(k_apply_fwd, dim3(tiles, nchunk, B), dim3(kBlock), 0, as_stream(stream),
-                     adv_x, table, R, idx, idx2, idx_bstride, S, H, W, s_per_block,
-                     make_norm(norm), out);
-  return launch_status();
+  return launch_apply_fwd(kApplyFwdDefaultVariant, adv_x, table, R, idx, idx2, idx_bstride, B, S, H, W,
+                          norm, out, stream);
 }
 
 static int bwd_s_per_slab(int B, int S, int P) {
@@ -842,6 +1170,52 @@ int dp_argmax(const float *logits, int N, int C, int32_t *pred, dp_stream_t stre
   DP_REQUIRE(logits && pred && N > 0 && C > 0);
   hipLaunchKernelGGL(k_argmax, dim3(cdiv(N, kBlock / 64)), dim3(kBlock), 0, as_stream(stream),
                      logits, N, C, pred);
+  return launch_status();
+}
+
+static int gn_check(const float *x, const float *gamma, const float *beta, int N, int C, int HW,
+                    int G, GnArgs &A, float eps) {
+  DP_REQUIRE(x && gamma && beta && aligned16(x));
+  DP_REQUIRE(N > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0);
+  const long L = (long)(C / G) * HW;
+  DP_REQUIRE((L & 3) == 0 && L < (1L << 20));  // float4 lanes; chan_of() exactness bound
+  DP_REQUIRE((long)N * G <= 0x7fffffffL);
+  A.x = x; A.gamma = gamma; A.beta = beta;
+  A.C = C; A.HW = HW; A.Cg = C / G;
+  A.eps = eps; A.inv_hw = 1.f / (float)HW;
+  return 0;
+}
+
+int dp_gn_relu_fwd(const float *x, const float *gamma, const float *beta, int N, int C, int HW,
+                   int G, float eps, float *y, float *mean, float *rstd, dp_stream_t stream) {
+  GnArgs A;
+  const int rc = gn_check(x, gamma, beta, N, C, HW, G, A, eps);
+  if (rc) return rc;
+  DP_REQUIRE(y && mean && rstd && aligned16(y));
+  const int L4 = (A.Cg * HW) >> 2;
+  int V, T;
+  gn_pick(L4, V, T);
+  const dim3 grid((unsigned)(N * G));
+  hipStream_t st = as_stream(stream);
+  if (V == 0) hipLaunchKernelGGL(k_gn_relu_fwd_stream, grid, dim3(kGnStreamT), 0, st, A, y, mean, rstd);
+  else DP_GN_DISPATCH(k_gn_relu_fwd, V, T, A, y, mean, rstd);
+  return launch_status();
+}
+
+int dp_gn_relu_bwd(const float *dy, const float *x, const float *gamma, const float *beta,
+                   const float *mean, const float *rstd, int N, int C, int HW, int G, float *dx,
+                   dp_stream_t stream) {
+  GnArgs A;
+  const int rc = gn_check(x, gamma, beta, N, C, HW, G, A, 0.f);
+  if (rc) return rc;
+  DP_REQUIRE(dy && mean && rstd && dx && aligned16(dy) && aligned16(dx));
+  const int L4 = (A.Cg * HW) >> 2;
+  int V, T;
+  gn_pick(L4, V, T);
+  const dim3 grid((unsigned)(N * G));
+  hipStream_t st = as_stream(stream);
+  if (V == 0) hipLaunchKernelGGL(k_gn_relu_bwd_stream, grid, dim3(kGnStreamT), 0, st, A, dy, mean, rstd, dx);
+  else DP_GN_DISPATCH(k_gn_relu_bwd, V, T, A, dy, mean, rstd, dx);
   return launch_status();
 }
 

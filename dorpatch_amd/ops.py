@@ -242,3 +242,60 @@ def project_update(x, adv_x, lv_x, g_adv, scale, structured, pattern, mask, *, s
                                      _p(mask), _p(best_pattern), _p(best_mask), _p(gp), _p(gm),
                                      _stream()), "dp_project_update")
     return gp, gm
+
+
+# ---------------------------------------------------------------- a-8: fused GroupNorm + ReLU (frozen backbone)
+def gn_relu_supported(x, groups):
+    """Shapes the fused kernel accepts: fp32 GPU NCHW, (C/groups)*H*W a multiple of 4 and < 2^20."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() >= 2):
+        return False
+    C = x.shape[1]
+    if C % groups:
+        return False
+    L = (C // groups) * int(np.prod(x.shape[2:]))
+    return L % 4 == 0 and L < (1 << 20)
+
+
+def gn_relu_fwd(x, weight, bias, groups, eps):
+    """y = relu(group_norm(x)); also returns the per-(sample, group) mean and rstd for the backward."""
+    lib = _lib.load()
+    _chk(x, torch.float32, "x"), _chk(weight, torch.float32, "weight"), _chk(bias, torch.float32, "bias")
+    N, C = x.shape[0], x.shape[1]
+    HW = int(np.prod(x.shape[2:]))
+    y = torch.empty_like(x)
+    mean = torch.empty((N * groups,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    _lib.check(lib.dp_gn_relu_fwd(_p(x), _p(weight), _p(bias), N, C, HW, int(groups), float(eps), _p(y),
+                                  _p(mean), _p(rstd), _stream()), "dp_gn_relu_fwd")
+    return y, mean, rstd
+
+
+def gn_relu_bwd(dy, x, weight, bias, mean, rstd, groups):
+    """d loss / d x of y = relu(group_norm(x)) (weights frozen: no gamma / beta gradients)."""
+    lib = _lib.load()
+    _chk(dy, torch.float32, "dy"), _chk(x, torch.float32, "x")
+    N, C = x.shape[0], x.shape[1]
+    HW = int(np.prod(x.shape[2:]))
+    dx = torch.empty_like(x)
+    _lib.check(lib.dp_gn_relu_bwd(_p(dy), _p(x), _p(weight), _p(bias), _p(mean), _p(rstd), N, C, HW,
+                                  int(groups), _p(dx), _stream()), "dp_gn_relu_bwd")
+    return dx
+
+
+class GnReluFunction(torch.autograd.Function):
+    """autograd node over dp_gn_relu_fwd / dp_gn_relu_bwd.  Saves only the GN input and 2*N*G
+    statistics (eager PyTorch also keeps the ReLU output)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps):
+        x = x.contiguous()
+        y, mean, rstd = gn_relu_fwd(x, weight, bias, groups, eps)
+        ctx.save_for_backward(x, weight, bias, mean, rstd)
+        ctx.groups = groups
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, mean, rstd = ctx.saved_tensors
+        dx = gn_relu_bwd(dy.contiguous(), x, weight, bias, mean, rstd, ctx.groups)
+        return dx, None, None, None, None

@@ -49,12 +49,25 @@ class StdConv2d(nn.Conv2d):
 
 
 class GroupNormAct(nn.GroupNorm):
-    """GroupNorm(32) + ReLU, parameters named ``weight`` / ``bias`` like timm's."""
+    """GroupNorm(32) + ReLU, parameters named ``weight`` / ``bias`` like timm's.
+
+    On a ROCm GPU with frozen affine parameters (the hot path: ``DorPatch.generate`` freezes the
+    backbone) the pair runs as ONE hand-written HIP kernel per direction
+    (``dp_gn_relu_fwd`` / ``dp_gn_relu_bwd``: 1 read + 1 write forward, 2 reads + 1 write
+    backward instead of eager PyTorch's 5 and 8 passes over the activation).  On CPU tensors, or
+    while the affine parameters still require gradients, it is the plain torch composition.
+    ``GroupNormAct.fused = False`` disables the HIP path globally (A/B measurements)."""
+
+    fused = True
 
     def __init__(self, num_channels, num_groups=32, eps=1e-5):
         super().__init__(num_groups, num_channels, eps=eps, affine=True)
 
     def forward(self, x):
+        if GroupNormAct.fused and x.is_cuda and not (self.weight.requires_grad or self.bias.requires_grad):
+            from . import ops
+            if ops.gn_relu_supported(x, self.num_groups):
+                return ops.GnReluFunction.apply(x, self.weight, self.bias, self.num_groups, self.eps)
         return F.relu(F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps), inplace=True)
 
 

@@ -181,6 +181,20 @@ int dp_project_update(const dp_update_cfg_t *cfg, const float *x,
 int dp_argmax(const float *logits, int N, int C, int32_t *pred,
               dp_stream_t stream);
 
+/* ---- a-8  GroupNorm + ReLU of the frozen backbone, fused (HBM-bound part of the backbone) ----
+ * timm 0.6.7 GroupNormAct as used by resnetv2_50x1_bit_distilled (reference utils.py:51-63;
+ * executed at attack.py:222 forward / :247 backward): y = relu(group_norm(x, G, gamma, beta, eps)).
+ * x, y, dy, dx (N,C,HW) fp32 NCHW; gamma, beta (C); mean, rstd (N*G) saved for the backward.
+ * Requires (C/G)*HW % 4 == 0.  The backward returns only d loss / d x (frozen weights):
+ *   dx = rstd * (dxh - mean_L(dxh) - xh * mean_L(dxh * xh)),  dxh = dy * [y > 0] * gamma.
+ * Algorithmic HBM traffic per element: forward 4 B read + 4 B write, backward 8 B read + 4 B write
+ * (groups up to 7168 float4 stay in registers; larger groups are re-read: +8 B per direction). */
+int dp_gn_relu_fwd(const float *x, const float *gamma, const float *beta, int N, int C, int HW,
+                   int G, float eps, float *y, float *mean, float *rstd, dp_stream_t stream);
+int dp_gn_relu_bwd(const float *dy, const float *x, const float *gamma, const float *beta,
+                   const float *mean, const float *rstd, int N, int C, int HW, int G, float *dx,
+                   dp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,8 +26,8 @@ def test_blend_matches_clip(B, H, eps):
     adv, scale, l2 = ops.blend(m.to(DEV), p.to(DEV), x.to(DEV), eps)
     delta, _, _ = ops.blend(m.to(DEV), p.to(DEV), x.to(DEV), eps, add_x=False)
     l2_want = (m * (p - x)).flatten(1).norm(dim=1)
-    np.testing.assert_allclose(l2.cpu().numpy(), l2_want.numpy(), rtol=2e-6)
-    np.testing.assert_allclose(scale.cpu().numpy(), (eps / l2_want).clamp(max=1).numpy(), rtol=2e-6)
+    np.testing.assert_allclose(l2.cpu().numpy(), l2_want.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(scale.cpu().numpy(), (eps / l2_want).clamp(max=1).numpy(), rtol=1e-5)
     np.testing.assert_allclose(delta.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(adv.cpu().numpy(), (want + x).numpy(), rtol=1e-5, atol=1e-7)
 
@@ -217,3 +217,109 @@ def test_project_update_grads_and_update(stage, B, H):
         assert flips.mean() < 2e-3, flips.mean()     # sign(ulp-noise) pixels only
         assert np.abs(got - want).max() <= 2 * max(c["lr"]) + 1e-6
     assert p.min() >= 0 and p.max() <= 1
+
+
+# ---------------------------------------------------------------- fused GroupNorm + ReLU (backbone, a-8)
+GN_SHAPES = [  # (N, C, H, W): every (V, T) register variant, the HW = 49 per-lane channel path, streaming
+    (3, 64, 56, 56),      # L4 = 1568  -> <4,512>
+    (2, 256, 56, 56),     # L4 = 6272  -> <7,1024>
+    (2, 128, 56, 56),     # L4 = 3136  -> <4,1024>
+    (3, 128, 28, 28),     # L4 = 784   -> <4,256>
+    (2, 256, 14, 14),     # L4 = 392   -> <2,256>
+    (5, 512, 7, 7),       # L4 = 196   -> <1,256>, HW % 4 != 0
+    (2, 2048, 7, 7),      # L4 = 784, HW % 4 != 0
+    (1, 256, 96, 96),     # L4 = 18432 -> streaming kernel (384x384 inputs)
+    (2, 32, 4, 4),        # one channel per group, tiny
+]
+
+
+@pytest.mark.parametrize("shape", GN_SHAPES)
+def test_gn_relu_matches_torch(shape):
+    """y = relu(group_norm(x)) vs torch (float64 on the CPU; the op is third-party maths — timm's
+    GroupNormAct — so the reference is torch, not the oracle) and the input gradient vs the analytic
+    GroupNorm backward in float64.  The ReLU gate is a step function: where |z| < 1e-5 fp32 and fp64
+    may legitimately disagree, so the gradient reference takes the gate from the kernel's own output
+    and the gate itself is checked everywhere else."""
+    N, C, H, W = shape
+    G = 32
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.2
+    dy = torch.randn(N, C, H, W, generator=g)
+    y, mean, rstd = ops.gn_relu_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV), G, 1e-5)
+    dx = ops.gn_relu_bwd(dy.to(DEV), x.to(DEV), gamma.to(DEV), beta.to(DEV), mean, rstd, G)
+    y, dx = y.cpu(), dx.cpu()
+    xd = x.double()
+    z = torch.nn.functional.group_norm(xd, G, gamma.double(), beta.double(), 1e-5)
+    np.testing.assert_allclose(y.numpy(), torch.relu(z).float().numpy(), rtol=2e-5, atol=2e-6)
+    xg = xd.view(N, G, -1)
+    mu, var = xg.mean(-1, keepdim=True), xg.var(-1, unbiased=False, keepdim=True)
+    r = (var + 1e-5).rsqrt()
+    np.testing.assert_allclose(mean.cpu().numpy(), mu.reshape(-1).float().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rstd.cpu().numpy(), r.reshape(-1).float().numpy(), rtol=1e-5)
+    gate = y > 0
+    assert bool(((gate == (z > 0)) | (z.abs() < 1e-5)).all())
+    xh = ((xg - mu) * r)
+    dxh = (dy.double() * gate * gamma.double().view(1, C, 1, 1)).view(N, G, -1)
+    want = r * (dxh - dxh.mean(-1, keepdim=True) - xh * (dxh * xh).mean(-1, keepdim=True))
+    np.testing.assert_allclose(dx.numpy(), want.view(N, C, H, W).float().numpy(), rtol=1e-4, atol=2e-5)
+    # and the analytic form above IS torch's autograd (checked in float64, gate from z)
+    xr = xd.clone().requires_grad_(True)
+    (dxr,) = torch.autograd.grad(torch.relu(torch.nn.functional.group_norm(xr, G, gamma.double(), beta.double(), 1e-5)),
+                                 xr, dy.double())
+    dxh2 = (dy.double() * (z > 0) * gamma.double().view(1, C, 1, 1)).view(N, G, -1)
+    want2 = r * (dxh2 - dxh2.mean(-1, keepdim=True) - xh * (dxh2 * xh).mean(-1, keepdim=True))
+    np.testing.assert_allclose(want2.view(N, C, H, W).numpy(), dxr.numpy(), rtol=1e-9, atol=1e-11)
+
+
+def test_gn_relu_autograd_function_in_module():
+    """GroupNormAct routes frozen GPU inputs through the fused kernels; trainable / CPU stay on torch."""
+    from dorpatch_amd.resnetv2 import GroupNormAct
+    m = GroupNormAct(64).to(DEV)
+    with torch.no_grad():
+        m.weight.uniform_(0.5, 1.5)
+        m.bias.normal_(0, 0.2)
+    x = torch.randn(4, 64, 28, 28, device=DEV)
+    xa = x.clone().requires_grad_(True)
+    ya = m(xa)                                  # trainable affine params -> torch path
+    assert "GnRelu" not in type(ya.grad_fn).__name__
+    (ga,) = torch.autograd.grad(ya.sum() + (ya * ya).sum(), xa)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    xb = x.clone().requires_grad_(True)
+    yb = m(xb)
+    assert "GnRelu" in type(yb.grad_fn).__name__
+    (gb,) = torch.autograd.grad(yb.sum() + (yb * yb).sum(), xb)
+    np.testing.assert_allclose(yb.detach().cpu().numpy(), ya.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+    bad = (gb - ga).abs() > 2e-4 * ga.abs() + 2e-5          # a ReLU gate at |z| ~ ulp may flip one group
+    assert float(bad.float().mean()) < 1e-2
+    GroupNormAct.fused = False
+    try:
+        assert "GnRelu" not in type(m(xb).grad_fn).__name__
+    finally:
+        GroupNormAct.fused = True
+
+
+def test_resnetv2_fused_equals_unfused():
+    """Whole frozen ResNetV2-50x1-BiT: logits and input gradient with the fused GN+ReLU kernels
+    vs the eager composition (same MIOpen convolutions either way)."""
+    from dorpatch_amd.resnetv2 import GroupNormAct, resnetv2_50x1_bit, seeded_init_
+    net = seeded_init_(resnetv2_50x1_bit(1000)).fold_weight_standardization().freeze().to(DEV)
+    x = torch.rand(4, 3, 224, 224, generator=torch.Generator().manual_seed(2)).to(DEV) * 2 - 1
+    dl = torch.randn(4, 1000, generator=torch.Generator().manual_seed(3)).to(DEV)
+    outs = []
+    for fused in (True, False):
+        GroupNormAct.fused = fused
+        try:
+            xi = x.clone().requires_grad_(True)
+            lg = net(xi)
+            (gx,) = torch.autograd.grad(lg, xi, dl)
+            outs.append((lg.detach().cpu().numpy(), gx.cpu().numpy()))
+        finally:
+            GroupNormAct.fused = True
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-3, atol=1e-4)
+    a, b = outs[0][1].astype(np.float64), outs[1][1].astype(np.float64)
+    # fp32 noise floor of this random-weight net is ~1e-2 rel-L2 (DESIGN.md §7): ReLU gates flip
+    assert np.linalg.norm(a - b) / np.linalg.norm(b) < 5e-2
+    assert (a * b).sum() / np.linalg.norm(a) / np.linalg.norm(b) > 0.998

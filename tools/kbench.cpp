@@ -1,0 +1,231 @@
+// kbench — standalone HIP micro-benchmark of every libdorpatch_hip.so entry point at
+// BASELINE.json configs[1] geometry (64 images x 32 sampled double-masks @224x224, fp32),
+// plus two calibration kernels (write-only fill, float4 copy) that give this box's
+// achievable HBM ceilings.  No Python / torch: starts in milliseconds on the GPU box.
+//
+//   build:  python -m dorpatch_amd.build  &&  make -C tools        (or __graft_entry__.build())
+//   run:    tools/kbench [B S H iters]
+//
+// Output: one line per kernel: name, avg ms (hipEvent on the launch stream), algorithmic
+// bytes per launch, GB/s, fraction of the 8 TB/s spec.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <random>
+#include <string>
+#include <vector>
+
+// White-box: the product translation unit is compiled INTO this binary so that the kernel
+// variants behind dp_apply_fwd (launch_apply_fwd(variant, ...)) can be swept; every other kernel
+// is still called through its extern "C" entry point.
+#include "../dorpatch_amd/csrc/dorpatch_hip.hip"
+
+#define CK(x)                                                                          \
+  do {                                                                                 \
+    hipError_t e_ = (x);                                                               \
+    if (e_ != hipSuccess) {                                                            \
+      fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(2);                                                                         \
+    }                                                                                  \
+  } while (0)
+#define DP(x)                                                                \
+  do {                                                                       \
+    int e_ = (x);                                                            \
+    if (e_ != 0) {                                                           \
+      fprintf(stderr, "dp error %d (%s) at %s:%d\n", e_, dp_error_string(e_), __FILE__, __LINE__); \
+      exit(3);                                                               \
+    }                                                                        \
+  } while (0)
+
+__global__ __launch_bounds__(256) void k_fill(f4 *__restrict__ out, size_t n4, float v) {
+  const f4 val = {v, v, v, v};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+    __builtin_nontemporal_store(val, out + i);
+}
+
+__global__ __launch_bounds__(256) void k_copy(const f4 *__restrict__ in, f4 *__restrict__ out, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+    __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
+}
+
+__global__ __launch_bounds__(256) void k_readsum(const f4 *__restrict__ in, float *__restrict__ out, size_t n4) {
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+    acc += __builtin_nontemporal_load(in + i);
+  if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = 1.f;  // keep the loads alive
+}
+
+static double bench(const char *name, double bytes, int iters, hipStream_t st, const std::function<void()> &fn) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) fn();
+  CK(hipStreamSynchronize(st));
+  CK(hipEventRecord(e0, st));
+  for (int i = 0; i < iters; ++i) fn();
+  CK(hipEventRecord(e1, st));
+  CK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= iters;
+  const double gbs = bytes / (ms * 1e-3) / 1e9;
+  printf("%-34s %9.4f ms  %12.0f B  %8.1f GB/s  %5.1f%% of 8 TB/s\n", name, ms, bytes, gbs, gbs / 80.0);
+  fflush(stdout);
+  CK(hipEventDestroy(e0));
+  CK(hipEventDestroy(e1));
+  return ms;
+}
+
+int main(int argc, char **argv) {
+  const int B = argc > 1 ? atoi(argv[1]) : 64;
+  const int S = argc > 2 ? atoi(argv[2]) : 32;
+  const int H = argc > 3 ? atoi(argv[3]) : 224;
+  const int iters = argc > 4 ? atoi(argv[4]) : 20;
+  const int W = H, P = H * W, N = B * S;
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  printf("# device %s, %d CUs; B=%d S=%d H=%d (N=%d masked images, %.3f GB), iters=%d\n", prop.name,
+         prop.multiProcessorCount, B, S, H, N, (double)N * 3 * P * 4 / 1e9, iters);
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+
+  // ---- PatchCleanser double-mask universe (defenses/PatchCleanser.py:11-16, 51-58, 23-29)
+  std::vector<int32_t> table;
+  const double ratios[4] = {0.015, 0.03, 0.06, 0.12};
+  for (double r : ratios) {
+    const int mask_size = (int)std::floor(std::sqrt((double)H * H * r));
+    const int stride = (int)std::ceil((H - mask_size + 1) / 6.0);
+    const int window = mask_size + stride - 1;
+    int rc[36][4];
+    for (int i = 0; i < 6; ++i)
+      for (int j = 0; j < 6; ++j) {
+        int *q = rc[i * 6 + j];
+        q[0] = stride * i; q[1] = std::min(H, stride * i + window);
+        q[2] = stride * j; q[3] = std::min(H, stride * j + window);
+      }
+    for (int a = 0; a < 36; ++a)
+      for (int b = a + 1; b < 36; ++b) {
+        table.insert(table.end(), rc[a], rc[a] + 4);
+        table.insert(table.end(), rc[b], rc[b] + 4);
+      }
+  }
+  const int n_mask = (int)table.size() / 8;
+  std::mt19937 rng(1234);
+  std::vector<int32_t> idx((size_t)B * S);
+  for (auto &v : idx) v = (int32_t)(rng() % n_mask);
+
+  auto dmalloc = [](size_t bytes) { void *p; CK(hipMalloc(&p, bytes)); return p; };
+  const size_t img = (size_t)3 * P * 4;
+  float *x = (float *)dmalloc(B * img), *pattern = (float *)dmalloc(B * img), *adv = (float *)dmalloc(B * img);
+  float *g_adv = (float *)dmalloc(B * img), *best_p = (float *)dmalloc(B * img);
+  float *mask = (float *)dmalloc((size_t)B * P * 4), *best_m = (float *)dmalloc((size_t)B * P * 4);
+  float *lv = (float *)dmalloc((size_t)B * P * 4);
+  float *big = (float *)dmalloc((size_t)N * img), *big2 = (float *)dmalloc((size_t)N * img);
+  int32_t *d_table = (int32_t *)dmalloc(table.size() * 4), *d_idx = (int32_t *)dmalloc(idx.size() * 4);
+  CK(hipMemcpy(d_table, table.data(), table.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
+  {  // random fill of the small state (host rng -> device)
+    std::vector<float> h((size_t)B * 3 * P);
+    std::uniform_real_distribution<float> U(0.f, 1.f);
+    for (float *dst : {x, pattern, g_adv}) {
+      for (auto &v : h) v = U(rng);
+      CK(hipMemcpy(dst, h.data(), B * img, hipMemcpyHostToDevice));
+    }
+    for (auto &v : h) v = U(rng);
+    CK(hipMemcpy(mask, h.data(), (size_t)B * P * 4, hipMemcpyHostToDevice));
+  }
+  const size_t n4_big = (size_t)N * 3 * P / 4;
+  hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, st, (f4 *)big2, n4_big, 0.25f);
+
+  const int nchunk = dp_sumsq_nchunk(P), ntile = dp_struct_ntile(H, W);
+  float *partials = (float *)dmalloc((size_t)B * nchunk * 4), *tpart = (float *)dmalloc((size_t)B * ntile * 4);
+  float *scale = (float *)dmalloc(B * 4), *l2 = (float *)dmalloc(B * 4), *sloss = (float *)dmalloc(B * 4);
+  float *structured = (float *)dmalloc(B * 4), *coeff = (float *)dmalloc(B * 4), *lr = (float *)dmalloc(B * 4);
+  float *gl = (float *)dmalloc(B * 4), *dens = (float *)dmalloc(B * 4);
+  {
+    std::vector<float> a(B, 1e-3f), b(B, 1e-5f), c(B, 1e-2f);
+    CK(hipMemcpy(structured, a.data(), B * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(coeff, b.data(), B * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(lr, c.data(), B * 4, hipMemcpyHostToDevice));
+  }
+  const int unit = 7, win = W / 8;
+  const int ncy = (H - unit) / unit + 1, nwy = (H - win) / win + 1;
+  float *cell = (float *)dmalloc((size_t)B * ncy * ncy * 4), *wsum = (float *)dmalloc((size_t)B * nwy * nwy * 4);
+  const int C = 1000;
+  float *logits = (float *)dmalloc((size_t)N * C * 4), *dlogits = (float *)dmalloc((size_t)N * C * 4);
+  float *loss = (float *)dmalloc((size_t)N * 4);
+  int32_t *pred = (int32_t *)dmalloc((size_t)N * 4), *tflag = (int32_t *)dmalloc(B * 4);
+  int64_t *y = (int64_t *)dmalloc(B * 8);
+  CK(hipMemset(tflag, 0, B * 4));
+  CK(hipMemset(y, 0, B * 8));
+  hipLaunchKernelGGL(k_fill, dim3(512), dim3(256), 0, st, (f4 *)logits, (size_t)N * C / 4, 0.5f);
+  const int nslab = dp_apply_bwd_nslab(B, S, P);
+  float *slabs = (float *)dmalloc((size_t)nslab * B * img);
+  CK(hipStreamSynchronize(st));
+
+  dp_norm_t norm = {1, {0.5f, 0.5f, 0.5f}, {0.5f, 0.5f, 0.5f}, 0.5f};
+  const double out_bytes = (double)N * img;
+
+  // ---- calibration: what this box's HBM does for the same footprint
+  bench("calib: fill (write-only)", out_bytes, iters, st,
+        [&] { hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, st, (f4 *)big, n4_big, 1.f); });
+  bench("calib: read-sum (read-only)", out_bytes, iters, st,
+        [&] { hipLaunchKernelGGL(k_readsum, dim3(2048), dim3(256), 0, st, (const f4 *)big2, loss, n4_big); });
+  bench("calib: copy (read+write)", 2 * out_bytes, iters, st,
+        [&] { hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, st, (const f4 *)big2, (f4 *)big, n4_big); });
+
+  // ---- a-2
+  bench("dp_sumsq_partials", (double)B * P * 28, iters, st,
+        [&] { DP(dp_sumsq_partials(mask, pattern, x, B, P, partials, st)); });
+  bench("dp_blend", (double)B * P * 40, iters, st,
+        [&] { DP(dp_blend(mask, pattern, x, partials, 4.f, B, P, 1, adv, scale, l2, st)); });
+  // ---- a-4 forward / backward
+  bench("dp_apply_fwd (default variant)", out_bytes + (double)B * img, iters, st,
+        [&] { DP(dp_apply_fwd(adv, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, big, st)); });
+  for (int variant : {1, 2, 4, 9, 10, 12}) {
+    char name[64];
+    snprintf(name, sizeof name, "  k_apply_fwd<G=%d,NT=%d>", variant & 7, variant >> 3);
+    bench(name, out_bytes + (double)B * img, iters, st, [&] {
+      DP(launch_apply_fwd(variant, adv, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, big, st));
+    });
+  }
+  bench("dp_apply_bwd (+dp_sum_slabs)", out_bytes + (double)B * img, iters, st, [&] {
+    DP(dp_apply_bwd(big2, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, nslab == 1 ? g_adv : slabs, st));
+    if (nslab > 1) DP(dp_sum_slabs(slabs, nslab, (int64_t)B * 3 * P, g_adv, 0, st));
+  });
+  {  // the shape HotLoop uses per micro-batch: 8 images x 32 masks
+    const int Bm = std::min(B, 8), ns = dp_apply_bwd_nslab(Bm, S, P);
+    float *sl = (float *)dmalloc((size_t)ns * Bm * img);
+    bench("dp_apply_bwd micro-batch 8x32", (double)Bm * S * img + (double)Bm * img, iters, st, [&] {
+      DP(dp_apply_bwd(big2, d_table, 2, d_idx, nullptr, S, Bm, S, H, W, &norm, ns == 1 ? g_adv : sl, st));
+      if (ns > 1) DP(dp_sum_slabs(sl, ns, (int64_t)Bm * 3 * P, g_adv, 0, st));
+    });
+  }
+  // ---- a-7
+  bench("dp_cw_loss (+grad, pred)", (double)N * C * 8, iters, st,
+        [&] { DP(dp_cw_loss(logits, y, tflag, N, C, S, 0.1f, 1.f / S, loss, dlogits, pred, st)); });
+  // ---- a-5 / a-6
+  bench("dp_local_variance", (double)B * P * 16, iters, st, [&] { DP(dp_local_variance(x, B, H, W, lv, st)); });
+  bench("dp_struct_loss (+reduce_rows)", (double)B * P * 16, iters, st, [&] {
+    DP(dp_struct_loss(adv, lv, B, H, W, tpart, st));
+    DP(dp_reduce_rows(tpart, B, ntile, 1.f / P, sloss, st));
+  });
+  bench("dp_mask_stats", (double)B * P * 4, iters, st,
+        [&] { DP(dp_mask_stats(mask, B, H, W, unit, win, cell, wsum, gl, dens, st)); });
+  // ---- a-2 bwd + a-5/a-6 grads + a-9
+  for (int stage = 0; stage < 2; ++stage) {
+    dp_update_cfg_t cfg = {B, H, W, stage, unit, win, 1, 1e-3f, 0.f, 1.f};
+    // x 12 + adv_x 12 + lv 4 + g_adv 12 + pattern 12 r + 12 w + mask 4 r (+ 4 w in stage 0)
+    const double bpp = stage == 0 ? 72.0 : 68.0;
+    bench(stage == 0 ? "dp_project_update stage 0" : "dp_project_update stage 1", (double)B * P * bpp, iters, st,
+          [&] {
+            DP(dp_project_update(&cfg, x, adv, lv, g_adv, scale, structured, coeff, lr, cell, wsum, nullptr,
+                                 pattern, mask, best_p, best_m, nullptr, nullptr, st));
+          });
+  }
+  CK(hipStreamSynchronize(st));
+  return 0;
+}
