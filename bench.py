@@ -52,6 +52,10 @@ def parse():
                     help="1: torch.backends.cudnn.benchmark=True (MIOpen exhaustive find: minutes on a fresh box); "
                          "0: MIOpen immediate mode")
     ap.add_argument("--no-fused-gn", action="store_true", help="eager GroupNorm+ReLU instead of dp_gn_relu_*")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for functional "
+                                                       "multi-rank tests on a single GPU)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="all ranks use cuda:0 (functional test of the multi-rank path on a 1-GPU box; gloo only)")
     return ap.parse_args()
 
 
@@ -111,13 +115,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (no CPU fallback for the product path)"
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
         pg = dist.group.WORLD
 
     from dorpatch_amd.attack import DorPatch, HotLoop

@@ -460,61 +460,72 @@ __global__ __launch_bounds__(kBlock) void k_reduce_rows(const float *__restrict_
 }
 
 // ----------------------------------------------------------------------------
-// a-6: mask statistics (one block per image; the mask is 200 KB @224)
+// a-6: mask statistics.  Two launches: k_mask_bands (one workgroup per row band of cells or of
+// density windows, (ncy + nwy) * B workgroups) and k_mask_finish (one workgroup per image).
 // ----------------------------------------------------------------------------
 
-__global__ __launch_bounds__(kBlock) void k_mask_stats(
+// blockIdx.x <  ncy : conv_group(mask**2) for cell row cy = blockIdx.x (attack.py:72-74, 243-244):
+//                     the unit x W band is staged in LDS with coalesced float4 loads, then one
+//                     thread per cell sums its unit x unit values in (row, col) order.
+// blockIdx.x >= ncy : conv_density(mask) for window row ky = blockIdx.x - ncy (attack.py:77-80,
+//                     237): one wave per window, lanes strided over the win x win pixels.
+__global__ __launch_bounds__(kBlock) void k_mask_bands(
     const float *__restrict__ mask, int H, int W, int unit, int win, int ncy, int ncx, int nwy,
-    int nwx, float *__restrict__ cell_sumsq, float *__restrict__ win_sum,
-    float *__restrict__ group_lasso, float *__restrict__ density) {
-  __shared__ float sm4[4];
-  __shared__ float s_win[256];
-  const int b = blockIdx.x;
+    int nwx, float *__restrict__ cell_sumsq, float *__restrict__ win_sum) {
+  extern __shared__ __attribute__((aligned(16))) float band[];  // unit * W floats
+  const int b = blockIdx.y;
   const float *m = mask + (size_t)b * H * W;
+  if ((int)blockIdx.x < ncy) {
+    const int cy = blockIdx.x;
+    const int W4 = W >> 2, n4 = unit * W4;
+    const f4 *src = reinterpret_cast<const f4 *>(m + (size_t)cy * unit * W);  // rows are contiguous
+    f4 *dst = reinterpret_cast<f4 *>(band);
+    for (int i = threadIdx.x; i < n4; i += kBlock) dst[i] = src[i];
+    __syncthreads();
+    for (int cx = threadIdx.x; cx < ncx; cx += kBlock) {
+      float acc = 0.f;
+      for (int i = 0; i < unit; ++i) {
+        const float *rowp = band + i * W + cx * unit;
+        for (int j = 0; j < unit; ++j) acc += rowp[j] * rowp[j];
+      }
+      cell_sumsq[((size_t)b * ncy + cy) * ncx + cx] = acc;
+    }
+  } else {
+    const int ky = blockIdx.x - ncy;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int kx = wid; kx < nwx; kx += kBlock / 64) {
+      float acc = 0.f;
+      for (int i = lane; i < win * win; i += 64) {
+        const int r = i / win, c = i - r * win;
+        acc += m[(size_t)(ky * win + r) * W + kx * win + c];
+      }
+      acc = wave_sum(acc);
+      if (lane == 0) win_sum[((size_t)b * nwy + ky) * nwx + kx] = acc;
+    }
+  }
+}
 
-  // conv_group(mask**2): unit x unit cells, stride unit (attack.py:72-74, 243-244)
+__global__ __launch_bounds__(kBlock) void k_mask_finish(
+    const float *__restrict__ cell_sumsq, const float *__restrict__ win_sum, int unit, int ncell,
+    int nwindow, float *__restrict__ group_lasso, float *__restrict__ density) {
+  __shared__ float sm4[4];
+  const int b = blockIdx.x;
   float gl_acc = 0.f;
-  const int ncell = ncy * ncx;
-  for (int cell = threadIdx.x; cell < ncell; cell += kBlock) {
-    const int cy = cell / ncx, cx = cell - cy * ncx;
-    float acc = 0.f;
-    for (int i = 0; i < unit; ++i) {
-      const float *rowp = m + (size_t)(cy * unit + i) * W + cx * unit;
-      for (int j = 0; j < unit; ++j) acc += rowp[j] * rowp[j];
-    }
-    cell_sumsq[(size_t)b * ncell + cell] = acc;
-    gl_acc += sqrtf(acc);
-  }
+  for (int cell = threadIdx.x; cell < ncell; cell += kBlock)
+    gl_acc += sqrtf(cell_sumsq[(size_t)b * ncell + cell]);
   const float gl_tot = block_sum(gl_acc, sm4);
-  if (threadIdx.x == 0) group_lasso[b] = (float)unit * gl_tot;
-
-  // conv_density(mask): win x win windows, stride win (attack.py:77-80, 237)
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int nwindow = nwy * nwx;
-  for (int k = wid; k < nwindow; k += kBlock / 64) {
-    const int ky = k / nwx, kx = k - ky * nwx;
-    float acc = 0.f;
-    for (int i = lane; i < win * win; i += 64) {
-      const int r = i / win, c = i - r * win;
-      acc += m[(size_t)(ky * win + r) * W + kx * win + c];
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      win_sum[(size_t)b * nwindow + k] = acc;
-      s_win[k] = acc;
-    }
-  }
-  __syncthreads();
   if (threadIdx.x == 0) {
+    group_lasso[b] = (float)unit * gl_tot;  // attack.py:243-244
+    const float *ws = win_sum + (size_t)b * nwindow;
     float mean = 0.f;
-    for (int k = 0; k < nwindow; ++k) mean += s_win[k];
+    for (int k = 0; k < nwindow; ++k) mean += ws[k];
     mean /= (float)nwindow;
     float var = 0.f;
     for (int k = 0; k < nwindow; ++k) {
-      const float d = s_win[k] - mean;
+      const float d = ws[k] - mean;
       var += d * d;
     }
-    density[b] = var / (float)(nwindow - 1);  // torch.var: unbiased
+    density[b] = var / (float)(nwindow - 1);  // torch.var: unbiased (attack.py:237)
   }
 }
 
@@ -1124,9 +1135,14 @@ int dp_mask_stats(const float *mask, int B, int H, int W, int unit, int win, flo
              win <= H && win <= W);
   const int ncy = (H - unit) / unit + 1, ncx = (W - unit) / unit + 1;
   const int nwy = (H - win) / win + 1, nwx = (W - win) / win + 1;
-  DP_REQUIRE(nwy * nwx >= 2 && nwy * nwx <= 256);
-  hipLaunchKernelGGL(k_mask_stats, dim3(B), dim3(kBlock), 0, as_stream(stream), mask, H, W, unit,
-                     win, ncy, ncx, nwy, nwx, cell_sumsq, win_sum, group_lasso, density);
+  DP_REQUIRE(nwy * nwx >= 2 && B <= 65535);
+  DP_REQUIRE((W & 3) == 0 && aligned16(mask));
+  const size_t lds = (size_t)unit * W * sizeof(float);
+  DP_REQUIRE(lds <= 64 * 1024);
+  hipLaunchKernelGGL(k_mask_bands, dim3(ncy + nwy, B), dim3(kBlock), lds, as_stream(stream), mask, H, W,
+                     unit, win, ncy, ncx, nwy, nwx, cell_sumsq, win_sum);
+  hipLaunchKernelGGL(k_mask_finish, dim3(B), dim3(kBlock), 0, as_stream(stream), cell_sumsq, win_sum,
+                     unit, ncy * ncx, nwy * nwx, group_lasso, density);
   return launch_status();
 }
 

@@ -198,8 +198,10 @@ def test_project_update_grads_and_update(stage, B, H):
     assert np.array_equal(np.isnan(gm.cpu().numpy()), np.isnan(gm_want))
     if stage == 0:
         assert np.isnan(gm_want).sum() == 49
+        # the density term is (window_sum - mean) * 3e-5 with window sums ~ H*H/128: the reference's own
+        # fp32 accumulation of a 28x28 window is only good to ~3e-4 absolute, i.e. ~1e-8 in the gradient
         np.testing.assert_allclose(np.nan_to_num(gm.cpu().numpy()), np.nan_to_num(gm_want), rtol=1e-4,
-                                   atol=1e-6 * np.nanmax(np.abs(gm_want)))
+                                   atol=1e-4 * np.nanmax(np.abs(gm_want)))
     assert torch.equal(p.cpu(), c["p"]) and torch.equal(m.cpu(), c["m"])       # do_update=False
     # now the signed update + best-copy
     best_p, best_m = torch.zeros_like(p), torch.zeros_like(m)
