@@ -43,7 +43,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="images per step (config 2: 64)")
     ap.add_argument("--samples", type=int, default=32, help="sampled masks per image per GPU (config 2: 32)")
     ap.add_argument("--size", type=int, default=224)
-    ap.add_argument("--micro-batch", type=int, default=256, help="EOT samples per backbone fwd/bwd")
+    ap.add_argument("--micro-batch", type=int, default=512, help="EOT samples per backbone fwd/bwd")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="time only the CPU oracle leg (no GPU needed)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0: min(cores, 32))")
     ap.add_argument("--patch-budget", type=float, default=0.0204, help="32x32 px @224 (SURVEY §0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the separately-timed collect_failure sweep")
@@ -66,12 +68,16 @@ def build_model(device):
     return NormModel(net, get_normalize("imagenet", "resnetv2")).to(device).eval()
 
 
-def cpu_baseline(size, n_masks=16, steps=2):
+def cpu_baseline(size, n_masks=16, max_steps=3, budget_s=25.0, threads=None):
     """The reference step restated on the CPU (oracle/restatement.py), weights left trainable as the
-    reference leaves them, all host cores, B = 1 (the only batch the reference supports)."""
+    reference leaves them, B = 1 (the only batch the reference supports).  Bounded: stops
+    after `max_steps` timed steps or `budget_s` seconds, whichever comes first.  `threads` defaults to
+    min(host cores, 32): oneDNN convolutions at batch 16 do not scale past one CCD-group of a big
+    2-socket host (256 threads measured 0.13 samples/s on a 2x64-core EPYC 9575F)."""
     from oracle import restatement as R
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    threads = int(threads or min(cores, 32))
+    torch.set_num_threads(threads)
     model = build_model("cpu")
     for p in model.parameters():
         p.requires_grad_(True)            # as-is: the reference never freezes the backbone
@@ -88,16 +94,36 @@ def cpu_baseline(size, n_masks=16, steps=2):
         R.eot_step(model, x, mask, pattern, y, keep, stage=0, targeted=True, n_classes=1000, lr=0.01,
                    local_var_x=lvx)
         model.zero_grad(set_to_none=True)
-    one()                                  # warm-up (oneDNN primitive creation)
     t0 = time.perf_counter()
-    for _ in range(steps):
+    one()                                  # warm-up (oneDNN primitive creation)
+    t_warm = time.perf_counter() - t0
+    done, t0 = 0, time.perf_counter()
+    while done < max_steps and (time.perf_counter() - t0) + t_warm < budget_s:
         one()
+        done += 1
     dt = time.perf_counter() - t0
-    return {"value": round(n_masks * steps / dt, 3), "unit": "EOT-samples/s", "cores": cores,
-            "kind": "port",
+    if done == 0:                          # the warm-up alone exhausted the budget: report it
+        done, dt = 1, t_warm
+    return {"value": round(n_masks * done / dt, 3), "unit": "EOT-samples/s", "cores": threads,
+            "host_cores": cores, "kind": "port",
             "sample": "oracle/restatement.eot_step (reference step, backbone weights trainable as in the "
-                      "reference), B=1 x %d masks x %d steps @%dx%d fp32, 1 warm-up step discarded"
-                      % (n_masks, steps, size, size)}
+                      "reference), B=1 x %d masks x %d steps @%dx%d fp32, %d threads, 1 warm-up step "
+                      "(%.1f s)" % (n_masks, done, size, size, threads, t_warm)}
+
+
+def pmc_traffic(B, S, H):
+    """HBM bytes per dp_apply_fwd launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE runs of tools/kbench; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM, WRITE_SIZE
+    verified exact against the fill/copy calibration kernels).  None when no pass matches this geometry."""
+    path = os.path.join(ROOT, "profiles", "pmc_apply_fwd.json")
+    try:
+        with open(path) as f:
+            for rec in json.load(f)["records"]:
+                if (rec["B"], rec["S"], rec["H"]) == (B, S, H):
+                    return rec["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def note(msg):
@@ -110,6 +136,9 @@ T_START = time.perf_counter()
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.size, threads=args.cpu_threads or None)))
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -191,7 +220,9 @@ def main():
 
     if rank == 0:
         P = H * H
-        apply_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+        apply_ms = float(np.mean([t.ms() for t in events]))   # kernel-begin -> kernel-end (dp_apply_fwd_timed)
+        for t in events:
+            t.close()
         algo_bytes = B * S_local * 3 * P * 4          # 3*P*4 B written per EOT sample
         achieved = algo_bytes / (apply_ms * 1e-3) / 1e9
         value = B * S * args.steps / dt
@@ -210,14 +241,14 @@ def main():
                        "parallelism": "eot-sample sharding x%d, 1 all-reduce of the patch gradient per step" % world},
             "roofline": {"kernel": "k_apply_fwd (dp_apply_fwd)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(B, S_local, H),
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(apply_ms, 4)},
         }
         if dt_sweep is not None:
             out["collect_failure_sweep_ms"] = round(dt_sweep * 1e3, 1)
             out["value_with_sweep_amortised"] = round(B * S * 100 / (100 * dt / args.steps + dt_sweep), 2)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(H)
+            out["cpu_baseline"] = cpu_baseline(H, threads=args.cpu_threads or None)
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
-DP_ABI_VERSION = 1
+DP_ABI_VERSION = 2
 DP_MAX_RECTS = 4
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
@@ -58,8 +58,15 @@ PROTOTYPES = {
     "dp_mask_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "dp_project_update": (_I, [ctypes.POINTER(DpUpdateCfg)] + [_P] * 18),
     "dp_argmax": (_I, [_P, _I, _I, _P, _P]),
-    "dp_gn_relu_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P]),
-    "dp_gn_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "dp_gn_relu_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P]),
+    "dp_gn_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "dp_pad_maxpool_fwd": (_I, [_P, _L, _I, _I, _P, _P, _P]),
+    "dp_pad_maxpool_bwd": (_I, [_P, _P, _L, _I, _I, _P, _P]),
+    "dp_stem_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "dp_event_create": (_I, [ctypes.POINTER(ctypes.c_void_p)]),
+    "dp_event_destroy": (_I, [_P]),
+    "dp_event_elapsed_ms": (_I, [_P, _P, ctypes.POINTER(ctypes.c_float)]),
+    "dp_apply_fwd_timed": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, ctypes.POINTER(DpNorm), _P, _P, _P, _P]),
 }
 
 _lib = None

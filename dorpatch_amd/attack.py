@@ -647,14 +647,11 @@ class HotLoop(object):
         B, Sl, S = self.B, self.S_local, self.S
         upstream = 1.0 / float(S)                  # loss_adv.mean(1) then .sum().backward()
         mb = max(1, self.o.micro_batch)
-        ev = self.kernel_events
-        if ev is not None:      # bench.py: HIP events on the launch stream around the dominant kernel
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        inp_all = ops.apply_fwd(self.adv_x, self.table, idx, idx2, self.dn)      # (B*Sl,3,H,W)
-        if ev is not None:
-            e1.record()
-            ev.append((e0, e1))
+        timer = None
+        if self.kernel_events is not None:   # bench.py: HIP events stamped by the dominant kernel itself
+            timer = ops.KernelTimer()
+            self.kernel_events.append(timer)
+        inp_all = ops.apply_fwd(self.adv_x, self.table, idx, idx2, self.dn, timer=timer)   # (B*Sl,3,H,W)
         loss_flat = torch.empty((B * Sl,), dtype=torch.float32, device=self.dev)
         if Sl <= mb:
             ipm = max(1, mb // Sl)                 # whole images per micro-batch

@@ -18,6 +18,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "dorpatch_hip.h"
@@ -702,6 +703,9 @@ __device__ __forceinline__ float block_allsum(float v, float *sm /* T/64 floats 
 
 struct GnArgs {
   const float *x, *gamma, *beta;
+  const float *res;   // forward: optional residual, the normalised tensor is x + res (nullptr: x)
+  float *sum_out;     // forward: x + res is also written here (the next block's shortcut)
+  const float *dres;  // backward: optional extra gradient w.r.t. (x + res), added to the result
   int C, HW, Cg;      // channels, pixels per channel, channels per group
   float eps, inv_hw;  // inv_hw = 1 / HW
 };
@@ -743,6 +747,8 @@ __global__ __launch_bounds__(T) void k_gn_relu_fwd(GnArgs A, float *__restrict__
   const int L = A.Cg * A.HW, L4 = L >> 2;
   const f4 *x4 = reinterpret_cast<const f4 *>(A.x + (size_t)ng * L);
   f4 *y4 = reinterpret_cast<f4 *>(y + (size_t)ng * L);
+  const f4 *r4 = A.res ? reinterpret_cast<const f4 *>(A.res + (size_t)ng * L) : nullptr;
+  f4 *s4 = A.res ? reinterpret_cast<f4 *>(A.sum_out + (size_t)ng * L) : nullptr;
   f4 v[V];
   float s = 0.f;
 #pragma unroll
@@ -750,6 +756,10 @@ __global__ __launch_bounds__(T) void k_gn_relu_fwd(GnArgs A, float *__restrict__
     const int i = threadIdx.x + k * T;
     if (i < L4) {
       v[k] = x4[i];
+      if (r4) {  // fused residual add (block output + shortcut): one extra read, one extra write
+        v[k] += r4[i];
+        s4[i] = v[k];
+      }
       s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
     }
   }
@@ -832,10 +842,15 @@ __global__ __launch_bounds__(T) void k_gn_relu_bwd(GnArgs A, const float *__rest
   }
   const float m1 = block_allsum<T>(s1, sm1) / (float)L;
   const float m2 = block_allsum<T>(s2, sm2) / (float)L;
+  const f4 *d4 = A.dres ? reinterpret_cast<const f4 *>(A.dres + (size_t)ng * L) : nullptr;
 #pragma unroll
   for (int k = 0; k < V; ++k) {
     const int i = threadIdx.x + k * T;
-    if (i < L4) o4[i] = (dh[k] - m1) - xh[k] * m2;  // rstd already folded into dh (a = rstd*gamma)
+    if (i < L4) {
+      f4 o = (dh[k] - m1) - xh[k] * m2;  // rstd already folded into dh (a = rstd*gamma)
+      if (d4) o += d4[i];                // gradient arriving through the shortcut (fused autograd add)
+      o4[i] = o;
+    }
   }
 }
 
@@ -855,9 +870,20 @@ __global__ __launch_bounds__(kGnStreamT) void k_gn_relu_fwd_stream(GnArgs A, flo
   const f4 *x4 = reinterpret_cast<const f4 *>(A.x + (size_t)ng * L);
   f4 *y4 = reinterpret_cast<f4 *>(y + (size_t)ng * L);
   float s = 0.f;
-  for (int i = threadIdx.x; i < L4; i += T) {
-    const f4 v = x4[i];
-    s += (v.x + v.y) + (v.z + v.w);
+  if (A.res) {  // pass 0 materialises x + res; the later passes re-read it (each thread its own elements)
+    const f4 *r4 = reinterpret_cast<const f4 *>(A.res + (size_t)ng * L);
+    f4 *s4 = reinterpret_cast<f4 *>(A.sum_out + (size_t)ng * L);
+    for (int i = threadIdx.x; i < L4; i += T) {
+      const f4 v = x4[i] + r4[i];
+      s4[i] = v;
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+    x4 = s4;
+  } else {
+    for (int i = threadIdx.x; i < L4; i += T) {
+      const f4 v = x4[i];
+      s += (v.x + v.y) + (v.z + v.w);
+    }
   }
   const float mean = block_allsum<T>(s, sm1) / (float)L;
   float q = 0.f;
@@ -929,8 +955,201 @@ __global__ __launch_bounds__(kGnStreamT) void k_gn_relu_bwd_stream(
       const float go = (z > 0.f) ? gs[j] * a[j] : 0.f;
       o[j] = (go - m1) - ((xs[j] - mean) * rstd) * m2;
     }
-    o4[i] = f4{o[0], o[1], o[2], o[3]};
+    f4 ov = f4{o[0], o[1], o[2], o[3]};
+    if (A.dres) ov += reinterpret_cast<const f4 *>(A.dres + (size_t)ng * L)[i];
+    o4[i] = ov;
   }
+}
+
+
+// ----------------------------------------------------------------------------
+// a-8 (backbone stem): ConstantPad2d(1, 0) + MaxPool2d(3, stride 2), fused, forward and
+// backward (the "fixed" BiT stem, timm 0.6.7 resnetv2 create_resnetv2_stem; reference call
+// sites utils.py:51-63, attack.py:222, 247).  Eager PyTorch materialises the padded tensor
+// and its max-pool backward scatters; here the forward reads the conv output once and emits
+// the pooled map + a 1-byte argmax code, the backward is a gather (no atomics, float4 stores).
+// Window of output (oh, ow): input rows 2oh-1..2oh+1, cols 2ow-1..2ow+1, out-of-range = 0 and
+// participates in the max exactly like the padded tensor does; ties: first in row-major
+// window order (strict >), NaN wins — torch's max_pool2d rule.  code = 3*r + c of the winner.
+// Requires Hin even, Win % 8 == 0 (so an output row is whole float4s and no bottom/right pad).
+// ----------------------------------------------------------------------------
+
+__global__ __launch_bounds__(kBlock) void k_pad_maxpool_fwd(const float *__restrict__ x, int Hin,
+                                                            int Win, long total /* NC*Ho*Wo/4 */,
+                                                            float *__restrict__ y,
+                                                            uint32_t *__restrict__ code4) {
+  const long tid = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (tid >= total) return;
+  const int Ho = Hin >> 1, Wq = Win >> 3;  // Wo/4 quads per output row
+  const int q = (int)(tid % Wq);
+  const long t2 = tid / Wq;
+  const int oh = (int)(t2 % Ho);
+  const long nc = t2 / Ho;
+  const float *xp = x + nc * (long)Hin * Win;
+  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  unsigned code[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int ih = 2 * oh - 1 + r;
+    float v[9];
+    if (ih >= 0) {  // ih <= Hin - 1 always (Hin even)
+      const float *row = xp + (long)ih * Win + 8 * q;
+      const f4 a = *reinterpret_cast<const f4 *>(row);
+      const f4 b = *reinterpret_cast<const f4 *>(row + 4);
+      v[0] = q > 0 ? row[-1] : 0.f;  // left pad
+      v[1] = a.x; v[2] = a.y; v[3] = a.z; v[4] = a.w;
+      v[5] = b.x; v[6] = b.y; v[7] = b.z; v[8] = b.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) v[k] = 0.f;  // top pad row
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float val = v[2 * j + c];
+        if (val > best[j] || val != val) {
+          best[j] = val;
+          code[j] = (unsigned)(3 * r + c);
+        }
+      }
+    }
+  }
+  reinterpret_cast<f4 *>(y)[tid] = f4{best[0], best[1], best[2], best[3]};
+  code4[tid] = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+}
+
+__global__ __launch_bounds__(kBlock) void k_pad_maxpool_bwd(const float *__restrict__ dy,
+                                                            const uint8_t *__restrict__ code,
+                                                            int Hin, int Win,
+                                                            long total /* NC*Hin*Win/4 */,
+                                                            float *__restrict__ dx) {
+  const long tid = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (tid >= total) return;
+  const int Ho = Hin >> 1, Wo = Win >> 1, W4 = Win >> 2;
+  const int t = (int)(tid % W4);
+  const long t2 = tid / W4;
+  const int h = (int)(t2 % Hin);
+  const long nc = t2 / Hin;
+  const float *dyp = dy + nc * (long)Ho * Wo;
+  const uint8_t *cp = code + nc * (long)Ho * Wo;
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+  const int a = h >> 1;
+  // (oh, r) pairs whose window contains input row h
+  const int n_rows = (h & 1) ? 2 : 1;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (k >= n_rows) break;
+    const int oh = (h & 1) ? a + k : a;
+    const int r = (h & 1) ? (k == 0 ? 2 : 0) : 1;
+    if (oh >= Ho) continue;
+    const long base = (long)oh * Wo + 2 * t;
+    const float g0 = dyp[base], g1 = dyp[base + 1];
+    const unsigned c0 = cp[base], c1 = cp[base + 1];
+    const bool has2 = (2 * t + 2) < Wo;
+    const float g2 = has2 ? dyp[base + 2] : 0.f;
+    const unsigned c2 = has2 ? cp[base + 2] : 255u;
+    const unsigned rc = 3u * (unsigned)r;
+    // input col 4t   (even): window ow = 2t,   c = 1
+    // input col 4t+1 (odd):  ow = 2t (c = 2),  ow = 2t+1 (c = 0)
+    // input col 4t+2 (even): ow = 2t+1, c = 1
+    // input col 4t+3 (odd):  ow = 2t+1 (c = 2), ow = 2t+2 (c = 0)
+    o[0] += (c0 == rc + 1u) ? g0 : 0.f;
+    o[1] += (c0 == rc + 2u) ? g0 : 0.f;
+    o[1] += (c1 == rc + 0u) ? g1 : 0.f;
+    o[2] += (c1 == rc + 1u) ? g1 : 0.f;
+    o[3] += (c1 == rc + 2u) ? g1 : 0.f;
+    o[3] += (c2 == rc + 0u) ? g2 : 0.f;
+  }
+  reinterpret_cast<f4 *>(dx)[tid] = f4{o[0], o[1], o[2], o[3]};
+}
+
+
+// ----------------------------------------------------------------------------
+// a-8 (backbone stem): input gradient of the 7x7 / stride 2 / pad 3 stem convolution,
+// d loss / d image (N,3,H,W) from d loss / d stem-out (N,K,H/2,W/2) — the last conv of the
+// backward pass and the tensor dp_apply_bwd consumes (reference attack.py:247).  With only 3 output
+// channels it is a poor fit for library implicit-GEMM / Winograd kernels (4 ms per 256 samples
+// measured for MIOpen's); here it is a direct gather on the fp32 VALU:
+//   * a thread owns a 2x2 output quad (h = 2a+ph, w = 2b+pw) x 3 channels = 12 accumulators;
+//     the four parities use disjoint filter taps: i = ph + 5 - 2r, j = pw + 5 - 2s over the 4x4
+//     patch dy[a-1+r][b-1+s]  (3x3, 3x4, 4x3, 4x4 taps: all 49 weights exactly once per (k, c));
+//   * the filter is read through wave-uniform scalar loads (SGPR operands of v_fmac), so the
+//     inner loop is 147 FMAs per 16 LDS reads per input channel k;
+//   * dy tiles (16x16 quads + 3 halo) are staged through LDS one k-plane at a time.
+// fmaf is used explicitly (one rounding per MAC; the file is built with -ffp-contract=off).
+// ----------------------------------------------------------------------------
+
+constexpr int SQ = 16;            // quads per tile side -> 256 threads
+constexpr int ST = SQ + 3;        // dy tile side (halo: 1 before, 2 after)
+
+__global__ __launch_bounds__(kBlock) void k_stem_dgrad(const float *__restrict__ dy,
+                                                       const float *__restrict__ w, int K, int Ho,
+                                                       int Wo, float *__restrict__ dx) {
+  __shared__ float tile[2][ST][ST + 1];
+  const int n = blockIdx.z;
+  const int a0 = blockIdx.y * SQ, b0 = blockIdx.x * SQ;
+  const int ta = threadIdx.x / SQ, tb = threadIdx.x % SQ;
+  const float *dyn = dy + (size_t)n * K * Ho * Wo;
+  float acc[3][2][2];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+      for (int pw = 0; pw < 2; ++pw) acc[c][ph][pw] = 0.f;
+
+  auto stage = [&](int k, int buf) {
+    const float *plane = dyn + (size_t)k * Ho * Wo;
+    for (int e = threadIdx.x; e < ST * ST; e += kBlock) {
+      const int r = e / ST, c = e - r * ST;
+      const int oh = a0 - 1 + r, ow = b0 - 1 + c;
+      float v = 0.f;
+      if (oh >= 0 && oh < Ho && ow >= 0 && ow < Wo) v = plane[(size_t)oh * Wo + ow];
+      tile[buf][r][c] = v;
+    }
+  };
+
+  stage(0, 0);
+  __syncthreads();
+  for (int k = 0; k < K; ++k) {
+    const int buf = k & 1;
+    if (k + 1 < K) stage(k + 1, buf ^ 1);  // the other buffer was last read two barriers ago
+    float p[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) p[r][q] = tile[buf][ta + r][tb + q];
+    const float *wk = w + (size_t)k * 147;  // wave-uniform: scalar loads
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int i = ph + 5 - 2 * r, j = pw + 5 - 2 * q;
+              if (i >= 0 && i <= 6 && j >= 0 && j <= 6)
+                acc[c][ph][pw] = __builtin_fmaf(p[r][q], wk[c * 49 + i * 7 + j], acc[c][ph][pw]);
+            }
+    __syncthreads();
+  }
+  const int a = a0 + ta, b = b0 + tb;
+  if (a >= Ho || b >= Wo) return;
+  const int H = 2 * Ho, W = 2 * Wo;
+  float *dxn = dx + (size_t)n * 3 * H * W;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      float2 o;
+      o.x = acc[c][ph][0];
+      o.y = acc[c][ph][1];
+      *reinterpret_cast<float2 *>(dxn + ((size_t)c * H + 2 * a + ph) * W + 2 * b) = o;
+    }
 }
 
 // (V float4 per thread, T threads) combinations that are instantiated, smallest first; the
@@ -964,7 +1183,8 @@ constexpr int kApplyFwdDefaultVariant = 1 + 8;
 
 int launch_apply_fwd(int variant, const float *adv_x, const int32_t *table, int R,
                      const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H,
-                     int W, const dp_norm_t *norm, float *out, dp_stream_t stream) {
+                     int W, const dp_norm_t *norm, float *out, dp_stream_t stream,
+                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
   const int G = variant & 7;
   const bool nt = (variant & 8) != 0;
   DP_REQUIRE(G == 1 || G == 2 || G == 4);
@@ -980,9 +1200,11 @@ int launch_apply_fwd(int variant, const float *adv_x, const int32_t *table, int 
   const dim3 grid(tiles, nchunk, B), block(kBlock);
   const NormDev nd = make_norm(norm);
   hipStream_t st = as_stream(stream);
+  // hipExtLaunchKernelGGL stamps the events with the kernel's own begin / end (what rocprofv3 reports),
+  // not with the position of a marker packet in the queue
 #define DP_LAUNCH_FWD(G_, NT_)                                                                    \
-  hipLaunchKernelGGL((k_apply_fwd<G_, NT_>), grid, block, 0, st, adv_x, table, R, idx, idx2,       \
-                     idx_bstride, S, H, W, s_per_block, nd, out)
+  hipExtLaunchKernelGGL((k_apply_fwd<G_, NT_>), grid, block, 0, st, ev_start, ev_stop, 0, adv_x,   \
+                        table, R, idx, idx2, idx_bstride, S, H, W, s_per_block, nd, out)
   if (G == 1 && nt) DP_LAUNCH_FWD(1, true);
   else if (G == 1) DP_LAUNCH_FWD(1, false);
   else if (G == 2 && nt) DP_LAUNCH_FWD(2, true);
@@ -1197,17 +1419,22 @@ static int gn_check(const float *x, const float *gamma, const float *beta, int N
   DP_REQUIRE((L & 3) == 0 && L < (1L << 20));  // float4 lanes; chan_of() exactness bound
   DP_REQUIRE((long)N * G <= 0x7fffffffL);
   A.x = x; A.gamma = gamma; A.beta = beta;
+  A.res = nullptr; A.sum_out = nullptr; A.dres = nullptr;
   A.C = C; A.HW = HW; A.Cg = C / G;
   A.eps = eps; A.inv_hw = 1.f / (float)HW;
   return 0;
 }
 
-int dp_gn_relu_fwd(const float *x, const float *gamma, const float *beta, int N, int C, int HW,
-                   int G, float eps, float *y, float *mean, float *rstd, dp_stream_t stream) {
+int dp_gn_relu_fwd(const float *x, const float *res, float *sum_out, const float *gamma,
+                   const float *beta, int N, int C, int HW, int G, float eps, float *y, float *mean,
+                   float *rstd, dp_stream_t stream) {
   GnArgs A;
   const int rc = gn_check(x, gamma, beta, N, C, HW, G, A, eps);
   if (rc) return rc;
   DP_REQUIRE(y && mean && rstd && aligned16(y));
+  DP_REQUIRE(!res || (sum_out && aligned16(res) && aligned16(sum_out)));
+  A.res = res;
+  A.sum_out = res ? sum_out : nullptr;
   const int L4 = (A.Cg * HW) >> 2;
   int V, T;
   gn_pick(L4, V, T);
@@ -1218,13 +1445,15 @@ int dp_gn_relu_fwd(const float *x, const float *gamma, const float *beta, int N,
   return launch_status();
 }
 
-int dp_gn_relu_bwd(const float *dy, const float *x, const float *gamma, const float *beta,
-                   const float *mean, const float *rstd, int N, int C, int HW, int G, float *dx,
-                   dp_stream_t stream) {
+int dp_gn_relu_bwd(const float *dy, const float *dres, const float *x, const float *gamma,
+                   const float *beta, const float *mean, const float *rstd, int N, int C, int HW,
+                   int G, float *dx, dp_stream_t stream) {
   GnArgs A;
   const int rc = gn_check(x, gamma, beta, N, C, HW, G, A, 0.f);
   if (rc) return rc;
   DP_REQUIRE(dy && mean && rstd && dx && aligned16(dy) && aligned16(dx));
+  DP_REQUIRE(!dres || aligned16(dres));
+  A.dres = dres;
   const int L4 = (A.Cg * HW) >> 2;
   int V, T;
   gn_pick(L4, V, T);
@@ -1233,6 +1462,71 @@ int dp_gn_relu_bwd(const float *dy, const float *x, const float *gamma, const fl
   if (V == 0) hipLaunchKernelGGL(k_gn_relu_bwd_stream, grid, dim3(kGnStreamT), 0, st, A, dy, mean, rstd, dx);
   else DP_GN_DISPATCH(k_gn_relu_bwd, V, T, A, dy, mean, rstd, dx);
   return launch_status();
+}
+
+int dp_pad_maxpool_fwd(const float *x, int64_t NC, int Hin, int Win, float *y, uint8_t *code,
+                       dp_stream_t stream) {
+  DP_REQUIRE(x && y && code && aligned16(x) && aligned16(y) && aligned16(code));
+  DP_REQUIRE(NC > 0 && Hin >= 2 && Win >= 8 && (Hin & 1) == 0 && (Win & 7) == 0);
+  const long total = NC * (Hin >> 1) * (Win >> 3);
+  const long blocks = (total + kBlock - 1) / kBlock;
+  DP_REQUIRE(blocks <= 0x7fffffffL);
+  hipLaunchKernelGGL(k_pad_maxpool_fwd, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), x,
+                     Hin, Win, total, y, reinterpret_cast<uint32_t *>(code));
+  return launch_status();
+}
+
+int dp_pad_maxpool_bwd(const float *dy, const uint8_t *code, int64_t NC, int Hin, int Win, float *dx,
+                       dp_stream_t stream) {
+  DP_REQUIRE(dy && dx && code && aligned16(dx));
+  DP_REQUIRE(NC > 0 && Hin >= 2 && Win >= 8 && (Hin & 1) == 0 && (Win & 7) == 0);
+  const long total = NC * Hin * (Win >> 2);
+  const long blocks = (total + kBlock - 1) / kBlock;
+  DP_REQUIRE(blocks <= 0x7fffffffL);
+  hipLaunchKernelGGL(k_pad_maxpool_bwd, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), dy,
+                     code, Hin, Win, total, dx);
+  return launch_status();
+}
+
+int dp_stem_dgrad(const float *dy, const float *w, int N, int K, int Ho, int Wo, float *dx,
+                  dp_stream_t stream) {
+  DP_REQUIRE(dy && w && dx && N > 0 && N <= 65535 && K > 0 && Ho > 0 && Wo > 0);
+  DP_REQUIRE((reinterpret_cast<uintptr_t>(dx) & 7u) == 0);
+  hipLaunchKernelGGL(k_stem_dgrad, dim3(cdiv(Wo, SQ), cdiv(Ho, SQ), N), dim3(kBlock), 0,
+                     as_stream(stream), dy, w, K, Ho, Wo, dx);
+  return launch_status();
+}
+
+/* ---- measurement support: kernel-precise timing of the dominant kernel (bench.py roofline) ---- */
+int dp_event_create(dp_event_t *ev) {
+  DP_REQUIRE(ev);
+  hipEvent_t e;
+  const hipError_t rc = hipEventCreate(&e);
+  *ev = rc == hipSuccess ? (dp_event_t)e : nullptr;
+  return (int)rc;
+}
+
+int dp_event_destroy(dp_event_t ev) {
+  DP_REQUIRE(ev);
+  return (int)hipEventDestroy((hipEvent_t)ev);
+}
+
+int dp_event_elapsed_ms(dp_event_t start, dp_event_t stop, float *ms) {
+  DP_REQUIRE(start && stop && ms);
+  hipError_t rc = hipEventSynchronize((hipEvent_t)stop);
+  if (rc != hipSuccess) return (int)rc;
+  return (int)hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+}
+
+int dp_apply_fwd_timed(const float *adv_x, const int32_t *table, int R, const int32_t *idx,
+                       const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
+                       const dp_norm_t *norm, float *out, dp_stream_t stream, dp_event_t start,
+                       dp_event_t stop) {
+  DP_REQUIRE(adv_x && out && aligned16(adv_x) && aligned16(out) && start && stop);
+  const int rc = check_occlusion_args(table, R, idx, idx_bstride, B, S, H, W, norm);
+  if (rc) return rc;
+  return launch_apply_fwd(kApplyFwdDefaultVariant, adv_x, table, R, idx, idx2, idx_bstride, B, S, H, W,
+                          norm, out, stream, (hipEvent_t)start, (hipEvent_t)stop);
 }
 
 }  // extern "C"

@@ -97,8 +97,31 @@ def _idx_args(idx, idx2, B):
     return S, bstride
 
 
-def apply_fwd(adv_x, table, idx, idx2=None, norm=RAW_NORM, out=None):
-    """Occlude (+ normalise) B images under S masks each -> (B*S, 3, H, W)."""
+class KernelTimer(object):
+    """A pair of HIP events stamped by the kernel itself (dp_apply_fwd_timed); ``ms()`` blocks."""
+
+    def __init__(self):
+        lib = _lib.load()
+        self.start, self.stop = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.dp_event_create(ctypes.byref(self.start)), "dp_event_create")
+        _lib.check(lib.dp_event_create(ctypes.byref(self.stop)), "dp_event_create")
+
+    def ms(self):
+        out = ctypes.c_float()
+        _lib.check(_lib.load().dp_event_elapsed_ms(self.start, self.stop, ctypes.byref(out)), "dp_event_elapsed_ms")
+        return float(out.value)
+
+    def close(self):
+        lib = _lib.load()
+        for ev in (self.start, self.stop):
+            if ev:
+                lib.dp_event_destroy(ev)
+        self.start = self.stop = None
+
+
+def apply_fwd(adv_x, table, idx, idx2=None, norm=RAW_NORM, out=None, timer=None):
+    """Occlude (+ normalise) B images under S masks each -> (B*S, 3, H, W).
+    ``timer`` (a KernelTimer) makes the launch stamp kernel-begin / kernel-end events."""
     lib = _lib.load()
     _chk(adv_x, torch.float32, "adv_x"), _chk(table, torch.int32, "table")
     B, C, H, W = adv_x.shape
@@ -109,8 +132,13 @@ def apply_fwd(adv_x, table, idx, idx2=None, norm=RAW_NORM, out=None):
     else:
         _chk(out, torch.float32, "out")
         assert out.numel() == B * S * 3 * H * W
-    _lib.check(lib.dp_apply_fwd(_p(adv_x), _p(table), table.shape[1], _p(idx), _p(idx2), bstride,
-                                B, S, H, W, ctypes.byref(norm), _p(out), _stream()), "dp_apply_fwd")
+    if timer is None:
+        _lib.check(lib.dp_apply_fwd(_p(adv_x), _p(table), table.shape[1], _p(idx), _p(idx2), bstride,
+                                    B, S, H, W, ctypes.byref(norm), _p(out), _stream()), "dp_apply_fwd")
+    else:
+        _lib.check(lib.dp_apply_fwd_timed(_p(adv_x), _p(table), table.shape[1], _p(idx), _p(idx2), bstride,
+                                          B, S, H, W, ctypes.byref(norm), _p(out), _stream(), timer.start,
+                                          timer.stop), "dp_apply_fwd_timed")
     return out
 
 
@@ -256,8 +284,9 @@ def gn_relu_supported(x, groups):
     return L % 4 == 0 and L < (1 << 20)
 
 
-def gn_relu_fwd(x, weight, bias, groups, eps):
-    """y = relu(group_norm(x)); also returns the per-(sample, group) mean and rstd for the backward."""
+def gn_relu_fwd(x, weight, bias, groups, eps, res=None):
+    """s = x (+ res);  y = relu(group_norm(s)).  Returns (y, mean, rstd, s); mean / rstd are the
+    per-(sample, group) statistics the backward needs; s is x itself when res is None."""
     lib = _lib.load()
     _chk(x, torch.float32, "x"), _chk(weight, torch.float32, "weight"), _chk(bias, torch.float32, "bias")
     N, C = x.shape[0], x.shape[1]
@@ -265,19 +294,27 @@ def gn_relu_fwd(x, weight, bias, groups, eps):
     y = torch.empty_like(x)
     mean = torch.empty((N * groups,), dtype=torch.float32, device=x.device)
     rstd = torch.empty_like(mean)
-    _lib.check(lib.dp_gn_relu_fwd(_p(x), _p(weight), _p(bias), N, C, HW, int(groups), float(eps), _p(y),
-                                  _p(mean), _p(rstd), _stream()), "dp_gn_relu_fwd")
-    return y, mean, rstd
+    ssum = None
+    if res is not None:
+        _chk(res, torch.float32, "res")
+        assert res.shape == x.shape
+        ssum = torch.empty_like(x)
+    _lib.check(lib.dp_gn_relu_fwd(_p(x), _p(res), _p(ssum), _p(weight), _p(bias), N, C, HW, int(groups),
+                                  float(eps), _p(y), _p(mean), _p(rstd), _stream()), "dp_gn_relu_fwd")
+    return y, mean, rstd, (x if res is None else ssum)
 
 
-def gn_relu_bwd(dy, x, weight, bias, mean, rstd, groups):
-    """d loss / d x of y = relu(group_norm(x)) (weights frozen: no gamma / beta gradients)."""
+def gn_relu_bwd(dy, x, weight, bias, mean, rstd, groups, dres=None):
+    """d loss / d s of y = relu(group_norm(s)) (+ dres, the gradient reaching s through the shortcut).
+    Weights frozen: no gamma / beta gradients."""
     lib = _lib.load()
     _chk(dy, torch.float32, "dy"), _chk(x, torch.float32, "x")
+    if dres is not None:
+        _chk(dres, torch.float32, "dres")
     N, C = x.shape[0], x.shape[1]
     HW = int(np.prod(x.shape[2:]))
     dx = torch.empty_like(x)
-    _lib.check(lib.dp_gn_relu_bwd(_p(dy), _p(x), _p(weight), _p(bias), _p(mean), _p(rstd), N, C, HW,
+    _lib.check(lib.dp_gn_relu_bwd(_p(dy), _p(dres), _p(x), _p(weight), _p(bias), _p(mean), _p(rstd), N, C, HW,
                                   int(groups), _p(dx), _stream()), "dp_gn_relu_bwd")
     return dx
 
@@ -289,7 +326,7 @@ class GnReluFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, groups, eps):
         x = x.contiguous()
-        y, mean, rstd = gn_relu_fwd(x, weight, bias, groups, eps)
+        y, mean, rstd, _ = gn_relu_fwd(x, weight, bias, groups, eps)
         ctx.save_for_backward(x, weight, bias, mean, rstd)
         ctx.groups = groups
         return y
@@ -299,3 +336,103 @@ class GnReluFunction(torch.autograd.Function):
         x, weight, bias, mean, rstd = ctx.saved_tensors
         dx = gn_relu_bwd(dy.contiguous(), x, weight, bias, mean, rstd, ctx.groups)
         return dx, None, None, None, None
+
+
+class AddGnReluFunction(torch.autograd.Function):
+    """(x, res) -> (s, y) with s = x + res and y = relu(group_norm(s)): the bottleneck's residual add
+    fused into the next GroupNorm+ReLU (one kernel each way).  In the backward the gradient arriving
+    at s through the shortcut is added inside dp_gn_relu_bwd, replacing autograd's accumulation add."""
+
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, groups, eps):
+        y, mean, rstd, s = gn_relu_fwd(x.contiguous(), weight, bias, groups, eps, res=res.contiguous())
+        ctx.save_for_backward(s, weight, bias, mean, rstd)
+        ctx.groups = groups
+        ctx.set_materialize_grads(False)
+        return s, y
+
+    @staticmethod
+    def backward(ctx, ds, dy):
+        s, weight, bias, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            dx = ds
+        else:
+            dx = gn_relu_bwd(dy.contiguous(), s, weight, bias, mean, rstd, ctx.groups,
+                             dres=None if ds is None else ds.contiguous())
+        return dx, dx, None, None, None, None
+
+
+# ---------------------------------------------------------------- a-8: fused zero-pad(1) + maxpool 3x3/2 (BiT stem)
+def pad_maxpool_supported(x):
+    return (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and x.shape[2] % 2 == 0 and x.shape[3] % 8 == 0)
+
+
+def pad_maxpool_fwd(x):
+    """max_pool2d(pad(x, 1, value=0), 3, stride=2) -> (y, code uint8 argmax codes for the backward)."""
+    lib = _lib.load()
+    _chk(x, torch.float32, "x")
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    code = torch.empty((N, C, H // 2, W // 2), dtype=torch.uint8, device=x.device)
+    _lib.check(lib.dp_pad_maxpool_fwd(_p(x), N * C, H, W, _p(y), _p(code), _stream()), "dp_pad_maxpool_fwd")
+    return y, code
+
+
+def pad_maxpool_bwd(dy, code, H, W):
+    lib = _lib.load()
+    _chk(dy, torch.float32, "dy"), _chk(code, torch.uint8, "code")
+    N, C = dy.shape[0], dy.shape[1]
+    dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.dp_pad_maxpool_bwd(_p(dy), _p(code), N * C, H, W, _p(dx), _stream()), "dp_pad_maxpool_bwd")
+    return dx
+
+
+class PadMaxPoolFunction(torch.autograd.Function):
+    """autograd node over dp_pad_maxpool_fwd / _bwd; saves 1 byte per output element."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y, code = pad_maxpool_fwd(x)
+        ctx.save_for_backward(code)
+        ctx.hw = (x.shape[2], x.shape[3])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (code,) = ctx.saved_tensors
+        return pad_maxpool_bwd(dy.contiguous(), code, *ctx.hw)
+
+
+# ---------------------------------------------------------------- a-8: stem conv (7x7/2, 3 input channels) input gradient
+def stem_dgrad_supported(x, weight, stride, padding):
+    return (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and tuple(weight.shape[1:]) == (3, 7, 7) and tuple(stride) == (2, 2) and tuple(padding) == (3, 3)
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.shape[0] <= 65535)
+
+
+def stem_dgrad(dy, weight):
+    """d loss / d input of conv2d(input, weight (K,3,7,7), stride 2, padding 3) given dy (N,K,Ho,Wo)."""
+    lib = _lib.load()
+    _chk(dy, torch.float32, "dy"), _chk(weight, torch.float32, "weight")
+    N, K, Ho, Wo = dy.shape
+    assert tuple(weight.shape) == (K, 3, 7, 7)
+    dx = torch.empty((N, 3, 2 * Ho, 2 * Wo), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.dp_stem_dgrad(_p(dy), _p(weight), N, K, Ho, Wo, _p(dx), _stream()), "dp_stem_dgrad")
+    return dx
+
+
+class StemConvFunction(torch.autograd.Function):
+    """Stem convolution with a frozen filter: forward through MIOpen, input gradient through
+    dp_stem_dgrad (the 3-channel transposed convolution libraries handle poorly)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(weight)
+        return torch.nn.functional.conv2d(x, weight, None, 2, 3)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (weight,) = ctx.saved_tensors
+        return stem_dgrad(dy.contiguous(), weight.contiguous()), None

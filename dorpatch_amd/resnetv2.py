@@ -63,12 +63,28 @@ class GroupNormAct(nn.GroupNorm):
     def __init__(self, num_channels, num_groups=32, eps=1e-5):
         super().__init__(num_groups, num_channels, eps=eps, affine=True)
 
-    def forward(self, x):
+    def _use_hip(self, x):
         if GroupNormAct.fused and x.is_cuda and not (self.weight.requires_grad or self.bias.requires_grad):
             from . import ops
-            if ops.gn_relu_supported(x, self.num_groups):
-                return ops.GnReluFunction.apply(x, self.weight, self.bias, self.num_groups, self.eps)
+            return ops.gn_relu_supported(x, self.num_groups)
+        return False
+
+    def forward(self, x):
+        if self._use_hip(x):
+            from . import ops
+            return ops.GnReluFunction.apply(x, self.weight, self.bias, self.num_groups, self.eps)
         return F.relu(F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps), inplace=True)
+
+    def add_forward(self, x, res=None):
+        """(x, res) -> (s, relu(gn(s))) with s = x + res (s = x when res is None): the residual add of
+        the previous bottleneck fused into this norm (one HIP kernel on the GPU hot path)."""
+        if res is None:
+            return x, self.forward(x)
+        if self._use_hip(x):
+            from . import ops
+            return ops.AddGnReluFunction.apply(x, res, self.weight, self.bias, self.num_groups, self.eps)
+        s = x + res
+        return s, F.relu(F.group_norm(s, self.num_groups, self.weight, self.bias, self.eps), inplace=False)
 
 
 class DownsampleConv(nn.Module):
@@ -92,12 +108,18 @@ class PreActBottleneck(nn.Module):
         self.norm3 = GroupNormAct(mid)
         self.conv3 = StdConv2d(mid, out_ch, 1)
 
-    def forward(self, x):
-        pre = self.norm1(x)
+    def forward_pair(self, x, res=None):
+        """Block input is ``x + res`` (``res`` = the previous block's un-added branch, or None);
+        returns this block's ``(branch, shortcut)`` un-added, so the add can fuse into the next norm."""
+        x, pre = self.norm1.add_forward(x, res)
         shortcut = self.downsample(pre) if self.downsample is not None else x
         out = self.conv1(pre)
         out = self.conv2(self.norm2(out))
         out = self.conv3(self.norm3(out))
+        return out, shortcut
+
+    def forward(self, x):
+        out, shortcut = self.forward_pair(x)
         return out + shortcut
 
 
@@ -115,14 +137,30 @@ class _Stage(nn.Module):
 
 
 class _Stem(nn.Module):
-    """'fixed' BiT stem: StdConv 7x7/2 -> zero pad 1 -> maxpool 3x3/2 (no padding)."""
+    """'fixed' BiT stem: StdConv 7x7/2 -> zero pad 1 -> maxpool 3x3/2 (no padding).
+
+    On the GPU the pad + pool pair is one HIP kernel per direction (``dp_pad_maxpool_fwd`` /
+    ``_bwd``) and the convolution's input gradient (frozen, folded filter) is ``dp_stem_dgrad``;
+    ``GroupNormAct.fused = False`` also disables both (eager A/B)."""
 
     def __init__(self, in_ch=3, out_ch=64):
         super().__init__()
         self.conv = StdConv2d(in_ch, out_ch, 7, stride=2, padding=3)
 
+    def _conv(self, x):
+        conv = self.conv
+        if GroupNormAct.fused and x.is_cuda and x.requires_grad and conv.folded and not conv.weight.requires_grad:
+            from . import ops
+            if ops.stem_dgrad_supported(x, conv.weight, conv.stride, conv.padding):
+                return ops.StemConvFunction.apply(x, conv.weight)    # input gradient via dp_stem_dgrad
+        return conv(x)
+
     def forward(self, x):
-        x = self.conv(x)
+        x = self._conv(x)
+        if GroupNormAct.fused and x.is_cuda:
+            from . import ops
+            if ops.pad_maxpool_supported(x):
+                return ops.PadMaxPoolFunction.apply(x)
         x = F.pad(x, (1, 1, 1, 1), value=0.0)
         return F.max_pool2d(x, kernel_size=3, stride=2, padding=0)
 
@@ -152,7 +190,12 @@ class ResNetV2(nn.Module):
         self.num_classes = num_classes
 
     def forward(self, x):
-        return self.head(self.norm(self.stages(self.stem(x))))
+        x, res = self.stem(x), None
+        for stage in self.stages:
+            for block in stage.blocks:
+                x, res = block.forward_pair(x, res)     # residual adds ride along into the next norm
+        _, y = self.norm.add_forward(x, res)
+        return self.head(y)
 
     def reset_classifier(self, num_classes):
         """timm API used by the reference (utils.py:58)."""

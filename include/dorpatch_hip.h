@@ -27,10 +27,11 @@
 extern "C" {
 #endif
 
-#define DP_ABI_VERSION 1
+#define DP_ABI_VERSION 2
 #define DP_MAX_RECTS 4 /* occlusion windows per mask-table entry */
 
 typedef void *dp_stream_t; /* hipStream_t */
+typedef void *dp_event_t;  /* hipEvent_t  */
 
 /* Per-channel input normalisation fused into the occlusion kernels
  * (reference utils.py:66-78 NormModel: (x - mean) / std, mean = std = 0.5).
@@ -181,19 +182,61 @@ int dp_project_update(const dp_update_cfg_t *cfg, const float *x,
 int dp_argmax(const float *logits, int N, int C, int32_t *pred,
               dp_stream_t stream);
 
-/* ---- a-8  GroupNorm + ReLU of the frozen backbone, fused (HBM-bound part of the backbone) ----
- * timm 0.6.7 GroupNormAct as used by resnetv2_50x1_bit_distilled (reference utils.py:51-63;
- * executed at attack.py:222 forward / :247 backward): y = relu(group_norm(x, G, gamma, beta, eps)).
- * x, y, dy, dx (N,C,HW) fp32 NCHW; gamma, beta (C); mean, rstd (N*G) saved for the backward.
- * Requires (C/G)*HW % 4 == 0.  The backward returns only d loss / d x (frozen weights):
- *   dx = rstd * (dxh - mean_L(dxh) - xh * mean_L(dxh * xh)),  dxh = dy * [y > 0] * gamma.
- * Algorithmic HBM traffic per element: forward 4 B read + 4 B write, backward 8 B read + 4 B write
- * (groups up to 7168 float4 stay in registers; larger groups are re-read: +8 B per direction). */
-int dp_gn_relu_fwd(const float *x, const float *gamma, const float *beta, int N, int C, int HW,
-                   int G, float eps, float *y, float *mean, float *rstd, dp_stream_t stream);
-int dp_gn_relu_bwd(const float *dy, const float *x, const float *gamma, const float *beta,
-                   const float *mean, const float *rstd, int N, int C, int HW, int G, float *dx,
-                   dp_stream_t stream);
+/* ---- a-8  [residual add +] GroupNorm + ReLU of the frozen backbone, fused (the HBM-bound part) ----
+ * timm 0.6.7 GroupNormAct / PreActBottleneck as used by resnetv2_50x1_bit_distilled (reference
+ * utils.py:51-63; executed at attack.py:222 forward / :247 backward):
+ *     s = x + res   (res == NULL: s = x)          -- the bottleneck's "out + shortcut"
+ *     y = relu(group_norm(s, G, gamma, beta, eps))  -- the next block's norm1 (or the final norm)
+ * x, res, sum_out, y, dy, dres, dx (N,C,HW) fp32 NCHW; gamma, beta (C); mean, rstd (N*G) saved for
+ * the backward.  Requires (C/G)*HW % 4 == 0.  sum_out receives s when res is given.
+ * Backward (frozen weights: only the input gradient; `x` is s, the tensor that was normalised):
+ *     dx = dres + rstd * (dxh - mean_L(dxh) - xh * mean_L(dxh * xh)),  dxh = dy * [y > 0] * gamma
+ * where dres (may be NULL) is the gradient reaching s through the shortcut — d loss/d x and
+ * d loss/d res are both dx.
+ * Algorithmic HBM traffic per element: forward 4 B read + 4 B write (+ 4 + 4 with res), backward
+ * 8 B read + 4 B write (+ 4 with dres); groups up to 7168 float4 stay in registers, larger groups
+ * are re-read (+8 B per direction). */
+int dp_gn_relu_fwd(const float *x, const float *res, float *sum_out, const float *gamma,
+                   const float *beta, int N, int C, int HW, int G, float eps, float *y, float *mean,
+                   float *rstd, dp_stream_t stream);
+int dp_gn_relu_bwd(const float *dy, const float *dres, const float *x, const float *gamma,
+                   const float *beta, const float *mean, const float *rstd, int N, int C, int HW,
+                   int G, float *dx, dp_stream_t stream);
+
+/* ---- a-8  ConstantPad2d(1, 0) + MaxPool2d(3, stride 2) of the BiT stem, fused ----
+ * (timm 0.6.7 create_resnetv2_stem 'fixed'; reference utils.py:51-63, attack.py:222, 247.)
+ * x (NC,Hin,Win) -> y (NC,Hin/2,Win/2); code (NC,Hin/2,Win/2) uint8 = 3*r + c of the winning
+ * window position (row-major first max, NaN wins; a padded zero can win, its gradient is dropped).
+ * Backward is a gather: dx[h,w] = sum over the <= 4 windows containing (h,w) whose code points at it.
+ * Requires Hin even, Win % 8 == 0.  Traffic per input element: forward 4 B read + 1.25 B write,
+ * backward 1.25 B read + 4 B write. */
+int dp_pad_maxpool_fwd(const float *x, int64_t NC, int Hin, int Win, float *y, uint8_t *code,
+                       dp_stream_t stream);
+int dp_pad_maxpool_bwd(const float *dy, const uint8_t *code, int64_t NC, int Hin, int Win, float *dx,
+                       dp_stream_t stream);
+
+/* ---- a-8  input gradient of the BiT stem convolution (7x7, stride 2, pad 3, 3 input channels) ----
+ * (timm 0.6.7 resnetv2 stem.conv; the last convolution of the backward pass, reference
+ * attack.py:247 — its result is what dp_apply_bwd reduces over the EOT samples.)
+ * dy (N,K,Ho,Wo) = d loss / d conv-out, w (K,3,7,7) the (standardised) filter,
+ * dx (N,3,2*Ho,2*Wo) = d loss / d conv-in:
+ *   dx[n,c,h,w] = sum_k sum_{i,j} dy[n,k,(h+3-i)/2,(w+3-j)/2] * w[k,c,i,j]   (even differences only)
+ * Direct fp32 gather on the VALU (2*K*147 flop per 2x2 output quad); compute-bound. */
+int dp_stem_dgrad(const float *dy, const float *w, int N, int K, int Ho, int Wo, float *dx,
+                  dp_stream_t stream);
+
+/* ---- measurement support (bench.py "roofline"): kernel-precise duration of dp_apply_fwd ----
+ * dp_apply_fwd_timed is dp_apply_fwd launched through hipExtLaunchKernelGGL, which stamps `start` /
+ * `stop` with the kernel's own begin / end on its stream (the duration rocprofv3 --kernel-trace
+ * reports), instead of the completion time of marker packets around it.  dp_event_elapsed_ms
+ * blocks until `stop` has happened. */
+int dp_event_create(dp_event_t *ev);
+int dp_event_destroy(dp_event_t ev);
+int dp_event_elapsed_ms(dp_event_t start, dp_event_t stop, float *ms);
+int dp_apply_fwd_timed(const float *adv_x, const int32_t *table, int R, const int32_t *idx,
+                       const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
+                       const dp_norm_t *norm, float *out, dp_stream_t stream, dp_event_t start,
+                       dp_event_t stop);
 
 #ifdef __cplusplus
 }

@@ -325,3 +325,87 @@ def test_resnetv2_fused_equals_unfused():
     # fp32 noise floor of this random-weight net is ~1e-2 rel-L2: ReLU gates flip
     assert np.linalg.norm(a - b) / np.linalg.norm(b) < 5e-2
     assert (a * b).sum() / np.linalg.norm(a) / np.linalg.norm(b) > 0.998
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 56, 56), (3, 512, 28, 28), (2, 2048, 7, 7), (1, 256, 96, 96)])
+def test_add_gn_relu_fusion(shape):
+    """Residual add fused into GroupNorm+ReLU: (x, res) -> (x + res, relu(gn(x + res))) and the backward
+    with the shortcut gradient folded in, against the unfused kernels (bit-exact: same arithmetic)
+    and through autograd against the eager torch composition."""
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(H)
+    x, r = torch.randn(N, C, H, W, generator=g).to(DEV), torch.randn(N, C, H, W, generator=g).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.2).to(DEV)
+    dy, ds = torch.randn(N, C, H, W, generator=g).to(DEV), torch.randn(N, C, H, W, generator=g).to(DEV)
+    y, mean, rstd, s = ops.gn_relu_fwd(x, gamma, beta, 32, 1e-5, res=r)
+    assert torch.equal(s, x + r)
+    y0, mean0, rstd0, s0 = ops.gn_relu_fwd(s, gamma, beta, 32, 1e-5)
+    assert s0 is s and torch.equal(y, y0) and torch.equal(mean, mean0) and torch.equal(rstd, rstd0)
+    dx = ops.gn_relu_bwd(dy, s, gamma, beta, mean, rstd, 32, dres=ds)
+    dx0 = ops.gn_relu_bwd(dy, s, gamma, beta, mean, rstd, 32)
+    assert torch.equal(dx, dx0 + ds)
+    # autograd: both outputs used, only y used, only s used
+    xa, ra = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    sa, ya = ops.AddGnReluFunction.apply(xa, ra, gamma, beta, 32, 1e-5)
+    gx, gr = torch.autograd.grad([sa, ya], [xa, ra], [ds, dy])
+    assert torch.equal(gx, dx) and torch.equal(gr, dx)
+    sa, ya = ops.AddGnReluFunction.apply(xa, ra, gamma, beta, 32, 1e-5)
+    (gx,) = torch.autograd.grad(ya, xa, dy)
+    assert torch.equal(gx, dx0)
+    sa, ya = ops.AddGnReluFunction.apply(xa, ra, gamma, beta, 32, 1e-5)
+    (gx,) = torch.autograd.grad(sa, xa, ds)
+    assert torch.equal(gx, ds)
+    # eager torch on the GPU
+    xe, re_ = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    se = xe + re_
+    ye = torch.relu(torch.nn.functional.group_norm(se, 32, gamma, beta, 1e-5))
+    ge, _ = torch.autograd.grad([se, ye], [xe, re_], [ds, dy])
+    np.testing.assert_allclose(y.cpu().numpy(), ye.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+    bad = (ge - dx).abs() > 2e-4 * ge.abs() + 2e-5
+    assert float(bad.float().mean()) < 1e-2
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 112, 112), (2, 5, 8, 16), (1, 64, 192, 192)])
+def test_pad_maxpool_matches_torch(shape):
+    """Fused ConstantPad2d(1,0)+MaxPool2d(3,2) (BiT stem) vs eager torch: forward exact, backward exact
+    (pure routing), including all-negative border windows where the padded zero wins and ties."""
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(N, C, H, W, generator=g)
+    x[0, 0, :3, :] = -1.0 - torch.rand(3, W, generator=g)        # top windows: pad zero is the max
+    x[0, 0, :, :3] = -1.0 - torch.rand(H, 3, generator=g)        # left windows likewise
+    x[0, 1 % C, 4:8, 4:8] = 0.5                                   # ties inside windows
+    x = x.to(DEV)
+    dy = torch.randn(N, C, H // 2, W // 2, generator=g).to(DEV)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.max_pool2d(torch.nn.functional.pad(xr, (1, 1, 1, 1), value=0.0), 3, 2, 0)
+    (gr,) = torch.autograd.grad(yr, xr, dy)
+    y, code = ops.pad_maxpool_fwd(x)
+    assert torch.equal(y, yr.detach())
+    assert int(code.max()) <= 8
+    gx = ops.pad_maxpool_bwd(dy, code, H, W)
+    # an input pixel can win up to 4 windows: torch's scatter adds them in atomic order, the gather here
+    # in a fixed order -> equal up to the rounding of a 3- or 4-term fp32 sum
+    np.testing.assert_allclose(gx.cpu().numpy(), gr.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    assert torch.equal(gx == 0, gr == 0)                            # identical routing
+    xa = x.clone().requires_grad_(True)
+    (ga,) = torch.autograd.grad(ops.PadMaxPoolFunction.apply(xa), xa, dy)
+    assert torch.equal(ga, gx)
+
+
+@pytest.mark.parametrize("N,K,H", [(3, 64, 224), (2, 8, 40), (1, 64, 384), (2, 5, 34)])
+def test_stem_dgrad_matches_torch(N, K, H):
+    """dp_stem_dgrad vs torch's conv2d input gradient (float64 on the CPU): direct fp32 gather with
+    one rounding per MAC — tolerance 2e-5 of the gradient scale (K*49-term dot products)."""
+    g = torch.Generator().manual_seed(K + H)
+    w = torch.randn(K, 3, 7, 7, generator=g) * 0.1
+    dy = torch.randn(N, K, H // 2, H // 2, generator=g)
+    x = torch.zeros(N, 3, H, H, dtype=torch.float64, requires_grad=True)
+    (want,) = torch.autograd.grad(torch.nn.functional.conv2d(x, w.double(), None, 2, 3), x, dy.double())
+    got = ops.stem_dgrad(dy.to(DEV), w.to(DEV)).cpu().double()
+    scale = float(want.abs().max())
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=2e-5 * scale)
+    # through autograd, frozen weight
+    xa = torch.rand(N, 3, H, H, generator=g).to(DEV).requires_grad_(True)
+    (ga,) = torch.autograd.grad(ops.StemConvFunction.apply(xa, w.to(DEV)), xa, dy.to(DEV))
+    assert torch.equal(ga.cpu().double(), got)

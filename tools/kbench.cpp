@@ -226,6 +226,64 @@ int main(int argc, char **argv) {
                                  pattern, mask, best_p, best_m, nullptr, nullptr, st));
           });
   }
+  // ---- a-8: backbone element-wise kernels at the training micro-batch (256 samples)
+  if (H == 224) {
+    const int Nb = 256;
+    struct Shape { int C, HW; const char *what; };
+    const Shape shapes[] = {{64, 3136, "64ch@56x56"}, {256, 3136, "256ch@56x56"}, {512, 784, "512ch@28x28"},
+                            {1024, 196, "1024ch@14x14"}, {2048, 49, "2048ch@7x7"}};
+    const size_t maxe = (size_t)Nb * 256 * 3136;
+    float *gx = (float *)dmalloc(maxe * 4), *gy = (float *)dmalloc(maxe * 4), *gr = (float *)dmalloc(maxe * 4);
+    float *gs = (float *)dmalloc(maxe * 4);
+    float *gam = (float *)dmalloc(2048 * 4), *bet = (float *)dmalloc(2048 * 4);
+    float *gmean = (float *)dmalloc(Nb * 32 * 4), *grstd = (float *)dmalloc(Nb * 32 * 4);
+    hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, st, (f4 *)gx, maxe / 4, 0.37f);
+    hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, st, (f4 *)gr, maxe / 4, -0.11f);
+    hipLaunchKernelGGL(k_fill, dim3(8), dim3(256), 0, st, (f4 *)gam, 512, 1.f);
+    hipLaunchKernelGGL(k_fill, dim3(8), dim3(256), 0, st, (f4 *)bet, 512, 0.05f);
+    for (const Shape &sh : shapes) {
+      const double e = (double)Nb * sh.C * sh.HW;
+      char name[96];
+      snprintf(name, sizeof name, "dp_gn_relu_fwd %s", sh.what);
+      bench(name, e * 8, iters, st,
+            [&] { DP(dp_gn_relu_fwd(gx, nullptr, nullptr, gam, bet, Nb, sh.C, sh.HW, 32, 1e-5f, gy, gmean, grstd, st)); });
+      snprintf(name, sizeof name, "dp_gn_relu_fwd +res %s", sh.what);
+      bench(name, e * 16, iters, st,
+            [&] { DP(dp_gn_relu_fwd(gx, gr, gs, gam, bet, Nb, sh.C, sh.HW, 32, 1e-5f, gy, gmean, grstd, st)); });
+      snprintf(name, sizeof name, "dp_gn_relu_bwd %s", sh.what);
+      bench(name, e * 12, iters, st,
+            [&] { DP(dp_gn_relu_bwd(gy, nullptr, gx, gam, bet, gmean, grstd, Nb, sh.C, sh.HW, 32, gs, st)); });
+      snprintf(name, sizeof name, "dp_gn_relu_bwd +dres %s", sh.what);
+      bench(name, e * 16, iters, st,
+            [&] { DP(dp_gn_relu_bwd(gy, gr, gx, gam, bet, gmean, grstd, Nb, sh.C, sh.HW, 32, gs, st)); });
+    }
+    // stem: pad + maxpool on (256, 64, 112, 112) and the 7x7/2 input gradient
+    const int64_t NC = (int64_t)Nb * 64;
+    uint8_t *code = (uint8_t *)dmalloc((size_t)NC * 56 * 56);
+    const double pe = (double)NC * 112 * 112;
+    bench("dp_pad_maxpool_fwd 256x64x112x112", pe * 5.25, iters, st,
+          [&] { DP(dp_pad_maxpool_fwd(gx, NC, 112, 112, gy, code, st)); });
+    bench("dp_pad_maxpool_bwd 256x64x112x112", pe * 5.25, iters, st,
+          [&] { DP(dp_pad_maxpool_bwd(gy, code, NC, 112, 112, gs, st)); });
+    float *wst = (float *)dmalloc(64 * 147 * 4);
+    hipLaunchKernelGGL(k_fill, dim3(8), dim3(256), 0, st, (f4 *)wst, 64 * 147 / 4, 0.01f);
+    {
+      const double flop = 2.0 * 64 * 147 * 112 * 112 * Nb;  // 60.4 GFLOP
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0));
+      CK(hipEventCreate(&e1));
+      for (int i = 0; i < 2; ++i) DP(dp_stem_dgrad(gx, wst, Nb, 64, 112, 112, gy, st));
+      CK(hipEventRecord(e0, st));
+      for (int i = 0; i < iters; ++i) DP(dp_stem_dgrad(gx, wst, Nb, 64, 112, 112, gy, st));
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= iters;
+      printf("%-34s %9.4f ms  %12.3e flop  %8.2f TFLOP/s  %5.1f%% of 157.3 TF fp32\n", "dp_stem_dgrad 256x64x112x112", ms,
+             flop, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 1.573);
+    }
+  }
   CK(hipStreamSynchronize(st));
   return 0;
 }
