@@ -64,7 +64,7 @@ class GroupNormAct(nn.GroupNorm):
         super().__init__(num_groups, num_channels, eps=eps, affine=True)
 
     def _use_hip(self, x):
-        if GroupNormAct.fused and x.is_cuda and not (self.weight.requires_grad or self.bias.requires_grad):
+        if GroupNormAct.fused and not (self.weight.requires_grad or self.bias.requires_grad):
             from . import ops
             return ops.gn_relu_supported(x, self.num_groups)
         return False
@@ -149,7 +149,7 @@ class _Stem(nn.Module):
 
     def _conv(self, x):
         conv = self.conv
-        if GroupNormAct.fused and x.is_cuda and x.requires_grad and conv.folded and not conv.weight.requires_grad:
+        if GroupNormAct.fused and x.requires_grad and conv.folded and not conv.weight.requires_grad:
             from . import ops
             if ops.stem_dgrad_supported(x, conv.weight, conv.stride, conv.padding):
                 return ops.StemConvFunction.apply(x, conv.weight)    # input gradient via dp_stem_dgrad
@@ -157,9 +157,9 @@ class _Stem(nn.Module):
 
     def forward(self, x):
         x = self._conv(x)
-        if GroupNormAct.fused and x.is_cuda:
+        if GroupNormAct.fused:
             from . import ops
-            if ops.pad_maxpool_supported(x):
+            if ops.pad_maxpool_supported(x):      # GPU fp32 NCHW only (checks x.is_cuda)
                 return ops.PadMaxPoolFunction.apply(x)
         x = F.pad(x, (1, 1, 1, 1), value=0.0)
         return F.max_pool2d(x, kernel_size=3, stride=2, padding=0)

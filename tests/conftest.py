@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# tests/hipemu (host emulation of the HIP execution model, test infrastructure) as an importable package
+import importlib.util as _ilu  # noqa: E402
+if "tests_hipemu" not in sys.modules:
+    _spec = _ilu.spec_from_file_location("tests_hipemu", os.path.join(ROOT, "tests", "hipemu", "__init__.py"),
+                                         submodule_search_locations=[os.path.join(ROOT, "tests", "hipemu")])
+    _m = _ilu.module_from_spec(_spec)
+    sys.modules["tests_hipemu"] = _m
+    _spec.loader.exec_module(_m)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")

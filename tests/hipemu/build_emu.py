@@ -1,0 +1,59 @@
+"""Build tests/hipemu/libdorpatch_emu.so: the product's HIP translation unit compiled UNCHANGED as host
+C++ against the hipemu shim (tests/hipemu/hip/hip_runtime.h).  TEST INFRASTRUCTURE ONLY — lets
+`pytest -m "not gpu"` check every kernel's indexing / LDS / shuffle logic against the CPU oracle in the
+GPU-less build container.  The product never loads this library (dorpatch_amd/_lib.py opens only
+libdorpatch_hip.so, and dorpatch_amd.ops rejects CPU tensors).
+
+The only source transformation: `extern __shared__ <type> name[];` (dynamic LDS, which has no host
+equivalent) becomes a pointer to the emulator's per-launch dynamic-LDS buffer.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+SRC = os.path.join(ROOT, "dorpatch_amd", "csrc", "dorpatch_hip.hip")
+OUT = os.path.join(HERE, "libdorpatch_emu.so")
+GEN = os.path.join(HERE, "_dorpatch_emu_gen.cpp")
+DEPS = [SRC, os.path.join(ROOT, "include", "dorpatch_hip.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
+        os.path.abspath(__file__)]
+
+_DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(\w+)\s+(\w+)\[\];")
+
+
+def host_compiler():
+    for exe in ("/opt/rocm/lib/llvm/bin/clang++", shutil.which("clang++")):
+        if exe and os.path.exists(exe):
+            return exe
+    return None
+
+
+def build(force=False):
+    """-> path of the emulation library, or None when no host clang++ exists (tests then skip)."""
+    cxx = host_compiler()
+    if cxx is None:
+        return None
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in DEPS):
+        return OUT
+    with open(SRC) as f:
+        text = f.read()
+    text = _DYN.sub(lambda m: "%s *%s = static_cast<%s *>(hipemu::dyn_lds_ptr());" % (m.group(1), m.group(2), m.group(1)),
+                    text)
+    with open(GEN, "w") as f:
+        f.write('#line 1 "%s"\n' % SRC)
+        f.write(text)
+    # same FP contract as the product build (dorpatch_amd/build.py): no fused multiply-add, no fast-math
+    cmd = [cxx, "-x", "c++", "-std=c++17", "-O1", "-g0", "-ffp-contract=off", "-fPIC", "-shared", "-w",
+           "-I", HERE, "-I", os.path.join(ROOT, "include"), GEN, "-o", OUT + ".tmp"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipemu build failed:\n" + res.stdout + res.stderr)
+    os.replace(OUT + ".tmp", OUT)
+    os.remove(GEN)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -1,0 +1,79 @@
+"""Route dorpatch_amd.ops through the host emulation library for the duration of a test.
+
+TEST INFRASTRUCTURE ONLY.  The product path (dorpatch_amd.ops) refuses CPU tensors and only ever
+loads libdorpatch_hip.so; this context manager swaps in tests/hipemu/libdorpatch_emu.so — the same
+translation unit compiled as host C++ — and relaxes the "must be a GPU tensor" guards, so that the
+Python host wrappers + the kernels' logic can be exercised on CPU tensors in the GPU-less container.
+"""
+import contextlib
+import ctypes
+
+import numpy as np
+import torch
+
+from dorpatch_amd import _lib, ops
+from . import build_emu
+
+_handle = None
+
+
+def emu_lib():
+    """ctypes handle of the emulation library with the product's prototypes, or None (no host clang++)."""
+    global _handle
+    if _handle is None:
+        path = build_emu.build()
+        if path is None:
+            return None
+        lib = ctypes.CDLL(path)
+        for name, (restype, argtypes) in _lib.PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = restype, argtypes
+        assert lib.dp_abi_version() == _lib.DP_ABI_VERSION
+        _handle = lib
+    return _handle
+
+
+def _chk_cpu(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or t.is_cuda:
+        raise RuntimeError("hipemu: `%s` must be a CPU tensor" % name)
+    if t.dtype != dtype:
+        raise TypeError(f"`{name}` must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"`{name}` must be contiguous")
+    return t
+
+
+def _gn_supported(x, groups):
+    if not (isinstance(x, torch.Tensor) and x.dtype == torch.float32 and x.dim() >= 2) or x.shape[1] % groups:
+        return False
+    L = (x.shape[1] // groups) * int(np.prod(x.shape[2:]))
+    return L % 4 == 0 and L < (1 << 20)
+
+
+def _pool_supported(x):
+    return (isinstance(x, torch.Tensor) and x.dtype == torch.float32 and x.dim() == 4
+            and x.shape[2] % 2 == 0 and x.shape[3] % 8 == 0)
+
+
+def _stem_supported(x, weight, stride, padding):
+    return (isinstance(x, torch.Tensor) and x.dtype == torch.float32 and x.dim() == 4
+            and tuple(weight.shape[1:]) == (3, 7, 7) and tuple(stride) == (2, 2) and tuple(padding) == (3, 3)
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
+
+
+@contextlib.contextmanager
+def emulated_ops():
+    lib = emu_lib()
+    assert lib is not None, "no host clang++: cannot build the emulation library"
+    saved = dict(lib=_lib._lib, chk=ops._chk, stream=ops._stream, gn=ops.gn_relu_supported,
+                 pool=ops.pad_maxpool_supported, stem=ops.stem_dgrad_supported)
+    _lib._lib = lib
+    ops._chk = _chk_cpu
+    ops._stream = lambda: None
+    ops.gn_relu_supported, ops.pad_maxpool_supported, ops.stem_dgrad_supported = _gn_supported, _pool_supported, _stem_supported
+    try:
+        yield lib
+    finally:
+        _lib._lib = saved["lib"]
+        ops._chk, ops._stream = saved["chk"], saved["stream"]
+        ops.gn_relu_supported, ops.pad_maxpool_supported, ops.stem_dgrad_supported = saved["gn"], saved["pool"], saved["stem"]

@@ -249,7 +249,7 @@ def test_gn_relu_matches_torch(shape):
     gamma = torch.rand(C, generator=g) + 0.5
     beta = torch.randn(C, generator=g) * 0.2
     dy = torch.randn(N, C, H, W, generator=g)
-    y, mean, rstd = ops.gn_relu_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV), G, 1e-5)
+    y, mean, rstd, _ = ops.gn_relu_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV), G, 1e-5)
     dx = ops.gn_relu_bwd(dy.to(DEV), x.to(DEV), gamma.to(DEV), beta.to(DEV), mean, rstd, G)
     y, dx = y.cpu(), dx.cpu()
     xd = x.double()
