@@ -299,9 +299,7 @@ class HotLoop(object):
     def __init__(self, owner, model, x, patch_budget, n_classes, save_dir, batch_id, y, targeted, lr,
                  confidence, clip_min, clip_max, max_iterations, basic_unit, selection, dropout,
                  sampling_size, density, structured, eps, dual, extras):
-        if not (isinstance(x, torch.Tensor) and x.is_cuda):
-            raise RuntimeError("DorPatch.generate needs `x` on a ROCm GPU: the HIP kernels are the only "
-                               "implementation of the hot path (no CPU fallback)")
+        ops.require_gpu(x, "DorPatch.generate (`x`)")
         if dropout not in (1, 2):
             raise ValueError("dropout must be 1 or 2 (reference attack.py:25-31 builds no mask set otherwise)")
         self.o = owner
@@ -335,8 +333,8 @@ class HotLoop(object):
         init_pattern = extras.get("init_pattern")
         adv_mask = torch.rand([B, 1, H, W]) if init_mask is None else init_mask.detach().cpu().float()
         adv_pattern = torch.rand((B, 3, H, W)) if init_pattern is None else init_pattern.detach().cpu().float()
-        self.adv_mask = adv_mask.to(dev).contiguous()
-        self.adv_pattern = adv_pattern.to(dev).contiguous()
+        self.adv_mask = adv_mask.to(dev, copy=True).contiguous()        # never alias the caller's init tensors
+        self.adv_pattern = adv_pattern.to(dev, copy=True).contiguous()
         dp_dist.broadcast_(self.adv_mask, owner.pg)
         dp_dist.broadcast_(self.adv_pattern, owner.pg)
         self.best_mask = torch.zeros_like(self.adv_mask)               # attack.py:63-64

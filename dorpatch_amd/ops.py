@@ -29,6 +29,15 @@ def _chk(t, dtype, name):
     return t
 
 
+def require_gpu(t, what):
+    """The product path exists only on the GPU: callers that take user tensors (DorPatch.generate,
+    PatchCleanser) reject anything else up front, loudly."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise RuntimeError("%s needs tensors on a ROCm GPU: the HIP kernels are the only implementation of "
+                           "the hot path (no CPU fallback)" % what)
+    return t
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 

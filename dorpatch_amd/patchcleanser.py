@@ -142,9 +142,7 @@ class PatchCleanser(object):
         return torch.cat(outs, dim=1)
 
     def _prep(self, img):
-        if not (isinstance(img, torch.Tensor) and img.is_cuda):
-            raise RuntimeError("PatchCleanser needs GPU tensors: the HIP occlusion kernel is the only "
-                               "implementation (no CPU fallback)")
+        ops.require_gpu(img, "PatchCleanser")
         if img.dim() == 3:
             img = img[None]
         return img.detach().contiguous().float()

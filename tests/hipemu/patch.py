@@ -65,15 +65,16 @@ def _stem_supported(x, weight, stride, padding):
 def emulated_ops():
     lib = emu_lib()
     assert lib is not None, "no host clang++: cannot build the emulation library"
-    saved = dict(lib=_lib._lib, chk=ops._chk, stream=ops._stream, gn=ops.gn_relu_supported,
+    saved = dict(lib=_lib._lib, req=ops.require_gpu, chk=ops._chk, stream=ops._stream, gn=ops.gn_relu_supported,
                  pool=ops.pad_maxpool_supported, stem=ops.stem_dgrad_supported)
     _lib._lib = lib
     ops._chk = _chk_cpu
+    ops.require_gpu = lambda t, what: t
     ops._stream = lambda: None
     ops.gn_relu_supported, ops.pad_maxpool_supported, ops.stem_dgrad_supported = _gn_supported, _pool_supported, _stem_supported
     try:
         yield lib
     finally:
         _lib._lib = saved["lib"]
-        ops._chk, ops._stream = saved["chk"], saved["stream"]
+        ops._chk, ops._stream, ops.require_gpu = saved["chk"], saved["stream"], saved["req"]
         ops.gn_relu_supported, ops.pad_maxpool_supported, ops.stem_dgrad_supported = saved["gn"], saved["pool"], saved["stem"]

@@ -32,8 +32,8 @@ class FixedDraw(object):
         return np.asarray(self.rows.pop(0)).copy()
 
 
-def _toy(gain=1.0, dev=DEV):
-    return toy_models.NormModel(toy_models.make_toy(gain=gain), toy_models.Normalize()).to(dev)
+def _toy(gain=1.0, dev=None):
+    return toy_models.NormModel(toy_models.make_toy(gain=gain), toy_models.Normalize()).to(dev or DEV)
 
 
 def _loop(model, x, y, S, extras, *, budget=0.12, targeted=True, lr=1e-2, eps=4.0, tmp="t/cfg/sub", mb=256,
@@ -126,7 +126,7 @@ def test_generate_trajectory_tracks_reference(golden_trace, tmp_path, monkeypatc
     for k in range(5):
         np.testing.assert_allclose(seen[k][3], t["loss_adv"][k], rtol=5e-3, atol=5e-4)
     m = mask.cpu().numpy()
-    assert mask.shape == (1, 1, H, H) and pattern.shape == (1, 3, H, H) and mask.is_cuda
+    assert mask.shape == (1, 1, H, H) and pattern.shape == (1, 3, H, H) and mask.device == x.device
     assert set(np.unique(m)) <= {0.0, 1.0}
     cells = m.reshape(1, 1, H // 7, 7, H // 7, 7)
     assert (cells.min(axis=(3, 5)) == cells.max(axis=(3, 5))).all()
@@ -142,6 +142,42 @@ def test_generate_trajectory_tracks_reference(golden_trace, tmp_path, monkeypatc
     fails_ref = R.collect_failure(_toy(float(t["gain"]), "cpu"), adv_ref, torch.from_numpy(t["y0"]),
                                   R.mask_universe(H, 2), True)
     assert abs(len(fails) - len(fails_ref)) <= 0.1 * 2520, (len(fails), len(fails_ref))
+
+
+def test_generate_short_run_both_stages(tmp_path, monkeypatch):
+    """A 12-iterations-per-stage DorPatch.generate (seconds, also under the CPU emulation): stage 0 consumes
+    the global RNG streams exactly like the recorded reference run (identical mask draws and first-step
+    losses), stage 1 starts from the top-k selected cells, the outputs honour the reference contract."""
+    from conftest import load_golden
+    t = load_golden("trace_56.npz")
+    H, S, n_it = int(t["H"]), int(t["S"]), 12
+    monkeypatch.chdir(tmp_path)
+    model = _toy(float(t["gain"]))
+    x = torch.from_numpy(t["x"]).to(DEV)
+    y = torch.from_numpy(t["y0"]).to(DEV)
+    seen = []
+    torch.manual_seed(1234)
+    np.random.seed(1234)
+    atk = DorPatch(verbose=False)
+    mask, pattern = atk.generate(model, x, 0.12, 10, "res/cfg/sub", 0, y=y, targeted=True, lr=float(t["lr0"]),
+                                 sampling_size=S, eps=float(t["eps"]), max_iterations=n_it,
+                                 step_hook=lambda d: seen.append((d["stage"], d["i"], d["idx"][0].copy(),
+                                                                  d["loss_adv"][0].copy(), d["mask"].cpu().clone())))
+    assert [(s, i) for s, i, _, _, _ in seen] == [(0, i) for i in range(n_it)] + [(1, i) for i in range(n_it)]
+    for k in range(n_it):
+        assert (int(t["stage"][k]), int(t["i"][k])) == (0, k)
+        assert np.array_equal(seen[k][2], t["idx"][k]), k
+    for k in range(3):
+        np.testing.assert_allclose(seen[k][3], t["loss_adv"][k], rtol=5e-3, atol=5e-4)
+    m = mask.cpu().numpy()
+    assert set(np.unique(m)) <= {0.0, 1.0} and m.sum() <= np.floor(H * H * 0.12 / 49) * 49
+    # stage 1 optimises the pattern only: its mask is the stage-0 selection, unchanged through the stage
+    assert all(torch.equal(seen[n_it][4], seen[k][4]) for k in range(n_it, 2 * n_it))
+    assert np.array_equal(seen[n_it][4].numpy(), m)
+    assert os.path.exists("res/cfg/adv_mask_0.pt") and os.path.exists("res/cfg/adv_pattern_0.pt")
+    cached = torch.load("res/cfg/adv_mask_0.pt", map_location="cpu")
+    assert torch.equal(R.patch_selection(cached, 0.12), mask.cpu())
+    assert atk.criterion is not None and atk.criterion.targeted
 
 
 def test_stage0_cache_is_reused(tmp_path, monkeypatch):
