@@ -349,6 +349,81 @@ def test_patchcleanser_matches_reference_records(golden_patchcleanser):
     assert cons.shape == (630,) and isinstance(cert, bool)
 
 
+# ---------------------------------------------------------------- the evaluation driver (reference main.py)
+def _driver_args(*extra):
+    from dorpatch_amd.driver import build_parser
+    return build_parser().parse_args(["--patch_budget", "0.12", "--num_images", "2", "--max_iterations", "4",
+                                      "--sampling_size", "4", "--img_size", "56", "--quiet", *extra])
+
+
+def _driver_batches(model, sizes, seed=100):
+    out = []
+    for i, B in enumerate(sizes):
+        x = torch.rand(B, 3, 56, 56, generator=torch.Generator().manual_seed(seed + i))
+        with torch.no_grad():
+            out.append((x, model(x.to(DEV)).argmax(-1).cpu()))
+    return out
+
+
+def test_driver_untargeted_run_files_and_resume(tmp_path, monkeypatch):
+    """reference main.py:82-184: result files where and how the reference writes them, the PatchCleanser
+    pickles carry the reference's module path, a second run resumes from the files without attacking."""
+    import pickle
+    from dorpatch_amd import driver
+    monkeypatch.chdir(tmp_path)
+    model = _toy(2.0)
+    batches = _driver_batches(model, [2, 1, 1])
+    out = driver.run(_driver_args(), model=model, dataloader=batches, device=DEV, n_classes=10)
+    rd = out["result_dir"]
+    assert rd == os.path.join("results", "dataset=imagenet_base_arch=resnetv2_targeted=False_attack=DorPatch_"
+                              "dropout=2_density=0.001_structured=0.001", "num_patch=-1_patch_budget=0.12")
+    assert out["n_images"] == 3 and out["acc_clean"] == 100.0       # num_images=2 batches (2 + 1 images); third never touched
+    for i in range(2):
+        m = torch.load(os.path.join(rd, "adv_mask_%d.pt" % i), map_location="cpu")
+        p = torch.load(os.path.join(rd, "adv_pattern_%d.pt" % i), map_location="cpu")
+        B = batches[i][0].shape[0]
+        assert m.shape == (B, 1, 56, 56) and p.shape == (B, 3, 56, 56) and set(m.unique().tolist()) <= {0.0, 1.0}
+        assert os.path.exists(os.path.join(os.path.dirname(rd), "adv_mask_%d.pt" % i))        # stage-0 cache
+        raw = open(os.path.join(rd, "adv_PC_%d.pt" % i), "rb").read()
+        assert b"defenses.PatchCleanser" in raw and b"dorpatch_amd" not in raw
+        recs = pickle.loads(raw)
+        assert len(recs) == B and all(len(r) == 4 for r in recs)
+        assert recs[0][0].preds_1.shape == (36,) and recs[0][0].preds_2.shape == (630,)
+    assert not os.path.exists(os.path.join(rd, "adv_mask_2.pt"))
+    assert all(len(out[k]) == 4 for k in ("acc_PC", "certified_acc_PC", "certified_asr_PC"))
+
+    def boom(*a, **k):
+        raise AssertionError("resume must not attack again")
+    monkeypatch.setattr(DorPatch, "generate", boom)
+    monkeypatch.setattr(PatchCleanser, "robust_predict_batch", boom)
+    again = driver.run(_driver_args(), model=model, dataloader=batches, device=DEV, n_classes=10)
+    for k in ("acc_clean", "acc_robust", "acc_PC", "certified_acc_PC", "certified_asr_PC"):
+        assert again[k] == out[k], k
+
+
+def test_driver_targeted_run(tmp_path, monkeypatch):
+    """--targeted: a random target per image (main.py:120-124) goes to generate as `y`; the certified-ASR
+    column counts certified predictions of the TARGET (main.py:176-179)."""
+    from dorpatch_amd import driver
+    monkeypatch.chdir(tmp_path)
+    # a toy whose clean class (4) differs from the seeded first target draws: the reference asserts target != y
+    model = toy_models.NormModel(toy_models.make_toy(gain=2.0, seed=8), toy_models.Normalize()).to(DEV)
+    seen = {}
+    orig = DorPatch.generate
+
+    def spy(self, model_, x, *a, **k):
+        seen.setdefault("y", []).append(k["y"].cpu().clone())
+        assert k["targeted"] is True and k["num_patch"] == -1 and k["batch_id"] == len(seen["y"]) - 1
+        return orig(self, model_, x, *a, **k)
+    monkeypatch.setattr(DorPatch, "generate", spy)
+    batches = _driver_batches(model, [1, 1], seed=300)
+    out = driver.run(_driver_args("--targeted"), model=model, dataloader=batches, device=DEV, n_classes=10)
+    assert "targeted=True" in out["result_dir"] and len(seen["y"]) == 2
+    for (x, y), t in zip(batches, seen["y"]):
+        assert t.shape == y.shape and bool((t != y).all())
+    assert all(0.0 <= v <= 100.0 for v in out["certified_asr_PC"])
+
+
 # ---------------------------------------------------------------- full-size, size-independent properties
 def test_config2_size_properties():
     """BASELINE configs[1] geometry (64 images x 32 masks @224, 1.23 GB of masked images): the oracle

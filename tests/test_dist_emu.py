@@ -1,0 +1,170 @@
+"""The product's multi-rank hot loop itself — ``HotLoop.step`` with a process group, the sharded
+``collect_failure`` sweep and the image-sharded evaluation driver — on world_size-2 ``gloo``, with the
+HIP kernels running through the host emulation (tests/hipemu) on CPU tensors.
+
+tests/test_dist_gloo.py checks the sharding arithmetic with the oracle standing in for the kernels;
+here the code under test is exactly what runs per GPU under ``torch.distributed.run`` (rank-0 index
+broadcast, S-slice per rank, ONE all-reduce of the patch gradient, loss-column all-gather, failure
+bitmap MAX-reduce), compared with the same problem on a single rank.
+"""
+import importlib.util
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _emu_patch():
+    """tests/hipemu as the package `tests_hipemu` (conftest.py does this in the pytest process; spawned
+    ranks do it themselves)."""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    if "tests_hipemu" not in sys.modules:
+        spec = importlib.util.spec_from_file_location("tests_hipemu", os.path.join(HERE, "hipemu", "__init__.py"),
+                                                      submodule_search_locations=[os.path.join(HERE, "hipemu")])
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules["tests_hipemu"] = mod
+        spec.loader.exec_module(mod)
+    from tests_hipemu import patch
+    return patch
+
+
+if _emu_patch().build_emu.host_compiler() is None:
+    pytest.skip("no host clang++ for the HIP emulation build", allow_module_level=True)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class FixedDraw(object):
+    def __init__(self, rows):
+        self.rows = list(rows)
+
+    def choice(self, a, n, replace=False):
+        return np.asarray(self.rows.pop(0)).copy()
+
+
+H, S, B, N_STEPS = 56, 8, 2, 3
+
+
+def _problem():
+    from oracle import toy_models
+    g = torch.Generator().manual_seed(3)
+    x, m, p = torch.rand(B, 3, H, H, generator=g), torch.rand(B, 1, H, H, generator=g), torch.rand(B, 3, H, H, generator=g)
+    y = torch.tensor([2, 7])
+    rows = [[np.random.RandomState(10 * b + k).choice(2520, S, replace=False) for k in range(N_STEPS)] for b in range(B)]
+    net = toy_models.NormModel(toy_models.make_toy(gain=3.0), toy_models.Normalize())
+    return x, m, p, y, rows, net
+
+
+def _run_loop(pg, rank):
+    """N_STEPS steps of the product's HotLoop (step 0 includes the collect_failure sweep)."""
+    from dorpatch_amd.attack import DorPatch, HotLoop
+    x, m, p, y, rows, net = _problem()
+    if rank != 0:                     # only rank 0's init and draws may matter: poison the others
+        m, p = torch.zeros_like(m), torch.zeros_like(p)
+        rows = [[np.zeros(S, dtype=np.int64) for _ in range(N_STEPS)] for _ in range(B)]
+    seen = []
+    hook = lambda d: seen.append(dict(idx=d["idx"].copy(), loss_adv=d["loss_adv"].copy(), g_adv=d["g_adv"].clone(),
+                                      grad_mask=d["grad_mask"].clone(), lr=d["lr"].copy()))
+    loop = HotLoop(DorPatch(micro_batch=6, process_group=pg, verbose=False), net, x, 0.12, 10, "t/cfg/sub", 0, y,
+                   True, 1e-2, 1e-1, 0, 1, 10 ** 6, 7, 'topk', 2, S, 1e-3, 1e-3, 4.0, False,
+                   dict(init_mask=m, init_pattern=p, rngs=[FixedDraw(rows[b]) for b in range(B)], step_hook=hook))
+    for i in range(N_STEPS):
+        loop.step(i)
+    out = dict(seen=seen, pattern=loop.adv_pattern.clone(), mask=loop.adv_mask.clone(),
+               failed=[list(st.failed_idxs) for st in loop.img], s_local=loop.S_local)
+    loop.close()
+    return out
+
+
+def _loop_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        with _emu_patch().emulated_ops():
+            out = _run_loop(dist.group.WORLD, rank)
+        torch.save(out, os.path.join(out_dir, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hot_loop_two_ranks_equals_one(tmp_path):
+    world = 2
+    mp.spawn(_loop_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    with _emu_patch().emulated_ops():
+        want = _run_loop(None, 0)
+    outs = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(world)]
+    assert want["s_local"] == S and all(o["s_local"] == S // world for o in outs)
+    for o in outs:
+        assert o["failed"] == want["failed"]                       # sharded sweep + MAX-reduce == full sweep
+        for k in range(N_STEPS):
+            a, w = o["seen"][k], want["seen"][k]
+            assert np.array_equal(a["idx"], w["idx"])                  # rank 0's draw, everywhere
+            if k == 0:
+                # identical parameters going in: only the S-summation order differs
+                np.testing.assert_allclose(a["loss_adv"], w["loss_adv"], rtol=1e-5, atol=1e-6)
+                scale = float(w["g_adv"].abs().max())
+                np.testing.assert_allclose(a["g_adv"].numpy(), w["g_adv"].numpy(), rtol=1e-4, atol=1e-5 * scale)
+                assert torch.equal(torch.isnan(a["grad_mask"]), torch.isnan(w["grad_mask"]))
+            else:
+                np.testing.assert_allclose(a["loss_adv"], w["loss_adv"], rtol=2e-2, atol=2e-3)
+        # the signed update may flip where |grad| ~ ulp (sum order): compare by fraction of differing pixels
+        assert ((o["pattern"] - want["pattern"]).abs() > 1e-6).float().mean() < 5e-3
+        assert ((o["mask"] - want["mask"]).abs() > 1e-6).float().mean() < 5e-3
+    # ranks stay in lock-step: bit-identical reduced gradients, losses and parameters
+    for k in range(N_STEPS):
+        assert torch.equal(outs[0]["seen"][k]["g_adv"], outs[1]["seen"][k]["g_adv"])
+        assert np.array_equal(outs[0]["seen"][k]["loss_adv"], outs[1]["seen"][k]["loss_adv"])
+    assert torch.equal(outs[0]["pattern"], outs[1]["pattern"]) and torch.equal(outs[0]["mask"], outs[1]["mask"])
+
+
+# ---------------------------------------------------------------- evaluation driver, both shard modes
+def _driver_worker(rank, world, port, out_dir, shard):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.chdir(out_dir)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dorpatch_amd import driver
+        from oracle import toy_models
+        model = toy_models.NormModel(toy_models.make_toy(gain=2.0), toy_models.Normalize())
+        batches = []
+        for i in range(2):
+            x = torch.rand(1, 3, H, H, generator=torch.Generator().manual_seed(100 + i))
+            with torch.no_grad():
+                batches.append((x, model(x).argmax(-1)))
+        args = driver.build_parser().parse_args(["--num_images", "2", "--max_iterations", "3", "--sampling_size", "4",
+                                                 "--img_size", str(H), "--quiet", "--shard", shard])
+        with _emu_patch().emulated_ops():
+            out = driver.run(args, model=model, dataloader=batches, device="cpu", process_group=dist.group.WORLD,
+                             n_classes=10)
+        torch.save(out, os.path.join(out_dir, "metrics%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shard", ["images", "samples"])
+def test_driver_two_ranks(shard, tmp_path):
+    world = 2
+    mp.spawn(_driver_worker, args=(world, _free_port(), str(tmp_path), shard), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), "metrics%d.pt" % r), weights_only=False) for r in range(world)]
+    keys = ("acc_clean", "acc_robust", "acc_PC", "certified_acc_PC", "certified_asr_PC", "n_images")
+    assert all(outs[0][k] == outs[1][k] for k in keys)                  # every rank reports the whole job
+    assert outs[0]["n_images"] == 2
+    rd = os.path.join(str(tmp_path), outs[0]["result_dir"])
+    for i in range(2):
+        for name in ("adv_mask_%d.pt", "adv_pattern_%d.pt", "adv_PC_%d.pt"):
+            assert os.path.exists(os.path.join(rd, name % i)), (shard, name % i)
