@@ -54,6 +54,9 @@ def parse():
                     help="1: torch.backends.cudnn.benchmark=True (MIOpen exhaustive find: minutes on a fresh box); "
                          "0: MIOpen immediate mode")
     ap.add_argument("--no-fused-gn", action="store_true", help="eager GroupNorm+ReLU instead of dp_gn_relu_*")
+    ap.add_argument("--conv1x1", default="auto", choices=["auto", "gemm", "miopen"],
+                    help="library route of the backbone's frozen 1x1/1 convolutions: measured per shape (auto), "
+                         "always the batched GEMM, or always MIOpen (dorpatch_amd/conv1x1.py)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for functional "
                                                        "multi-rank tests on a single GPU)")
     ap.add_argument("--same-device", action="store_true",
@@ -163,6 +166,8 @@ def main():
     if args.no_fused_gn:
         from dorpatch_amd.resnetv2 import GroupNormAct
         GroupNormAct.fused = False
+    from dorpatch_amd import conv1x1
+    conv1x1.MODE = args.conv1x1
     B, S_local, H = args.batch, args.samples, args.size
     S = S_local * world                          # weak scaling: fixed per-GPU work
     torch.manual_seed(1234)
@@ -238,6 +243,7 @@ def main():
                        "images": B, "masks_per_image_per_gpu": S_local, "masks_per_image_total": S,
                        "image_size": H, "micro_batch": args.micro_batch, "miopen_find": bool(args.find),
                        "fused_gn_relu": not args.no_fused_gn,
+                       "conv1x1": dict(mode=args.conv1x1, **conv1x1.report()),
                        "parallelism": "eot-sample sharding x%d, 1 all-reduce of the patch gradient per step" % world},
             "roofline": {"kernel": "k_apply_fwd (dp_apply_fwd)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

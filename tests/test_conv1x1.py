@@ -1,0 +1,69 @@
+"""dorpatch_amd.conv1x1: both library routes of a frozen 1x1 convolution compute the same thing as
+F.conv2d and its autograd, and "auto" caches one measured choice per (direction, shape)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from dorpatch_amd import conv1x1
+
+
+@pytest.fixture(autouse=True)
+def _restore():
+    mode = conv1x1.MODE
+    conv1x1.reset()
+    yield
+    conv1x1.MODE = mode
+    conv1x1.reset()
+
+
+@pytest.mark.parametrize("mode", ["gemm", "miopen", "auto"])
+@pytest.mark.parametrize("N,C,O,H", [(3, 64, 256, 14), (2, 512, 128, 7), (1, 8, 8, 5)])
+def test_matches_conv2d_and_its_input_gradient(mode, N, C, O, H):
+    conv1x1.MODE = mode
+    g = torch.Generator().manual_seed(N * 1000 + C)
+    x = torch.randn(N, C, H, H, generator=g)
+    w = torch.randn(O, C, 1, 1, generator=g) / np.sqrt(C)
+    dy = torch.randn(N, O, H, H, generator=g)
+    xr = x.clone().requires_grad_(True)
+    want = F.conv2d(xr, w)
+    (gx_want,) = torch.autograd.grad(want, xr, dy)
+    xa = x.clone().requires_grad_(True)
+    got = conv1x1.Conv1x1Function.apply(xa, w)
+    (gx,) = torch.autograd.grad(got, xa, dy)
+    assert got.shape == want.shape and got.is_contiguous() and gx.is_contiguous()
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gx, gx_want, rtol=1e-5, atol=1e-5)
+
+
+def test_auto_calibrates_once_per_shape_and_direction():
+    conv1x1.MODE = "auto"
+    w = torch.randn(16, 8, 1, 1)
+    for _ in range(3):
+        x = torch.randn(2, 8, 6, 6, requires_grad=True)
+        conv1x1.Conv1x1Function.apply(x, w).sum().backward()
+    x = torch.randn(4, 8, 6, 6)                       # another batch size: its own entry, forward only
+    with torch.no_grad():
+        conv1x1.Conv1x1Function.apply(x, w)
+    rep = conv1x1.report()
+    assert rep["fwd"]["gemm"] + rep["fwd"]["miopen"] == 2 and rep["bwd"]["gemm"] + rep["bwd"]["miopen"] == 1
+    assert set(k[0] for k in conv1x1._choice) == {"fwd", "bwd"}
+
+
+def test_backbone_uses_it_only_for_frozen_folded_1x1_stride1_gpu_tensors():
+    from dorpatch_amd.resnetv2 import StdConv2d
+    conv = StdConv2d(8, 8, 1)
+    x = torch.randn(1, 8, 4, 4)
+
+    class Cuda(object):      # stand-in with the attributes `applicable` reads
+        is_cuda, dtype = True, torch.float32
+        dim = staticmethod(lambda: 4)
+        is_contiguous = staticmethod(lambda: True)
+    assert not conv1x1.applicable(conv, x)                              # CPU tensor
+    assert not conv1x1.applicable(conv, Cuda)                           # weight still trainable
+    conv.weight.requires_grad_(False)
+    assert conv1x1.applicable(conv, Cuda)
+    assert not conv1x1.applicable(StdConv2d(8, 8, 1, stride=2).requires_grad_(False), Cuda)
+    assert not conv1x1.applicable(StdConv2d(8, 8, 3, padding=1).requires_grad_(False), Cuda)
+    conv1x1.MODE = "miopen"
+    assert not conv1x1.applicable(conv, Cuda)
