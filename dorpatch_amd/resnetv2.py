@@ -12,8 +12,10 @@ image, so this is a restatement of the published architecture with
     stages.{s}.blocks.{b}.norm{1,2,3}.{weight,bias}
     norm.{weight,bias}      head.fc.{weight,bias}
 
-Validated by parameter count (25 549 352) and MAC count only — no reference
-test pins any logits at this boundary ("parity unpinned").
+No reference test pins any logits at this boundary and timm cannot be installed offline; the
+restatement is pinned against transformers' ``BitForImageClassification`` (the HF port of the same timm
+model: equal logits / input gradients for equal weights, ``tests/test_backbone_vs_hf_bit.py``) and by
+parameter count (25 549 352); parity against timm itself stays unpinned.
 
 The backbone is *frozen* on the hot path, so the per-forward weight
 standardisation of ``StdConv2d`` is folded once (``fold_weight_standardization``).
