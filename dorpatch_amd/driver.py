@@ -23,7 +23,7 @@ recomputed, ``main.py:100-118, 144-153``).  What changes is the machinery:
   patch gradient per step);
 * extra flags (never part of the result path, so directories stay interchangeable with the
   reference's): ``--num_images`` (the reference hard-codes 10, ``main.py:85``), ``--max_iterations``,
-  ``--sampling_size``, ``--img_size``, ``--synthetic`` (seeded-random weights + ``torch.rand`` images:
+  ``--sampling_size``, ``--img_size``, ``--miopen_find``, ``--synthetic`` (seeded-random weights + ``torch.rand`` images:
   neither ImageNet nor the checkpoint can be fetched offline), ``--shard``, ``--micro_batch``.
 """
 import argparse
@@ -81,6 +81,9 @@ def build_parser():
     extra.add_argument('--shard', default='images', choices=['images', 'samples'],
                        help='multi-process work split: whole batches per rank, or EOT samples of every batch')
     extra.add_argument('--micro_batch', default=512, type=int, help='EOT samples per backbone forward/backward')
+    extra.add_argument('--miopen_find', action='store_true',
+                       help="keep the reference's cudnn.benchmark=True (utils.py:17): on ROCm that is MIOpen's exhaustive "
+                            "find, minutes per new batch shape for < 2 %% (profiles/README.md); default: immediate mode")
     extra.add_argument('--quiet', action='store_true', help='no per-iteration progress lines')
     return parser
 
@@ -128,6 +131,7 @@ def run(args, model=None, dataloader=None, device=None, process_group=None, n_cl
     if device.type == "cuda":
         torch.cuda.set_device(device)
     U.set_random_seed()                                                        # main.py:49
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
     n_classes = n_classes or U.NUM_CLASSES_DICT[args.dataset]
     ref_cfg = {k: getattr(args, k) for k in REFERENCE_KEYS}
     if rank == 0:
@@ -168,6 +172,7 @@ def run(args, model=None, dataloader=None, device=None, process_group=None, n_cl
                 if i % world != rank:
                     continue
                 U.set_random_seed(1234 + i)           # image-sharded: draws do not depend on the world size
+                torch.backends.cudnn.benchmark = bool(args.miopen_find)
             x, y = x.to(device), y.to(device)
             logits = model(x)                                                  # main.py:91-100
             preds = logits.argmax(-1)

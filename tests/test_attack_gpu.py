@@ -253,6 +253,38 @@ def test_micro_batching_does_not_change_the_step(mb):
     np.testing.assert_allclose(outs[0]["g_adv"].numpy(), outs[1]["g_adv"].numpy(), rtol=1e-4, atol=1e-5 * scale)
 
 
+def test_oversampling_and_single_window_universe():
+    """attack.py:92-94: a sampling_size larger than the universe is cut to the universe (dropout = 1: the
+    4 x 36 = 144 single-window masks), so every mask is drawn exactly once per step; losses match the oracle.
+    The other extreme, S = 1, also runs."""
+    H = 56
+    model = _toy(2.0)
+    g = torch.Generator().manual_seed(41)
+    x, m0, p0 = torch.rand(1, 3, H, H, generator=g), torch.rand(1, 1, H, H, generator=g), torch.rand(1, 3, H, H, generator=g)
+    got = {}
+    loop = HotLoop(DorPatch(verbose=False), model, x.to(DEV), 0.12, 10, "t/cfg/sub", 0, torch.tensor([3], device=DEV),
+                   True, 1e-2, 1e-1, 0, 1, 10 ** 6, 7, 'topk', 1, 500, 1e-3, 1e-3, 4.0, False,
+                   dict(failure_refresh=10 ** 9, rngs=[np.random.RandomState(0)], step_hook=_grab(got),
+                        init_mask=m0, init_pattern=p0))
+    assert loop.n_mask == 144 and loop.S == 144
+    loop.step(1)
+    loop.close()
+    idx = got["idx"][0]
+    assert sorted(idx.tolist()) == list(range(144))
+    uni = R.mask_universe(H, 1)
+    assert uni.shape[0] == 144
+    want = R.eot_step(_toy(2.0, "cpu"), x, m0, p0, torch.tensor([3]), uni[torch.from_numpy(idx)], stage=0,
+                      targeted=True, n_classes=10)
+    np.testing.assert_allclose(got["loss_adv"][0], want["loss_adv"][0].numpy(), rtol=1e-4, atol=1e-5)
+    gw = want["grad_pattern"].numpy()
+    np.testing.assert_allclose(got["grad_pattern"].numpy(), gw, rtol=1e-3, atol=1e-3 * np.abs(gw).max())
+    one = _loop(model, x.to(DEV), torch.tensor([3], device=DEV), 1,
+                dict(step_hook=_grab(got), rngs=[np.random.RandomState(1)]))
+    one.step(1)
+    one.close()
+    assert got["loss_adv"].shape == (1, 1) and np.isfinite(got["loss_adv"]).all()
+
+
 def test_dual_masks_match_oracle():
     """attack.py:208-218 (`dual=True`): two sampled masks per EOT sample."""
     H, S = 56, 6

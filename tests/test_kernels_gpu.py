@@ -75,6 +75,62 @@ def test_apply_fwd_dual_and_shared_idx():
     assert torch.equal(out, want)
 
 
+def test_apply_fwd_edge_geometries():
+    """Degenerate and maximal inputs of the occlusion kernel: a single sample of a single image, the
+    3-window tables of MaskWindow(n_patch=2) (DP_MAX_RECTS - 1), windows clipped at the image border,
+    an empty rectangle (nothing occluded), a rectangle covering the whole image (everything = fill), and
+    a width with a ragged float4 tail count (W = 20: 5 groups per row)."""
+    from dorpatch_amd.patchcleanser import MaskWindow
+    H = 56
+    adv = _rand(1, 3, H, H, seed=8)
+    mw = MaskWindow(H, 0.06, 2)
+    assert mw.double_rects.shape == (36 * 630, 3, 4)
+    t3 = ops.upload_table(mw.double_rects, DEV)
+    pick = np.array([0, 629, 630 * 17 + 311, 36 * 630 - 1])
+    keep3 = masks.rects_to_bool(mw.double_rects[pick], H)
+    for k, m in enumerate(pick):                                   # S = 1, B = 1
+        out = ops.apply_fwd(adv.to(DEV), t3, torch.tensor([int(m)], dtype=torch.int32, device=DEV)).cpu()
+        assert torch.equal(out, R.occlude(adv, keep3[k:k + 1])[0])
+    special = np.array([[[0, 0, 0, 0]], [[0, H, 0, H]], [[H - 3, H, H - 5, H]]], dtype=np.int32)
+    ts = ops.upload_table(special, DEV)
+    out = ops.apply_fwd(adv.to(DEV), ts, torch.arange(3, dtype=torch.int32, device=DEV)).cpu()
+    assert torch.equal(out[0], adv[0]) and bool((out[1] == 0.5).all())
+    want = adv[0].clone()
+    want[:, H - 3:, H - 5:] = 0.5
+    assert torch.equal(out[2], want)
+    Hn, Wn = 12, 20                                                # non-square, W/4 odd
+    a2 = _rand(2, 3, Hn, Wn, seed=9)
+    t2 = ops.upload_table(np.array([[[2, 7, 3, 18]], [[0, 12, 19, 20]]], dtype=np.int32), DEV)
+    o2 = ops.apply_fwd(a2.to(DEV), t2, torch.tensor([[0, 1], [1, 0]], dtype=torch.int32, device=DEV)).cpu()
+    o2 = o2.view(2, 2, 3, Hn, Wn)
+    w0, w1 = a2.clone(), a2.clone()
+    w0[:, :, 2:7, 3:18] = 0.5
+    w1[:, :, :, 19:20] = 0.5
+    assert torch.equal(o2[0, 0], w0[0]) and torch.equal(o2[0, 1], w1[0])
+    assert torch.equal(o2[1, 0], w1[1]) and torch.equal(o2[1, 1], w0[1])
+
+
+def test_invalid_geometry_is_rejected_not_computed():
+    """Error convention of the C ABI (hipErrorInvalidValue -> RuntimeError in the host wrapper): a width
+    that is not a multiple of 4, more windows than DP_MAX_RECTS, a zero std, B*S mismatch."""
+    adv = _rand(1, 3, 8, 6, seed=1).to(DEV)                       # W % 4 != 0
+    t = ops.upload_table(np.zeros((1, 1, 4), dtype=np.int32), DEV)
+    i0 = torch.zeros(1, dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.apply_fwd(adv, t, i0)
+    with pytest.raises(AssertionError):
+        ops.upload_table(np.zeros((1, 5, 4), dtype=np.int32), DEV)
+    ok = _rand(1, 3, 8, 8, seed=2).to(DEV)
+    with pytest.raises(RuntimeError):
+        ops.apply_fwd(ok, t, i0, None, ops.make_norm([0.5] * 3, [0.5, 0.0, 0.5], 0.5))
+    with pytest.raises(AssertionError):
+        ops.apply_bwd(torch.zeros(3, 3, 8, 8, device=DEV), t, torch.zeros((2, 2), dtype=torch.int32, device=DEV))
+    with pytest.raises(TypeError):
+        ops.apply_fwd(ok, t, i0.long())
+    with pytest.raises(ValueError):
+        ops.apply_fwd(ok.transpose(2, 3), t, i0)
+
+
 @pytest.mark.parametrize("B,S,H", [(1, 128, 56), (4, 8, 224), (1, 64, 384), (64, 4, 56)])
 @pytest.mark.parametrize("normalize", [False, True])
 def test_apply_bwd_matches_autograd(B, S, H, normalize):
