@@ -49,7 +49,15 @@ def main():
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--find", type=int, nargs="+", default=[0, 1])
     ap.add_argument("--formats", nargs="+", default=["nchw", "nhwc"])
+    ap.add_argument("--no-fused", action="store_true",
+                    help="eager GroupNorm/ReLU/max-pool and plain F.conv2d everywhere, so that the memory format is "
+                         "the only difference between the runs (set PYTORCH_MIOPEN_SUGGEST_NHWC=1 for nhwc)")
     args = ap.parse_args()
+    if args.no_fused:
+        from dorpatch_amd import conv1x1
+        from dorpatch_amd.resnetv2 import GroupNormAct
+        GroupNormAct.fused = False
+        conv1x1.MODE = "miopen"
     net = seeded_init_(resnetv2_50x1_bit(1000)).fold_weight_standardization().freeze().cuda()
     for find in args.find:
         torch.backends.cudnn.benchmark = bool(find)

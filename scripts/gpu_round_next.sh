@@ -1,0 +1,17 @@
+#!/bin/bash
+# First GPU call of the NEXT round (~12 min of box time): the measurements DESIGN.md §10 asks for before any
+# NHWC work is written, then the knob A/B that round 6 could not finish, then the default bench + CPU baseline.
+#   1. backbone_probe: frozen ResNetV2-50 fwd + input-grad bwd, NCHW vs channels_last (MIOpen told to use NHWC
+#      kernels), eager GroupNorm in both so only the convolution layout differs          -> is NHWC worth building?
+#   2. ab_sweep: conv1x1 route (auto / forced gemm / miopen) x BLAS library at micro-batch 512
+#   3. bench.py (full line incl. cpu_baseline) and kbench
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/next
+mkdir -p $O
+cd $R
+( PYTORCH_MIOPEN_SUGGEST_NHWC=1 timeout 300 python scripts/backbone_probe.py --mb 256 --find 0 --formats nchw nhwc --no-fused ) > $O/probe_layout.txt 2>&1; echo "probe rc=$?" | tee -a $O/rc.txt
+( timeout 240 python scripts/ab_sweep.py --micro-batches 512 --modes auto,gemm,miopen,auto@cublas --steps 3 ) > $O/ab.jsonl 2> $O/ab.err; echo "ab rc=$?" | tee -a $O/rc.txt
+( time timeout 200 python bench.py ) > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" | tee -a $O/rc.txt
+( timeout 60 tools/kbench ) > $O/kbench.txt 2>&1; echo "kbench rc=$?" | tee -a $O/rc.txt
+cat $O/rc.txt; cat $O/probe_layout.txt | tail -8; cut -c1-300 $O/ab.jsonl; cut -c1-600 $O/bench.json
