@@ -15,7 +15,10 @@ stride-1 1x1 convolution IS a strided-batched GEMM on the tensors as they lie in
 Neither is always faster, so each (direction, N, C, O, HW) is timed once with both at first use
 (1 warm-up + ``CAL_ITERS`` launches each, HIP events) and the winner is cached for the process:
 MIOpen's own find mode, extended by one candidate it does not have.  ``MODE``: ``"auto"`` (default),
-``"gemm"``, ``"miopen"`` (the plain ``F.conv2d`` path, bypassing this module).
+``"gemm"``, ``"miopen"`` (the plain ``F.conv2d`` path, bypassing this module); the environment variable
+``DORPATCH_CONV1X1`` sets it at import.  A measured choice can differ between runs when two routes tie,
+which changes fp32 summation order only (like the reference's ``cudnn.benchmark = True``,
+``utils.py:17``); pin a mode for run-to-run bit reproducibility.
 
 Weights are frozen on this path (``DorPatch.generate`` freezes the backbone): there is no weight
 gradient.
@@ -25,7 +28,11 @@ import time
 import torch
 import torch.nn.functional as F
 
-MODE = "auto"
+import os
+
+MODE = os.environ.get("DORPATCH_CONV1X1", "auto")     # "auto" | "gemm" | "miopen"
+if MODE not in ("auto", "gemm", "miopen"):
+    raise ValueError("DORPATCH_CONV1X1 must be auto, gemm or miopen, got %r" % MODE)
 CAL_ITERS = 3
 _choice = {}          # (direction, N, C, O, HW, device) -> "gemm" | "miopen"
 _timings = {}         # same key -> (gemm_ms, miopen_ms)
