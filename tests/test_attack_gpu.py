@@ -285,6 +285,46 @@ def test_oversampling_and_single_window_universe():
     assert got["loss_adv"].shape == (1, 1) and np.isfinite(got["loss_adv"]).all()
 
 
+@pytest.mark.parametrize("stage", [0, 1])
+def test_step_at_384_matches_oracle(stage):
+    """BASELINE configs[2] geometry (384 x 384, 384 not a multiple of the 7-px cell): one whole step vs the
+    oracle.  The 54 x 54 group-lasso cells cover rows/cols 0..377, the 6-px border gets no group-lasso
+    gradient; density windows are 48 x 48.  Also the 384 rule of patch_selection: border 0."""
+    H, S = 384, 4
+    model = _toy(2.0)
+    g = torch.Generator().manual_seed(51)
+    x, m0, p0 = torch.rand(1, 3, H, H, generator=g), torch.rand(1, 1, H, H, generator=g), torch.rand(1, 3, H, H, generator=g)
+    if stage == 1:
+        m0 = (m0 > 0.9).float()
+    idx = np.random.RandomState(3).choice(2520, S, replace=False)
+    got = {}
+    loop = _loop(model, x.to(DEV), torch.tensor([3], device=DEV), S,
+                 dict(init_mask=m0, init_pattern=p0, step_hook=_grab(got), rngs=[FixedDraw([idx])]), budget=0.015625)
+    loop.stage = stage
+    assert loop.win == 48
+    loop.step(1)
+    new_mask, new_pattern = loop.adv_mask.cpu(), loop.adv_pattern.cpu()
+    loop.close()
+    want = R.eot_step(_toy(2.0, "cpu"), x, m0, p0, torch.tensor([3]), R.mask_universe(H, 2)[torch.from_numpy(idx)],
+                      stage=stage, targeted=True, n_classes=10, lr=0.01)
+    np.testing.assert_allclose(got["loss_adv"][0], want["loss_adv"][0].numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(got["loss_struc"][0], float(want["loss_struc"][0]), rtol=2e-5)
+    gw = want["grad_pattern"].numpy()
+    np.testing.assert_allclose(got["grad_pattern"].numpy(), gw, rtol=1e-3, atol=1e-3 * np.abs(gw).max())
+    assert ((new_pattern - want["new_pattern"]).abs() > 1e-6).float().mean() < 2e-3
+    if stage == 0:
+        np.testing.assert_allclose(got["group_lasso"][0], float(want["group_lasso"][0]), rtol=2e-5)
+        np.testing.assert_allclose(got["density"][0], float(want["density"][0]), rtol=1e-4)
+        gm, gmw = got["grad_mask"].numpy(), want["grad_mask"].numpy()
+        np.testing.assert_allclose(gm, gmw, rtol=1e-3, atol=1e-3 * np.abs(gmw).max())
+        assert ((new_mask - want["new_mask"]).abs() > 1e-6).float().mean() < 2e-3
+    else:
+        assert torch.equal(new_mask, m0)
+    sel = DorPatch(verbose=False).patch_selection(torch.rand(1, 1, H, H, generator=g).to(DEV), 0.015625).cpu()
+    assert sel.shape == (1, 1, H, H) and float(sel[..., 378:, :].sum()) == 0 and float(sel[..., :, 378:].sum()) == 0
+    assert float(sel.sum()) == np.floor(H * H * 0.015625 / 49) * 49          # 47 cells of 49 px
+
+
 def test_dual_masks_match_oracle():
     """attack.py:208-218 (`dual=True`): two sampled masks per EOT sample."""
     H, S = 56, 6
