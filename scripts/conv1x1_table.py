@@ -39,7 +39,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=512)
     ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--find", type=int, default=0, help="1: MIOpen exhaustive find for the MIOpen route")
     args = ap.parse_args()
+    torch.backends.cudnn.benchmark = bool(args.find)
     conv1x1.MODE = "auto"
     dev = torch.device("cuda", 0)
     todo = sorted(shapes(args.size).items(), key=lambda kv: -kv[1] * kv[0][0] * kv[0][1] * kv[0][2])

@@ -12,6 +12,9 @@ mkdir -p $O
 cd $R
 ( PYTORCH_MIOPEN_SUGGEST_NHWC=1 timeout 300 python scripts/backbone_probe.py --mb 256 --find 0 --formats nchw nhwc --no-fused ) > $O/probe_layout.txt 2>&1; echo "probe rc=$?" | tee -a $O/rc.txt
 ( timeout 240 python scripts/ab_sweep.py --micro-batches 512 --modes auto,gemm,miopen,auto@cublas --steps 3 ) > $O/ab.jsonl 2> $O/ab.err; echo "ab rc=$?" | tee -a $O/rc.txt
+# 2b. can the GEMM route go faster with PyTorch's TunableOp picking the hipBLASLt/rocBLAS solution per shape?
+( timeout 60 python scripts/conv1x1_table.py ) > $O/conv1x1_default.jsonl 2> $O/c1.err; echo "table rc=$?" | tee -a $O/rc.txt
+( PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1 PYTORCH_TUNABLEOP_FILENAME=$O/tunableop.csv PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS=200 timeout 240 python scripts/conv1x1_table.py ) > $O/conv1x1_tunableop.jsonl 2> $O/c2.err; echo "table-tuned rc=$?" | tee -a $O/rc.txt
 ( time timeout 200 python bench.py ) > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" | tee -a $O/rc.txt
 ( timeout 60 tools/kbench ) > $O/kbench.txt 2>&1; echo "kbench rc=$?" | tee -a $O/rc.txt
 cat $O/rc.txt; cat $O/probe_layout.txt | tail -8; cut -c1-300 $O/ab.jsonl; cut -c1-600 $O/bench.json
