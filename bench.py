@@ -35,9 +35,18 @@ import torch
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
+# BASELINE.json `configs` entries that fit one GPU: (images, masks per image per GPU, side, budget)
+PRESETS = {0: (8, 4, 224, 0.0204),          # configs[0]: the reference's own CPU-runnable case
+           1: (64, 32, 224, 0.0204),        # configs[1]: the configuration the metric is quoted on (default)
+           2: (1, 64, 384, 0.015625),       # configs[2]: 384x384, 48x48 budget, 64 EOT samples
+           3: (1, 64, 224, 0.0204)}         # configs[3]: per-GPU share (64 of 512 samples of one image)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--config", type=int, default=None, choices=sorted(PRESETS),
+                    help="index into BASELINE.json `configs`: sets --batch/--samples/--size/--patch-budget")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="images per step (config 2: 64)")
@@ -61,7 +70,12 @@ def parse():
                                                        "multi-rank tests on a single GPU)")
     ap.add_argument("--same-device", action="store_true",
                     help="all ranks use cuda:0 (functional test of the multi-rank path on a 1-GPU box; gloo only)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config is not None:
+        args.batch, args.samples, args.size, args.patch_budget = PRESETS[args.config]
+    args.config_label = next(("BASELINE configs[%d]" % k for k, v in PRESETS.items()
+                              if v == (args.batch, args.samples, args.size, args.patch_budget)), "custom")
+    return args
 
 
 def build_model(device):
@@ -236,10 +250,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d images x %d sampled PatchCleanser double-masks per "
+            "config": {"workload": "%s: %d images x %d sampled PatchCleanser double-masks per "
                                    "image per GPU = %d EOT samples/step/GPU, %dx%d, ResNetV2-50x1-BiT "
                                    "(seeded random weights, frozen, fp32), stage-%d step of DorPatch.generate, "
-                                   "patch_budget %.4f" % (B, S_local, B * S_local, H, H, args.stage, args.patch_budget),
+                                   "patch_budget %.4f" % (args.config_label, B, S_local, B * S_local, H, H, args.stage,
+                                                          args.patch_budget),
                        "images": B, "masks_per_image_per_gpu": S_local, "masks_per_image_total": S,
                        "image_size": H, "micro_batch": args.micro_batch, "miopen_find": bool(args.find),
                        "fused_gn_relu": not args.no_fused_gn,

@@ -16,5 +16,6 @@ cd $R
 ( timeout 60 python scripts/conv1x1_table.py ) > $O/conv1x1_default.jsonl 2> $O/c1.err; echo "table rc=$?" | tee -a $O/rc.txt
 ( PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1 PYTORCH_TUNABLEOP_FILENAME=$O/tunableop.csv PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS=200 timeout 240 python scripts/conv1x1_table.py ) > $O/conv1x1_tunableop.jsonl 2> $O/c2.err; echo "table-tuned rc=$?" | tee -a $O/rc.txt
 ( time timeout 200 python bench.py ) > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" | tee -a $O/rc.txt
+for c in 2 3; do ( timeout 150 python bench.py --config $c --no-cpu-baseline --no-sweep ) > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err; echo "bench cfg$c rc=$?" | tee -a $O/rc.txt; done
 ( timeout 60 tools/kbench ) > $O/kbench.txt 2>&1; echo "kbench rc=$?" | tee -a $O/rc.txt
 cat $O/rc.txt; cat $O/probe_layout.txt | tail -8; cut -c1-300 $O/ab.jsonl; cut -c1-600 $O/bench.json
