@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
+DEVICE_OVERRIDE = None     # test hook (tests/test_bench_emu.py runs main() on CPU tensors through the HIP emulation)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 
 
@@ -160,11 +161,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
-    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (no CPU fallback for the product path)"
-    if args.same_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if DEVICE_OVERRIDE is None:
+        assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (no CPU fallback for the product path)"
+        if args.same_device:
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device(DEVICE_OVERRIDE)
     pg = None
     if world > 1:
         import torch.distributed as dist
@@ -197,11 +201,13 @@ def main():
     loop.stage = args.stage
 
     def barrier():
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
 
     note("model + loop ready (B=%d S=%d H=%d world=%d)" % (B, S, H, world))
     i = 1                                        # i % 100 != 0: the periodic failure sweep is timed apart

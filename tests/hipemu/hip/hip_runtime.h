@@ -262,6 +262,6 @@ inline hipError_t hipEventDestroy(hipEvent_t e) {
 }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) {
-  *ms = 0.f;
+  *ms = 1.0f;  // the emulation has no clock: a fixed, non-zero placeholder (callers divide by it)
   return hipSuccess;
 }

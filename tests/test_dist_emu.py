@@ -168,3 +168,33 @@ def test_driver_two_ranks(shard, tmp_path):
     for i in range(2):
         for name in ("adv_mask_%d.pt", "adv_pattern_%d.pt", "adv_PC_%d.pt"):
             assert os.path.exists(os.path.join(rd, name % i)), (shard, name % i)
+
+
+# ---------------------------------------------------------------- bench.py's multi-rank control flow
+def _bench_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.argv = ["bench.py", "--gpus", str(world), "--backend", "gloo", "--batch", "1", "--samples", "2", "--size", "64",
+                "--steps", "1", "--warmup", "1", "--micro-batch", "2", "--no-sweep", "--no-cpu-baseline"]
+    import contextlib
+    import bench
+    bench.DEVICE_OVERRIDE = "cpu"
+    with open(os.path.join(out_dir, "stdout%d.txt" % rank), "w") as f, contextlib.redirect_stdout(f):
+        with _emu_patch().emulated_ops():
+            bench.main()
+
+
+def test_bench_two_ranks_prints_one_whole_job_line(tmp_path):
+    """`python -m torch.distributed.run ... bench.py --gpus 2` as the driver launches it (here: gloo, CPU
+    tensors, emulated kernels): rank 0 alone prints the line, for the WHOLE job (weak scaling: 2 masks per
+    image per rank -> 4 per image in total)."""
+    import json
+    world = 2
+    mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    out0 = open(os.path.join(str(tmp_path), "stdout0.txt")).read().strip().splitlines()
+    out1 = open(os.path.join(str(tmp_path), "stdout1.txt")).read().strip()
+    assert len(out0) == 1 and out1 == ""
+    line = json.loads(out0[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "cpu_baseline" not in line
+    assert line["config"]["masks_per_image_per_gpu"] == 2 and line["config"]["masks_per_image_total"] == 4
+    assert abs(line["value"] - 1 * 4 / (line["ms_per_step"] / 1e3)) <= 0.006 + 1e-3 * line["value"]
