@@ -1,6 +1,6 @@
 """bench.py's own control flow and its one-JSON-line contract, exercised without a GPU: main() runs on
 CPU tensors with every dp_* kernel going through the host emulation (tests/hipemu), on a tiny geometry
-(1 image x 2 masks @64x64, the real ResNetV2-50x1-BiT).  Guards the driver's round-end bench against
+(1 image x 2 masks @32x32, the real ResNetV2-50x1-BiT).  Guards the driver's round-end bench against
 host-side breakage (argument handling, the roofline / cpu_baseline / config objects); says nothing about
 speed — the numbers printed here are meaningless and are not checked."""
 import json
@@ -32,12 +32,12 @@ def _run_bench(monkeypatch, capsys, argv):
 
 
 def test_bench_line_contract(monkeypatch, capsys):
-    out = _run_bench(monkeypatch, capsys, ["--batch", "1", "--samples", "2", "--size", "64", "--steps", "1",
-                                           "--warmup", "1", "--micro-batch", "2", "--no-sweep", "--no-cpu-baseline"])
+    out = _run_bench(monkeypatch, capsys, ["--batch", "1", "--samples", "2", "--size", "32", "--steps", "1",
+                                           "--warmup", "0", "--micro-batch", "2", "--no-sweep", "--no-cpu-baseline"])
     for k, t in REQUIRED.items():
         assert isinstance(out[k], t), (k, out[k])
     assert out["metric"] == "EOT-samples/sec" and out["unit"] == "EOT-samples/s" and out["higher_is_better"] is True
-    assert (out["n_gpus"], out["steps"], out["warmup"]) == (1, 1, 1) and out["scaling"] == "weak"
+    assert (out["n_gpus"], out["steps"], out["warmup"]) == (1, 1, 0) and out["scaling"] == "weak"
     assert out["vs_baseline"] is None and out["dtype"] == "f32" and out["data"] == "synthetic"
     # value == B*S / step time (both are rounded to 2-3 decimals in the line)
     assert abs(out["value"] - 1 * 2 / (out["ms_per_step"] / 1e3)) <= 0.006 + 1e-3 * out["value"]
@@ -45,7 +45,7 @@ def test_bench_line_contract(monkeypatch, capsys):
     assert cfg["workload"].startswith("custom:") and "model" not in cfg
     assert cfg["conv1x1"]["mode"] == "auto" and cfg["images"] == 1 and cfg["masks_per_image_per_gpu"] == 2
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
-    assert roof["algorithmic_bytes_per_launch"] == 1 * 2 * 3 * 64 * 64 * 4
+    assert roof["algorithmic_bytes_per_launch"] == 1 * 2 * 3 * 32 * 32 * 4
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["traffic"] is None
     assert "cpu_baseline" not in out and "collect_failure_sweep_ms" not in out
 
@@ -58,7 +58,7 @@ def test_presets_name_the_baseline_configs(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "2"])
     a = bench.parse()
     assert (a.batch, a.samples, a.size, a.patch_budget) == (1, 64, 384, 0.015625)
-    assert bench.pmc_traffic(64, 32, 224) == 1274372598 and bench.pmc_traffic(1, 2, 64) is None
+    assert bench.pmc_traffic(64, 32, 224) == 1274372598 and bench.pmc_traffic(1, 2, 32) is None
 
 
 def test_cpu_baseline_leg_is_bounded_and_labelled():

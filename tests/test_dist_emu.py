@@ -58,6 +58,7 @@ class FixedDraw(object):
 
 
 H, S, B, N_STEPS = 56, 8, 2, 3
+N_MASK = 144          # dropout = 1: the 4 x 36 single-window universe keeps the sharded failure sweep cheap
 
 
 def _problem():
@@ -65,7 +66,7 @@ def _problem():
     g = torch.Generator().manual_seed(3)
     x, m, p = torch.rand(B, 3, H, H, generator=g), torch.rand(B, 1, H, H, generator=g), torch.rand(B, 3, H, H, generator=g)
     y = torch.tensor([2, 7])
-    rows = [[np.random.RandomState(10 * b + k).choice(2520, S, replace=False) for k in range(N_STEPS)] for b in range(B)]
+    rows = [[np.random.RandomState(10 * b + k).choice(N_MASK, S, replace=False) for k in range(N_STEPS)] for b in range(B)]
     net = toy_models.NormModel(toy_models.make_toy(gain=3.0), toy_models.Normalize())
     return x, m, p, y, rows, net
 
@@ -81,8 +82,9 @@ def _run_loop(pg, rank):
     hook = lambda d: seen.append(dict(idx=d["idx"].copy(), loss_adv=d["loss_adv"].copy(), g_adv=d["g_adv"].clone(),
                                       grad_mask=d["grad_mask"].clone(), lr=d["lr"].copy()))
     loop = HotLoop(DorPatch(micro_batch=6, process_group=pg, verbose=False), net, x, 0.12, 10, "t/cfg/sub", 0, y,
-                   True, 1e-2, 1e-1, 0, 1, 10 ** 6, 7, 'topk', 2, S, 1e-3, 1e-3, 4.0, False,
+                   True, 1e-2, 1e-1, 0, 1, 10 ** 6, 7, 'topk', 1, S, 1e-3, 1e-3, 4.0, False,
                    dict(init_mask=m, init_pattern=p, rngs=[FixedDraw(rows[b]) for b in range(B)], step_hook=hook))
+    assert loop.n_mask == N_MASK
     for i in range(N_STEPS):
         loop.step(i)
     out = dict(seen=seen, pattern=loop.adv_pattern.clone(), mask=loop.adv_mask.clone(),
@@ -140,6 +142,7 @@ def _driver_worker(rank, world, port, out_dir, shard):
     try:
         from dorpatch_amd import driver
         from oracle import toy_models
+        driver.DEFENSE_RATIOS = (0.03,)           # one defence instead of four: the sweeps dominate under emulation
         model = toy_models.NormModel(toy_models.make_toy(gain=2.0), toy_models.Normalize())
         batches = []
         for i in range(2):
@@ -174,8 +177,8 @@ def test_driver_two_ranks(shard, tmp_path):
 def _bench_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
-    sys.argv = ["bench.py", "--gpus", str(world), "--backend", "gloo", "--batch", "1", "--samples", "2", "--size", "64",
-                "--steps", "1", "--warmup", "1", "--micro-batch", "2", "--no-sweep", "--no-cpu-baseline"]
+    sys.argv = ["bench.py", "--gpus", str(world), "--backend", "gloo", "--batch", "1", "--samples", "2", "--size", "32",
+                "--steps", "1", "--warmup", "0", "--micro-batch", "2", "--no-sweep", "--no-cpu-baseline"]
     import contextlib
     import bench
     bench.DEVICE_OVERRIDE = "cpu"
