@@ -11,6 +11,10 @@ O=$R/gpurun_out/next
 mkdir -p $O
 cd $R
 ( PYTORCH_MIOPEN_SUGGEST_NHWC=1 timeout 300 python scripts/backbone_probe.py --mb 256 --find 0 --formats nchw nhwc --no-fused ) > $O/probe_layout.txt 2>&1; echo "probe rc=$?" | tee -a $O/rc.txt
+# micro-batches small enough that one layer's activations (64 x 256 x 56^2 x 4 B = 205 MB) stay in the 256 MB
+# Infinity Cache between producer and consumer kernels: do the HBM-bound GroupNorm kernels speed up, and does the
+# host keep up (~450 launches per micro-batch)?  If the GPU wins but the host cannot: hipGraph the micro-batch.
+( timeout 300 python scripts/ab_sweep.py --micro-batches 64,128 --modes auto --steps 3 ) > $O/ab_small_mb.jsonl 2> $O/ab_small_mb.err; echo "ab-small rc=$?" | tee -a $O/rc.txt
 ( timeout 240 python scripts/ab_sweep.py --micro-batches 512 --modes auto,gemm,miopen,auto@cublas --steps 3 ) > $O/ab.jsonl 2> $O/ab.err; echo "ab rc=$?" | tee -a $O/rc.txt
 # 2b. can the GEMM route go faster with PyTorch's TunableOp picking the hipBLASLt/rocBLAS solution per shape?
 ( timeout 60 python scripts/conv1x1_table.py ) > $O/conv1x1_default.jsonl 2> $O/c1.err; echo "table rc=$?" | tee -a $O/rc.txt
