@@ -21,11 +21,14 @@ def main():
         res = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp)
     if res.returncode != 0:
         sys.exit(res.stderr)
-    try:
-        names = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(
-            re.findall(r"Function Name: (\S+)", res.stderr)), capture_output=True, text=True).stdout.splitlines()
-    except OSError:
-        names = re.findall(r"Function Name: (\S+)", res.stderr)
+    names = re.findall(r"Function Name: (\S+)", res.stderr)
+    for filt in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "c++filt"):
+        try:
+            names = subprocess.run([filt], input="\n".join(names), capture_output=True, text=True,
+                                   check=True).stdout.splitlines()
+            break
+        except (OSError, subprocess.CalledProcessError):
+            continue
     blocks = re.split(r"remark: [^\n]*Function Name: ", res.stderr)[1:]
     print("# %s" % " ".join(cmd[1:-4]))
     print("%-58s %5s %5s %5s %8s %10s %9s" % ("kernel", "SGPR", "VGPR", "AGPR", "scratch", "waves/SIMD", "LDS B/WG"))
@@ -34,7 +37,7 @@ def main():
             m = re.search(k + r": (\d+)", b)
             return int(m.group(1)) if m else -1
         short = re.sub(r"\(anonymous namespace\)::", "", name)
-        short = re.sub(r"\(.*", "", short).replace("void ", "")
+        short = re.sub(r"\((?!anonymous).*", "", short).replace("void ", "")
         print("%-58s %5d %5d %5d %8d %10d %9d" % (short[:58], g("SGPRs"), g("VGPRs"), g("AGPRs"),
                                                   g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]"),
                                                   g(r"LDS Size \[bytes/block\]")))
