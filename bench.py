@@ -64,9 +64,10 @@ def parse():
                     help="1: torch.backends.cudnn.benchmark=True (MIOpen exhaustive find: minutes on a fresh box); "
                          "0: MIOpen immediate mode")
     ap.add_argument("--no-fused-gn", action="store_true", help="eager GroupNorm+ReLU instead of dp_gn_relu_*")
-    ap.add_argument("--conv1x1", default="auto", choices=["auto", "gemm", "miopen"],
-                    help="library route of the backbone's frozen 1x1/1 convolutions: measured per shape (auto), "
-                         "always the batched GEMM, or always MIOpen (dorpatch_amd/conv1x1.py)")
+    ap.add_argument("--conv1x1", default="table", choices=["table", "auto", "gemm", "miopen"],
+                    help="library route of the backbone's frozen 1x1/1 convolutions: the committed per-shape gfx950 "
+                         "table (deterministic, default), measured per shape at first use (auto), always the batched "
+                         "GEMM, or always MIOpen (dorpatch_amd/conv1x1.py)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for functional "
                                                        "multi-rank tests on a single GPU)")
     ap.add_argument("--same-device", action="store_true",

@@ -24,9 +24,10 @@ Differences from the reference, all deliberate and documented in DESIGN.md:
 * backbone parameters are frozen while ``generate`` runs (the reference wastes a
   third of the backward on weight gradients it never reads);
 * one device->host synchronisation per step instead of >= 8;
-* EOT samples shard across ranks (``process_group``) with one all-reduce of the
-  (B,3,H,W) patch gradient per step — the reference's only multi-GPU mechanism is
-  ``nn.DataParallel`` (``main.py:53``);
+* EOT samples shard across ranks (``process_group``) with ONE all-reduce per step: the
+  (B,3,H,W) patch gradient with every rank's loss / prediction columns riding in its tail
+  (``HotLoop._comm``) — the reference's only multi-GPU mechanism is ``nn.DataParallel``
+  (``main.py:53``);
 * two latent reference bugs on the untargeted path (``set_target`` called with a
   missing argument, ``attack.py:155, 359``) are implemented as evidently intended.
 """
@@ -163,7 +164,7 @@ class DorPatch(object):
     each hold a replica and process 1/world of the S sampled masks; ``verbose``.
     """
 
-    def __init__(self, micro_batch=256, process_group=None, verbose=True):
+    def __init__(self, micro_batch=512, process_group=None, verbose=True):
         self.micro_batch = int(micro_batch)
         self.pg = process_group
         self.verbose = verbose
@@ -230,15 +231,34 @@ class DorPatch(object):
     # ------------------------------------------------------------------ attack.py:384-406
     def collect_failure(self, adv_x, y, mask_set_universe, targeted, model, batch_size=128,
                         transforms=None):
-        """Forward-only sweep of every mask of the universe; returns, per image, the
-        ascending list of mask indices on which the attack fails.  ``mask_set_universe``
-        is a device rectangle table (see ``masks.py``); for a single image the return
-        value is the flat list the reference returns."""
-        net, norm = _unwrap_model(model)
-        lists = _collect_failure(net, norm, adv_x.detach().contiguous().float(), y, mask_set_universe,
+        """Forward-only sweep of every mask of the universe (``attack.py:384-406``); returns the
+        ascending list of mask indices on which the attack fails — for B > 1 images the union over
+        the images, like the reference (``failed_idx.unique()``, ``attack.py:403``).
+
+        ``mask_set_universe`` is a device rectangle table (``masks.universe_rects`` /
+        ``MaskWindow(...).rects``): the reference's (n,1,H,W) bool tensor is rejected with a
+        TypeError (masks are never materialised on this path).  ``y`` may be (B,) or the
+        reference's expanded (B*sampling_size,) labels (``attack.py:98, 399``).  ``transforms``
+        (``attack.py:395-396``), if given, is applied to the occluded images in [0,1] right before
+        ``model``, exactly where the reference applies it."""
+        ops.require_gpu(adv_x, "DorPatch.collect_failure (`adv_x`)")
+        table = mask_set_universe
+        if not (isinstance(table, torch.Tensor) and table.dtype == torch.int32 and table.dim() == 3
+                and table.shape[2] == 4):
+            raise TypeError("collect_failure needs the mask universe as an (n, R, 4) int32 rectangle table "
+                            "(dorpatch_amd.masks.universe_rects(H, dropout) / MaskWindow(...).rects uploaded with "
+                            "ops.upload_table), not the reference's (n,1,H,W) bool tensor")
+        B = adv_x.shape[0]
+        y_img = y.detach().to(adv_x.device).long().reshape(B, -1)[:, 0].contiguous()
+        if transforms is None:
+            net, norm = _unwrap_model(model)
+        else:                      # the hook sees un-normalised occluded images, then the model as the caller built it
+            net, norm = (lambda t: model(transforms(t))), None
+        lists = _collect_failure(net, norm, adv_x.detach().contiguous().float(), y_img, table,
                                  targeted, batch_size, pg=self.pg)
-        self._log(">> %d failures collected!" % sum(len(l) for l in lists))
-        return lists[0] if len(lists) == 1 else lists
+        union = sorted(set().union(*[set(l) for l in lists]))
+        self._log(">> %d failures collected!" % len(union))
+        return union
 
 
 # ======================================================================================
@@ -343,6 +363,7 @@ class HotLoop(object):
         if y is None:                                                  # attack.py:67-69
             with torch.no_grad():
                 y = ops.argmax(self._forward_plain(self.x)).long()
+            dp_dist.broadcast_(y, owner.pg)      # a near-tie argmax must not differ between replicas
         y = y.detach().to(dev).long().view(-1)
         assert y.numel() == B
         self.y = y.contiguous()
@@ -359,27 +380,48 @@ class HotLoop(object):
 
         y_host = self.y.cpu().numpy()
         self.img = [_ImageState(lr, structured, 1e-5, targeted, y_host[b]) for b in range(B)]  # :87
+        # Mask draws (attack.py:193-204) happen on EVERY rank from the same generator state, so the ranks
+        # sample identical indices without exchanging them: the state is synchronised from rank 0 once,
+        # here; afterwards the inputs of every draw (failure lists, step number) are themselves identical
+        # on all ranks.  A per-step checksum rides in the step's all-reduce and is verified on the host.
+        # User-supplied `rngs` must already be identical on every rank.
         rngs = extras.get("rngs")
         if rngs is None:
             if B == 1:
+                if self.world > 1:
+                    np.random.set_state(dp_dist.broadcast_object(np.random.get_state(), owner.pg))
                 rngs = [np.random]          # the reference's global legacy stream, bit for bit
             else:
-                seeds = np.random.randint(0, 2 ** 31 - 1, size=B)
+                seeds = dp_dist.broadcast_object(np.random.randint(0, 2 ** 31 - 1, size=B), owner.pg)
                 rngs = [np.random.RandomState(int(s)) for s in seeds]
         self.rngs = list(rngs)
         self.idx_np = np.zeros((B, self.S), dtype=np.int64)
         self.idx2_np = np.zeros((B, self.S), dtype=np.int64) if self.dual else None
         self.n_fail = [0] * B
 
-        # device scratch reused every step
-        # [loss_adv (B*S_local) | loss_struc (B) | group_lasso (B) | density (B)]: one D2H per step
-        self.stats = torch.zeros((B * self.S_local + 3 * B,), dtype=torch.float32, device=dev)
-        self.g_adv = torch.zeros((B, 3, H, W), dtype=torch.float32, device=dev)
-        self.pred = torch.zeros((B * self.S_local,), dtype=torch.int32, device=dev)
+        # Device scratch reused every step.  ONE buffer carries everything that leaves the step:
+        #   [ g_adv (B*3*H*W) | per rank: loss_adv slab (B*S_local), pred slab (B*S_local), draw checksum (1) |
+        #     loss_struc (B), group_lasso (B), density (B) ]
+        # With N > 1 ranks the first two regions are all-reduced (SUM) in one call: every rank fills only its
+        # own slab (the others are zero, x + 0 == x exactly), so the sum IS the gather of the loss / prediction
+        # columns — one collective per step, the patch-gradient all-reduce.  Everything after
+        # g_adv goes to the host in one copy: the step's only device->host synchronisation.
+        n_g, n_slab = B * 3 * H * W, B * self.S_local
+        self._n_g, self._n_slab = n_g, n_slab
+        self._n_tail = self.world * (2 * n_slab + 1)
+        self._comm = torch.zeros((n_g + self._n_tail + 3 * B,), dtype=torch.float32, device=dev)
+        self.g_adv = self._comm[:n_g].view(B, 3, H, W)
+        self._tail = self._comm[n_g:n_g + self._n_tail].view(self.world, 2 * n_slab + 1)
+        own = self._tail[self.rank]
+        self._own_loss, self._own_pred, self._own_chk = own[:n_slab], own[n_slab:2 * n_slab], own[2 * n_slab:]
+        self._reg = self._comm[n_g + self._n_tail:]                       # loss_struc | group_lasso | density
+        self.pred = torch.zeros((n_slab,), dtype=torch.int32, device=dev)
+        self.pred_host = np.zeros((B, self.S), dtype=np.int64)           # argmax of the last step's logits, all ranks' columns
         self.adv_x = torch.empty_like(self.x)
         self.stage = 0
         self.samples_done = 0
         self.kernel_events = None
+        self._conv_shared = False
 
     # ---------------------------------------------------------------- plumbing
     def close(self):
@@ -438,7 +480,8 @@ class HotLoop(object):
             for s in self.img:
                 s.reset_stage()
             mpath = os.path.join(dir_0, "adv_mask_%d.pt" % self.batch_id)
-            if stage == 0 and os.path.exists(mpath):                   # attack.py:134-141
+            # every rank follows rank 0's view of the cache (skipping stage 0 on one rank only would deadlock)
+            if stage == 0 and dp_dist.broadcast_object(os.path.exists(mpath), o.pg):   # attack.py:134-141
                 self.best_mask = torch.load(mpath, map_location=self.dev).float().contiguous()
                 self.best_pattern = torch.load(os.path.join(dir_0, "adv_pattern_%d.pt" % self.batch_id),
                                                map_location=self.dev).float().contiguous()
@@ -458,7 +501,7 @@ class HotLoop(object):
         with torch.no_grad():
             adv_x, _, _ = ops.blend(self.best_mask, self.best_pattern, self.x, self.eps)   # :148-149
             if not all(self._flags("flag_targeted")):                  # :151-155 (set_target(preds_adv, y))
-                preds = ops.argmax(self._forward_plain(adv_x)).cpu().numpy()
+                preds = dp_dist.broadcast_(ops.argmax(self._forward_plain(adv_x)), self.o.pg).cpu().numpy()
                 for b, st in enumerate(self.img):
                     if not st.flag_targeted:
                         st.flag_targeted = True
@@ -477,19 +520,23 @@ class HotLoop(object):
                 self.best_mask[b] = self.adv_mask[b]
                 self.best_pattern[b] = self.adv_pattern[b]
         if stage == 0:
-            if self.rank == 0:                                         # :351-356 stage-0 cache
-                os.makedirs(dir_0, exist_ok=True)
-                torch.save(self.best_mask, os.path.join(dir_0, "adv_mask_%d.pt" % self.batch_id))
-                torch.save(self.best_pattern, os.path.join(dir_0, "adv_pattern_%d.pt" % self.batch_id))
+            if self.rank == 0:                                         # :351-356 stage-0 cache (pattern first:
+                os.makedirs(dir_0, exist_ok=True)                      # the mask file's presence means "complete")
+                for name, t in (("adv_pattern_%d.pt", self.best_pattern), ("adv_mask_%d.pt", self.best_mask)):
+                    path = os.path.join(dir_0, name % self.batch_id)
+                    torch.save(t, path + ".tmp")
+                    os.replace(path + ".tmp", path)
             if not all(self._flags("flag_targeted")) and last_i >= 0:  # :357-359 (set_target(preds_adv, y))
-                preds = self._gather_pred().reshape(self.B, self.S)
+                preds = self.pred_host
                 for b, st in enumerate(self.img):
                     if not st.flag_targeted:
                         self._set_target(b, preds[b])
                 self._sync_labels()
 
     def _gather_pred(self):
-        return dp_dist.gather_columns(self.pred.view(self.B, self.S_local), self.o.pg).cpu().numpy()
+        """(B, S) argmax of the last step's logits over all ranks' samples.  A host array that arrived with the
+        step's statistics: no collective, so callers need not be rank-symmetric."""
+        return self.pred_host
 
     # ---------------------------------------------------------------- one optimisation step
     def _refresh_failures(self):
@@ -521,7 +568,7 @@ class HotLoop(object):
 
         # --- attack.py:169-182: untargeted -> targeted switch
         if stage == 0 and i == self.switch_iteration and not all(self._flags("flag_targeted")):
-            preds = self._gather_pred().reshape(B, S)
+            preds = self.pred_host
             for b, st in enumerate(self.img):
                 if st.flag_targeted:
                     continue
@@ -538,34 +585,33 @@ class HotLoop(object):
             self._refresh_failures()
 
         # --- a-3: mask sampling on the host (same RNG calls as the reference)
+        # (every rank draws the full (B, S) index set from identical generator state and keeps its own S-slice)
         self._draw(i)
-        idx = torch.as_tensor(self.idx_np, dtype=torch.int32, device=dev)
-        idx2 = torch.as_tensor(self.idx2_np, dtype=torch.int32, device=dev) if self.dual else None
-        if self.world > 1:      # every rank occludes with rank 0's draw, then keeps its own S-slice
-            idx_full = dp_dist.broadcast_(idx, o.pg)
-            if self.rank != 0:
-                self.idx_np = idx_full.cpu().numpy().astype(np.int64)
-            idx = idx_full[:, self.s_lo:self.s_hi].contiguous()
-            if self.dual:
-                idx2 = dp_dist.broadcast_(idx2, o.pg)[:, self.s_lo:self.s_hi].contiguous()
+        idx = self._dev_i32(self.idx_np[:, self.s_lo:self.s_hi])
+        idx2 = self._dev_i32(self.idx2_np[:, self.s_lo:self.s_hi]) if self.dual else None
 
         structured_pre = [st.structured for st in self.img]
         coeff_pre = [st.coeff_group_lasso for st in self.img]
         crit_flags = self._dev_i32(self._flags("crit_targeted"))
 
-        # --- a-5 / a-6 forward terms
-        n_adv = B * Sl
-        loss_adv = self.stats[:n_adv].view(B, Sl)
-        ops.struct_loss(self.adv_x, self.lv_x, out=self.stats[n_adv:n_adv + B])
+        # --- a-5 / a-6 forward terms (identical on every rank: same inputs, fixed-order reductions)
+        if self.world > 1:
+            self._tail.zero_()          # the other ranks' slabs must be 0 going into the SUM
+            self._own_chk.fill_(self._draw_checksum())
+        ops.struct_loss(self.adv_x, self.lv_x, out=self._reg[:B])
         cell = wsum = None
         if stage == 0:
             cell, wsum, _, _ = ops.mask_stats(self.adv_mask, self.unit, self.win,
-                                              gl_out=self.stats[n_adv + B:n_adv + 2 * B],
-                                              dens_out=self.stats[n_adv + 2 * B:n_adv + 3 * B])
+                                              gl_out=self._reg[B:2 * B], dens_out=self._reg[2 * B:3 * B])
 
         # --- a-4, a-8, a-7: occlude -> frozen backbone fwd/bwd -> CW loss, in micro-batches
-        self._eot_forward_backward(idx, idx2, crit_flags, loss_adv)
-        dp_dist.allreduce_sum_(self.g_adv, o.pg)   # 602 112 B per image @224: the only data-path collective
+        self._eot_forward_backward(idx, idx2, crit_flags)
+        if self.world > 1 and not self._conv_shared:    # conv1x1 "auto" only: every replica adopts rank 0's routes
+            from . import conv1x1
+            conv1x1.share_choices(o.pg)
+            self._conv_shared = True
+        # THE collective of the step: patch gradient (602 112 B per image @224) + the loss / prediction slabs
+        dp_dist.allreduce_sum_(self._comm[:self._n_g + self._n_tail], o.pg)
 
         # --- the one device->host sync of the step
         loss_adv_np, loss_struc_np, gl_np, dens_np = self._gather_stats()
@@ -587,8 +633,8 @@ class HotLoop(object):
             else:
                 lr_now[b] = st.lr_current
 
-        if i % self.log_every == 0 and o.verbose and self.rank == 0:   # attack.py:318-330
-            preds = self._gather_pred().reshape(B, S)
+        if i % self.log_every == 0 and o.verbose and self.rank == 0:   # attack.py:318-330 (host data only: no collective)
+            preds = self.pred_host
             y_host = np.array([s.y for s in self.img]).reshape(B, 1)
             acc = float((preds == y_host).mean()) * 100
             total = loss_adv_np.mean(1) + np.asarray(structured_pre, dtype=np.float32) * loss_struc_np
@@ -624,20 +670,27 @@ class HotLoop(object):
         self.samples_done += B * S
         return any(st.active for st in self.img)
 
-    def _gather_stats(self):
-        """Host copies of loss_adv (B,S) over all ranks' samples, loss_struc, group lasso, density (B,)."""
-        B, Sl = self.B, self.S_local
-        n_adv = B * Sl
-        if self.world == 1:
-            host = self.stats.cpu().numpy()            # THE device->host sync of the step
-            loss_adv = host[:n_adv].reshape(B, Sl)
-        else:
-            loss_adv = dp_dist.gather_columns(self.stats[:n_adv].view(B, Sl), self.o.pg).cpu().numpy()
-            host = self.stats.cpu().numpy()
-        return (loss_adv, host[n_adv:n_adv + B], host[n_adv + B:n_adv + 2 * B],
-                host[n_adv + 2 * B:n_adv + 3 * B])
+    def _draw_checksum(self):
+        """A float-exact fingerprint of this step's draw; all ranks must agree (verified in _gather_stats)."""
+        w = np.arange(1, self.S + 1, dtype=np.int64)
+        return float(int((self.idx_np * w).sum()) % 8388593)      # < 2^23: exact in fp32
 
-    def _eot_forward_backward(self, idx, idx2, crit_flags, loss_adv_out):
+    def _gather_stats(self):
+        """Host copies of loss_adv (B,S) over all ranks' samples, loss_struc, group lasso, density (B,);
+        also refreshes ``pred_host``.  One device->host copy: THE synchronisation of the step."""
+        B, Sl, world, n_slab = self.B, self.S_local, self.world, self._n_slab
+        host = self._comm[self._n_g:].cpu().numpy()
+        tail = host[:self._n_tail].reshape(world, 2 * n_slab + 1)
+        loss_adv = tail[:, :n_slab].reshape(world, B, Sl).transpose(1, 0, 2).reshape(B, world * Sl)
+        self.pred_host = tail[:, n_slab:2 * n_slab].reshape(world, B, Sl).transpose(1, 0, 2) \
+            .reshape(B, world * Sl).astype(np.int64)
+        if world > 1 and not (tail[:, -1] == tail[self.rank, -1]).all():
+            raise RuntimeError("EOT-sample sharding: the ranks drew different mask indices (checksums %s); every rank "
+                               "must enter generate() with identical RNG state / `rngs`" % tail[:, -1].tolist())
+        reg = host[self._n_tail:]
+        return loss_adv, reg[:B], reg[B:2 * B], reg[2 * B:3 * B]
+
+    def _eot_forward_backward(self, idx, idx2, crit_flags):
         """Occlude (dp_apply_fwd), run the frozen backbone forward + input-gradient backward,
         CW loss (dp_cw_loss) and reduce the input gradients over the samples (dp_apply_bwd).
         Micro-batched over whole images (or over S when one image's samples exceed the
@@ -650,7 +703,7 @@ class HotLoop(object):
             timer = ops.KernelTimer()
             self.kernel_events.append(timer)
         inp_all = ops.apply_fwd(self.adv_x, self.table, idx, idx2, self.dn, timer=timer)   # (B*Sl,3,H,W)
-        loss_flat = torch.empty((B * Sl,), dtype=torch.float32, device=self.dev)
+        loss_flat = self._own_loss                 # this rank's (B, S_local) slab of the step's all-reduce buffer
         if Sl <= mb:
             ipm = max(1, mb // Sl)                 # whole images per micro-batch
             for b0 in range(0, B, ipm):
@@ -669,7 +722,7 @@ class HotLoop(object):
                     ops.apply_bwd(G, self.table, idx[b:b + 1, s0:s1].contiguous(),
                                   None if idx2 is None else idx2[b:b + 1, s0:s1].contiguous(),
                                   self.dn, B=1, out=self.g_adv[b:b + 1], accumulate=(k > 0))
-        loss_adv_out.copy_(loss_flat.view(B, Sl))
+        self._own_pred.copy_(self.pred)            # int32 -> fp32 (class ids are exact), rides in the same buffer
 
     def _fb_chunk(self, inp, y, flags, S_chunk, upstream, loss_out, pred_out):
         inp = inp.detach().requires_grad_(True)

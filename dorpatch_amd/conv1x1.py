@@ -1,4 +1,4 @@
-"""Frozen 1x1 convolutions of the backbone: which LIBRARY kernel runs them, decided by measurement.
+"""Frozen 1x1 convolutions of the backbone: which LIBRARY kernel runs them.
 
 ``north_star`` leaves the backbone's MFMA work to rocBLAS / MIOpen; this module only chooses between
 the two for the 33 stride-1 1x1 convolutions of ResNetV2-50 (reference call sites ``attack.py:222,
@@ -12,30 +12,46 @@ stride-1 1x1 convolution IS a strided-batched GEMM on the tensors as they lie in
     input gradient dx[n]  (C x HW) = W^T (C x O) @ dy[n] (O x HW)
 
 (``torch.bmm`` with a stride-0 batch of the weight -> rocBLAS/hipBLASLt, fp32 MFMA, no copies).
-Neither is always faster, so each (direction, N, C, O, HW) is timed once with both at first use
-(1 warm-up + ``CAL_ITERS`` launches each, HIP events) and the winner is cached for the process:
-MIOpen's own find mode, extended by one candidate it does not have.  ``MODE``: ``"auto"`` (default),
-``"gemm"``, ``"miopen"`` (the plain ``F.conv2d`` path, bypassing this module); the environment variable
-``DORPATCH_CONV1X1`` sets it at import.  A measured choice can differ between runs when two routes tie,
-which changes fp32 summation order only (like the reference's ``cudnn.benchmark = True``,
-``utils.py:17``); pin a mode for run-to-run bit reproducibility.
+Neither route is always faster (``profiles/r01d_conv1x1_table_n512.jsonl``).
+
+``MODE`` (environment variable ``DORPATCH_CONV1X1`` at import):
+
+``"table"`` (default)  the committed per-(gfx950, direction, C, O, HW) table ``conv1x1_gfx950.json``,
+                       measured once on an MI355X; shapes it does not list go to MIOpen.  Deterministic:
+                       every process, every rank and every run executes the same kernels in the same
+                       order, so two runs give bit-identical gradients (the optimiser takes ``sign(grad)``:
+                       reproducibility outranks the last per cent).
+``"auto"``             opt-in: time both routes at first use of each (direction, N, C, O, HW) and keep the
+                       faster (MIOpen's find mode extended by one candidate).  A tie can flip between
+                       runs, which changes the fp32 summation order (like the reference's
+                       ``cudnn.benchmark = True``, ``utils.py:17``).  Under a process group call
+                       ``share_choices(pg)`` after the warm-up so every rank runs rank 0's choices
+                       (``HotLoop`` does).
+``"gemm"`` / ``"miopen"``  force one route (``"miopen"`` = the plain ``F.conv2d`` path).
 
 Weights are frozen on this path (``DorPatch.generate`` freezes the backbone): there is no weight
 gradient.
 """
+import json
+import os
 import time
 
 import torch
 import torch.nn.functional as F
 
-import os
-
-MODE = os.environ.get("DORPATCH_CONV1X1", "auto")     # "auto" | "gemm" | "miopen"
-if MODE not in ("auto", "gemm", "miopen"):
-    raise ValueError("DORPATCH_CONV1X1 must be auto, gemm or miopen, got %r" % MODE)
+MODES = ("table", "auto", "gemm", "miopen")
+MODE = os.environ.get("DORPATCH_CONV1X1", "table")
+if MODE not in MODES:
+    raise ValueError("DORPATCH_CONV1X1 must be one of %s, got %r" % (", ".join(MODES), MODE))
 CAL_ITERS = 3
-_choice = {}          # (direction, N, C, O, HW, device) -> "gemm" | "miopen"
+_choice = {}          # auto mode: (direction, N, C, O, HW) -> "gemm" | "miopen"
 _timings = {}         # same key -> (gemm_ms, miopen_ms)
+_frozen = False       # auto mode: no further calibration (unknown shapes fall back to the table)
+_used = {}            # (direction, route) -> number of distinct shapes routed (report())
+
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv1x1_gfx950.json")) as _f:
+    TABLE = {tuple([k.split(":")[0]] + [int(v) for v in k.split(":")[1:]]): v
+             for k, v in json.load(_f)["choices"].items()}
 
 
 def _fwd_gemm(x, w4d, _=None):
@@ -81,25 +97,36 @@ def _time_ms(fn, t, w4d, x):
     return (time.perf_counter() - t0) * 1e3 / CAL_ITERS
 
 
+def _from_table(direction, C, O, HW):
+    return TABLE.get((direction, C, O, HW), "miopen")
+
+
 def _pick(direction, t, w4d, x):
-    if MODE in ("gemm", "miopen"):
-        return MODE
     O, C = w4d.shape[0], w4d.shape[1]
-    key = (direction, t.shape[0], C, O, t.shape[2] * t.shape[3], str(t.device))
-    algo = _choice.get(key)
-    if algo is None:
-        with torch.no_grad():
-            ms_lib = _time_ms(_IMPL[(direction, "miopen")], t, w4d, x)
-            try:        # the GEMM route is the optional candidate: any refusal or disagreement keeps MIOpen
-                ms_gemm = _time_ms(_IMPL[(direction, "gemm")], t, w4d, x)
-                a, b = _IMPL[(direction, "gemm")](t, w4d, x), _IMPL[(direction, "miopen")](t, w4d, x)
-                tol = 1e-3 * float(b.abs().max()) + 1e-30
-                if not bool(((a - b).abs() <= tol).all()):
+    HW = t.shape[2] * t.shape[3]
+    if MODE in ("gemm", "miopen"):
+        algo = MODE
+    elif MODE == "table":
+        algo = _from_table(direction, C, O, HW)
+    else:
+        key = (direction, t.shape[0], C, O, HW)
+        algo = _choice.get(key)
+        if algo is None and _frozen:
+            algo = _from_table(direction, C, O, HW)
+        elif algo is None:
+            with torch.no_grad():
+                ms_lib = _time_ms(_IMPL[(direction, "miopen")], t, w4d, x)
+                try:        # the GEMM route is the optional candidate: any refusal or disagreement keeps MIOpen
+                    ms_gemm = _time_ms(_IMPL[(direction, "gemm")], t, w4d, x)
+                    a, b = _IMPL[(direction, "gemm")](t, w4d, x), _IMPL[(direction, "miopen")](t, w4d, x)
+                    tol = 1e-3 * float(b.abs().max()) + 1e-30
+                    if not bool(((a - b).abs() <= tol).all()):
+                        ms_gemm = float("inf")
+                except RuntimeError:
                     ms_gemm = float("inf")
-            except RuntimeError:
-                ms_gemm = float("inf")
-        algo = "gemm" if ms_gemm < ms_lib else "miopen"
-        _choice[key], _timings[key] = algo, (ms_gemm, ms_lib)
+            algo = "gemm" if ms_gemm < ms_lib else "miopen"
+            _choice[key], _timings[key] = algo, (ms_gemm, ms_lib)
+    _used.setdefault((direction, t.shape[0], C, O, HW), algo)
     return algo
 
 
@@ -130,19 +157,39 @@ def applicable(conv, x):
             and x.is_contiguous())
 
 
+def share_choices(pg):
+    """auto mode under a process group: every rank adopts rank 0's calibrated choices and stops calibrating,
+    so all replicas run the same kernels (shapes rank 0 has not seen fall back to the table)."""
+    global _frozen
+    if MODE != "auto" or pg is None:
+        return
+    from . import dist as dp_dist
+    mine = dict(_choice)
+    theirs = dp_dist.broadcast_object(mine, pg)
+    _choice.clear()
+    _choice.update(theirs)
+    _frozen = True
+
+
 def report():
-    """{"fwd": {"gemm": n, "miopen": m}, "bwd": {...}, "saved_ms": ...} over the shapes calibrated so far."""
+    """{"fwd": {"gemm": n, "miopen": m}, "bwd": {...}} over the distinct shapes routed so far (+ what the
+    calibration measured, in auto mode)."""
     out = {"fwd": {"gemm": 0, "miopen": 0}, "bwd": {"gemm": 0, "miopen": 0}}
-    saved = 0.0
-    for key, algo in _choice.items():
+    for key, algo in _used.items():
         out[key[0]][algo] += 1
-        g, m = _timings[key]
-        if g < m:
-            saved += m - g
-    out["gemm_faster_by_ms_per_call_sum"] = round(saved, 3)
+    if MODE == "auto":
+        saved = 0.0
+        for key in _choice:
+            g, m = _timings.get(key, (0.0, 0.0))
+            if g < m:
+                saved += m - g
+        out["gemm_faster_by_ms_per_call_sum"] = round(saved, 3)
     return out
 
 
 def reset():
+    global _frozen
     _choice.clear()
     _timings.clear()
+    _used.clear()
+    _frozen = False

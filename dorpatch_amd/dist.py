@@ -1,13 +1,16 @@
 """EOT-sample sharding across ranks.
 
 One process per GPU, a permanent frozen backbone replica per rank.  Every rank
-holds the full (small) optimiser state and the same sampled mask indices; rank
-``r`` pushes samples ``[r*S/world, (r+1)*S/world)`` of every image through the
-backbone.  Per step there is exactly one data-path collective — an
-``all_reduce(SUM)`` of the (B,3,H,W) fp32 patch gradient (602 112 B per image at
-224²) over RCCL/xGMI — plus an ``all_gather`` of the tiny per-sample loss slab
-for the bookkeeping.  The functions below are backend-agnostic (``nccl`` = RCCL
-on ROCm, ``gloo`` in the CPU tests).
+holds the full (small) optimiser state and draws the same mask indices from
+identical generator state (synchronised once, at ``HotLoop`` construction);
+rank ``r`` pushes samples ``[r*S/world, (r+1)*S/world)`` of every image through
+the backbone.  Per step there is exactly ONE collective — an ``all_reduce(SUM)``
+over RCCL/xGMI of the (B,3,H,W) fp32 patch gradient (602 112 B per image at
+224²) with every rank's (B, S/world) loss / prediction columns and a draw
+checksum riding in zero-padded slots behind it (x + 0 == x: the sum is the
+gather).  Every 100 steps the failure sweep adds a MAX-reduce of a (B, 2520)
+bitmap.  The functions below are backend-agnostic (``nccl`` = RCCL on ROCm,
+``gloo`` in the CPU tests).
 """
 import numpy as np
 import torch
@@ -46,8 +49,18 @@ def broadcast_(t, pg):
     return t
 
 
+def broadcast_object(obj, pg):
+    """Rank 0's picklable ``obj`` on every rank (setup only: RNG state / seeds)."""
+    if pg is None:
+        return obj
+    import torch.distributed as dist
+    box = [obj]
+    dist.broadcast_object_list(box, src=src_rank(pg), group=pg)
+    return box[0]
+
+
 def allreduce_sum_(t, pg):
-    """In-place sum over ranks of the patch gradient — THE data-path collective."""
+    """In-place sum over ranks of the patch gradient (+ loss slabs) — THE data-path collective."""
     if pg is not None:
         import torch.distributed as dist
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=pg)
@@ -59,14 +72,3 @@ def allreduce_max_(t, pg):
         import torch.distributed as dist
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=pg)
     return t
-
-
-def gather_columns(local, pg):
-    """(B, S_local) per rank -> (B, S) with rank r's columns at [r*S_local, (r+1)*S_local)."""
-    if pg is None:
-        return local
-    import torch.distributed as dist
-    world = dist.get_world_size(pg)
-    parts = [torch.empty_like(local) for _ in range(world)]
-    dist.all_gather(parts, local.contiguous(), group=pg)
-    return torch.cat(parts, dim=1)

@@ -119,6 +119,15 @@ def _load(path, device):
     return torch.load(path, map_location=device)
 
 
+def _atomic_write(path, write):
+    """``write(file_object)`` into a temporary sibling, then rename: a reader (another rank, a resumed run)
+    sees either no file or a complete one, never a torn pickle."""
+    tmp = "%s.tmp.%d" % (path, os.getpid())
+    with open(tmp, "wb") as f:
+        write(f)
+    os.replace(tmp, path)
+
+
 def run(args, model=None, dataloader=None, device=None, process_group=None, n_classes=None):
     """``main(args)`` of the reference (``main.py:47-184``).  ``model`` / ``dataloader`` / ``device``
     default to what the reference builds; tests and ``--synthetic`` inject their own.
@@ -162,6 +171,13 @@ def run(args, model=None, dataloader=None, device=None, process_group=None, n_cl
     defense = [PatchCleanser(MaskWindow(args.img_size, r, 1), model) for r in DEFENSE_RATIOS]   # main.py:61
     owns_files = rank == 0 or not shard_samples       # sample-sharded ranks compute the same tensors: rank 0 writes
 
+    def exists(path):
+        """Resume-or-compute is decided ONCE: sample-sharded ranks follow rank 0's view of the file system (a
+        slower rank must not take the resume branch on a file rank 0 has just written while rank 0 itself
+        computes: the collectives inside generate() would then mismatch)."""
+        found = os.path.exists(path)
+        return bool(dp_dist.broadcast_object(found, process_group)) if shard_samples else found
+
     per_batch = {}                                    # i -> dict of numpy results (gathered over ranks at the end)
     t_attack = t_defense = 0.0
     with torch.no_grad():
@@ -183,7 +199,7 @@ def run(args, model=None, dataloader=None, device=None, process_group=None, n_cl
             mpath = os.path.join(result_dir, "adv_mask_%d.pt" % i)
             ppath = os.path.join(result_dir, "adv_pattern_%d.pt" % i)
             target = None
-            if os.path.exists(mpath):                                          # main.py:102-118
+            if exists(mpath):                                                  # main.py:102-118
                 adv_mask, adv_pattern = _load(mpath, device), _load(ppath, device)
                 if args.targeted:       # recover the target label from stage 0
                     dir_0 = os.path.join(*result_dir.split('/')[:-1])
@@ -207,13 +223,13 @@ def run(args, model=None, dataloader=None, device=None, process_group=None, n_cl
                 if device.type == "cuda":
                     torch.cuda.synchronize()
                 t_attack += time.perf_counter() - t0
-                if owns_files:
-                    torch.save(adv_mask, mpath)                                # main.py:135-138
-                    torch.save(adv_pattern, ppath)
+                if owns_files:                                                 # main.py:135-138
+                    _atomic_write(ppath, lambda f: torch.save(adv_pattern, f))
+                    _atomic_write(mpath, lambda f: torch.save(adv_mask, f))    # the mask last: its presence means "done"
             adv_x = x + U.clip(adv_mask, adv_pattern, x, args.epsilon)         # main.py:140-141
 
             pc_path = os.path.join(result_dir, "adv_PC_%d.pt" % i)             # main.py:143-153
-            if os.path.exists(pc_path):
+            if exists(pc_path):
                 with open(pc_path, 'rb') as f:
                     records_batch = pickle.load(f)
             else:
@@ -222,8 +238,7 @@ def run(args, model=None, dataloader=None, device=None, process_group=None, n_cl
                 records_batch = [[recs[b] for recs in by_defense] for b in range(adv_x.shape[0])]
                 t_defense += time.perf_counter() - t0
                 if owns_files:
-                    with open(pc_path, 'wb') as f:
-                        pickle.dump(records_batch, f)
+                    _atomic_write(pc_path, lambda f: pickle.dump(records_batch, f))
             per_batch[i] = dict(preds=preds.cpu().numpy(), y=y.cpu().numpy(),
                                 preds_adv=model(adv_x).argmax(-1).cpu().numpy(),            # main.py:158-159
                                 target=None if target is None else target.cpu().numpy(), records=records_batch)

@@ -5,10 +5,10 @@ NOT part of the product: only ``tests/``, ``__graft_entry__.smoke()`` and the
 reported CPU baseline.  It restates, with plain ``torch`` CPU ops and autograd
 used exactly the way the reference uses it, what ``/root/reference`` computes on
 the hot path; every function cites the reference lines it follows.  It is pinned
-against the *unmodified* reference (``oracle/ref_shim.py``) by
-``tests/test_oracle_vs_reference.py`` (build container) and against the committed
-``tests/golden/*.npz`` fixtures generated from the reference by
-``oracle/gen_golden.py`` (everywhere).
+against the committed ``tests/golden/*.npz`` fixtures, which ``oracle/gen_golden.py``
+records by executing the *unmodified* reference through ``oracle/ref_shim.py`` in the build
+container (``tests/test_oracle_golden.py``, ``tests/test_patchcleanser_oracle.py``,
+``tests/test_end_metric_golden.py``).
 
 Parity status: pinned for everything below; the timm backbone is opaque to this
 path (any ``nn.Module``) and is unpinned (see oracle/__init__.py).

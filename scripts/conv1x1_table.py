@@ -52,7 +52,7 @@ def main():
         dy = torch.randn(args.n, O, H, H, device=dev)
         for direction, t in (("fwd", x), ("bwd", dy)):
             conv1x1._pick(direction, t, w, x)
-            key = (direction, args.n, C, O, HW, str(dev))
+            key = (direction, args.n, C, O, HW)
             g, m = conv1x1._timings[key]
             flop = 2.0 * args.n * C * O * HW
             print(json.dumps({"dir": direction, "N": args.n, "C": C, "O": O, "HW": HW, "per_forward": mult,

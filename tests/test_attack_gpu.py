@@ -387,8 +387,23 @@ def test_collect_failure_matches_oracle():
         want = R.collect_failure(cpu, adv[b:b + 1], y[b:b + 1], uni, targeted)
         diff = set(lists[b]) ^ set(want)
         assert len(diff) <= 2, (b, len(diff))       # argmax near-ties under fp32 reordering only
-    single = DorPatch(verbose=False).collect_failure(adv[:1].to(DEV), y[:1].to(DEV), table, False, model)
+    atk = DorPatch(verbose=False)
+    single = atk.collect_failure(adv[:1].to(DEV), y[:1].to(DEV), table, False, model)
     assert single == lists[0]
+    # the reference's calling convention (attack.py:98, 187-190): y expanded to B * sampling_size labels
+    assert atk.collect_failure(adv[:1].to(DEV), y[:1].repeat_interleave(128).to(DEV), table, False, model,
+                               batch_size=128) == single
+    # B > 1: the union over the images, ascending (attack.py:403 `.unique()` per chunk)
+    both = _collect_failure(net, norm, adv.to(DEV), y.to(DEV), table, False, 128)
+    assert atk.collect_failure(adv.to(DEV), y.to(DEV), table, False, model) == sorted(set(both[0]) | set(both[1]))
+    # the reference's bool (n,1,H,W) universe is rejected loudly, not mis-read
+    with pytest.raises(TypeError):
+        atk.collect_failure(adv[:1].to(DEV), y[:1].to(DEV), uni.to(DEV), False, model)
+    # `transforms` (attack.py:395-396) is applied to the occluded [0,1] images right before the model
+    dark = lambda t: t * 0.5
+    want_t = R.collect_failure(lambda t: cpu(dark(t)), adv[:1], y[:1], uni, False)
+    got_t = atk.collect_failure(adv[:1].to(DEV), y[:1].to(DEV), table, False, model, transforms=dark)
+    assert len(set(got_t) ^ set(want_t)) <= 2 and got_t != single
 
 
 def test_patchcleanser_matches_reference_records(golden_patchcleanser):

@@ -43,7 +43,7 @@ def test_bench_line_contract(monkeypatch, capsys):
     assert abs(out["value"] - 1 * 2 / (out["ms_per_step"] / 1e3)) <= 0.006 + 1e-3 * out["value"]
     cfg, roof = out["config"], out["roofline"]
     assert cfg["workload"].startswith("custom:") and "model" not in cfg
-    assert cfg["conv1x1"]["mode"] == "auto" and cfg["images"] == 1 and cfg["masks_per_image_per_gpu"] == 2
+    assert cfg["conv1x1"]["mode"] == "table" and cfg["images"] == 1 and cfg["masks_per_image_per_gpu"] == 2
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert roof["algorithmic_bytes_per_launch"] == 1 * 2 * 3 * 32 * 32 * 4
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["traffic"] is None

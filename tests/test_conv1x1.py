@@ -1,5 +1,6 @@
 """dorpatch_amd.conv1x1: both library routes of a frozen 1x1 convolution compute the same thing as
-F.conv2d and its autograd, and "auto" caches one measured choice per (direction, shape)."""
+F.conv2d and its autograd; the default routing is the committed gfx950 table (deterministic), "auto"
+(opt-in) caches one measured choice per (direction, shape)."""
 import numpy as np
 import pytest
 import torch
@@ -17,7 +18,7 @@ def _restore():
     conv1x1.reset()
 
 
-@pytest.mark.parametrize("mode", ["gemm", "miopen", "auto"])
+@pytest.mark.parametrize("mode", ["table", "gemm", "miopen", "auto"])
 @pytest.mark.parametrize("N,C,O,H", [(3, 64, 256, 14), (2, 512, 128, 7), (1, 8, 8, 5)])
 def test_matches_conv2d_and_its_input_gradient(mode, N, C, O, H):
     conv1x1.MODE = mode
@@ -67,3 +68,42 @@ def test_backbone_uses_it_only_for_frozen_folded_1x1_stride1_gpu_tensors():
     assert not conv1x1.applicable(StdConv2d(8, 8, 3, padding=1).requires_grad_(False), Cuda)
     conv1x1.MODE = "miopen"
     assert not conv1x1.applicable(conv, Cuda)
+
+
+def test_default_is_the_committed_table_and_it_is_deterministic():
+    """no timing race decides which kernel runs.  The table lists every stride-1 1x1
+    shape of ResNetV2-50 at 224x224, both directions; anything else goes to MIOpen."""
+    import importlib
+    import os
+    assert os.environ.get("DORPATCH_CONV1X1") is None and importlib.reload(conv1x1).MODE == "table"
+    from scripts.conv1x1_table import shapes
+    want = {(d, C, O, HW) for (C, O, HW) in shapes(224) for d in ("fwd", "bwd")}
+    assert set(conv1x1.TABLE) == want and set(conv1x1.TABLE.values()) <= {"gemm", "miopen"}
+    w = torch.randn(256, 64, 1, 1)
+    x = torch.randn(2, 64, 56, 56)
+    picks = [conv1x1._pick("fwd", x, w, None) for _ in range(3)]
+    assert picks == [conv1x1.TABLE[("fwd", 64, 256, 3136)]] * 3 and not conv1x1._timings      # looked up, never timed
+    assert conv1x1._pick("bwd", torch.randn(2, 24, 5, 5), torch.randn(24, 12, 1, 1), None) == "miopen"
+
+
+def test_share_choices_freezes_auto_mode():
+    """Under a process group every rank adopts rank 0's choices; shapes seen later fall back to the table."""
+    conv1x1.MODE = "auto"
+    conv1x1.share_choices(None)                        # no group: nothing changes
+    assert not conv1x1._frozen
+    w, x = torch.randn(16, 8, 1, 1), torch.randn(2, 8, 6, 6)
+    conv1x1._pick("fwd", x, w, None)
+    assert len(conv1x1._choice) == 1
+
+    class OneRank(object):
+        pass
+    import dorpatch_amd.dist as dp_dist
+    orig = dp_dist.broadcast_object
+    dp_dist.broadcast_object = lambda obj, pg: {("fwd", 2, 8, 16, 36): "gemm"}       # what rank 0 sent
+    try:
+        conv1x1.share_choices(OneRank())
+    finally:
+        dp_dist.broadcast_object = orig
+    assert conv1x1._frozen and conv1x1._pick("fwd", x, w, None) == "gemm"
+    n = len(conv1x1._timings)
+    assert conv1x1._pick("bwd", torch.randn(2, 16, 6, 6), w, x) == "miopen" and len(conv1x1._timings) == n

@@ -3,9 +3,9 @@
 HIP kernels running through the host emulation (tests/hipemu) on CPU tensors.
 
 tests/test_dist_gloo.py checks the sharding arithmetic with the oracle standing in for the kernels;
-here the code under test is exactly what runs per GPU under ``torch.distributed.run`` (rank-0 index
-broadcast, S-slice per rank, ONE all-reduce of the patch gradient, loss-column all-gather, failure
-bitmap MAX-reduce), compared with the same problem on a single rank.
+here the code under test is exactly what runs per GPU under ``torch.distributed.run`` (same-state
+draws on every rank, S-slice per rank, ONE all-reduce carrying the patch gradient + the loss / prediction
+slabs + a draw checksum, failure bitmap MAX-reduce), compared with the same problem on a single rank.
 """
 import importlib.util
 import os
@@ -75,13 +75,13 @@ def _run_loop(pg, rank):
     """N_STEPS steps of the product's HotLoop (step 0 includes the collect_failure sweep)."""
     from dorpatch_amd.attack import DorPatch, HotLoop
     x, m, p, y, rows, net = _problem()
-    if rank != 0:                     # only rank 0's init and draws may matter: poison the others
-        m, p = torch.zeros_like(m), torch.zeros_like(p)
-        rows = [[np.zeros(S, dtype=np.int64) for _ in range(N_STEPS)] for _ in range(B)]
+    if rank != 0:                     # only rank 0's init may matter (broadcast at construction): poison the others.
+        m, p = torch.zeros_like(m), torch.zeros_like(p)      # The draws are NOT exchanged: same `rngs` on every rank.
     seen = []
     hook = lambda d: seen.append(dict(idx=d["idx"].copy(), loss_adv=d["loss_adv"].copy(), g_adv=d["g_adv"].clone(),
                                       grad_mask=d["grad_mask"].clone(), lr=d["lr"].copy()))
-    loop = HotLoop(DorPatch(micro_batch=6, process_group=pg, verbose=False), net, x, 0.12, 10, "t/cfg/sub", 0, y,
+    # verbose=True: the progress line (attack.py:318-330) must not involve a collective only rank 0 enters
+    loop = HotLoop(DorPatch(micro_batch=6, process_group=pg, verbose=True), net, x, 0.12, 10, "t/cfg/sub", 0, y,
                    True, 1e-2, 1e-1, 0, 1, 10 ** 6, 7, 'topk', 1, S, 1e-3, 1e-3, 4.0, False,
                    dict(init_mask=m, init_pattern=p, rngs=[FixedDraw(rows[b]) for b in range(B)], step_hook=hook))
     assert loop.n_mask == N_MASK
@@ -115,7 +115,7 @@ def test_hot_loop_two_ranks_equals_one(tmp_path):
         assert o["failed"] == want["failed"]                       # sharded sweep + MAX-reduce == full sweep
         for k in range(N_STEPS):
             a, w = o["seen"][k], want["seen"][k]
-            assert np.array_equal(a["idx"], w["idx"])                  # rank 0's draw, everywhere
+            assert np.array_equal(a["idx"], w["idx"])                  # the same draw, everywhere
             if k == 0:
                 # identical parameters going in: only the S-summation order differs
                 np.testing.assert_allclose(a["loss_adv"], w["loss_adv"], rtol=1e-5, atol=1e-6)

@@ -4,7 +4,8 @@ The HIP kernels need a GPU, so each rank's per-shard compute is done here by the
 what is under test is the product's sharding/collective layer (`dorpatch_amd.dist`) and the
 arithmetic contract HotLoop relies on: with upstream = 1/S_total, the all-reduced sum of the
 per-shard input gradients equals the unsharded gradient, regularisers are added once after the
-reduce, the gathered loss columns land in sample order, and the failure bitmap OR-reduces."""
+reduce, the loss columns riding in zero-padded slabs of the same all-reduce land in sample order
+bit-exactly, and the failure bitmap OR-reduces."""
 import os
 import socket
 
@@ -57,15 +58,23 @@ def _worker(rank, world, port, out_dir):
         assert dp_dist.world_rank(pg) == (world, rank)
         H, S, B, x, m, p, y, idx, net = _problem()
         adv_x = (R.clip(m, p, x, 4.0) + x).detach()
-        # every rank occludes with rank 0's draw (HotLoop.step broadcasts idx)
-        idx_t = torch.from_numpy(idx.copy() if rank == 0 else np.zeros_like(idx)).int()
-        dp_dist.broadcast_(idx_t, pg)
-        assert np.array_equal(idx_t.numpy(), idx)
+        # every rank draws from rank 0's generator state (HotLoop.__init__ synchronises it once)
+        state = dp_dist.broadcast_object(np.random.RandomState(0 if rank == 0 else 99).get_state(), pg)
+        rs = np.random.RandomState()
+        rs.set_state(state)
+        assert np.array_equal(rs.choice(2520, S, replace=False), idx)
         lo, hi = dp_dist.shard_bounds(S, world, rank)
         keep = R.mask_universe(H, 2)[torch.from_numpy(idx[lo:hi])]
         g_local, loss_local = _shard_grad(net, adv_x, y, keep, S)
-        g = dp_dist.allreduce_sum_(g_local.clone(), pg)              # THE data-path collective
-        loss = dp_dist.gather_columns(loss_local, pg)                # (B, S) in sample order
+        # THE data-path collective (HotLoop._comm): [patch gradient | one zero-padded loss slab per rank];
+        # every rank fills only its own slab, so the SUM is the gather of the loss columns
+        Sl = hi - lo
+        comm = torch.zeros(g_local.numel() + world * B * Sl)
+        comm[:g_local.numel()] = g_local.reshape(-1)
+        comm[g_local.numel():].view(world, B * Sl)[rank] = loss_local.reshape(-1)
+        dp_dist.allreduce_sum_(comm, pg)
+        g = comm[:g_local.numel()].view_as(g_local).clone()
+        loss = comm[g_local.numel():].view(world, B, Sl).permute(1, 0, 2).reshape(B, S).clone()   # sample order
         # failure bitmap: each rank sweeps its slice of the universe, OR-reduce
         n_mask = 2520
         mlo, mhi = dp_dist.mask_bounds(n_mask, world, rank)
@@ -104,4 +113,4 @@ def test_shard_bounds_and_mask_bounds():
     assert sum(b - a for a, b in spans) == 2520
     assert dp_dist.world_rank(None) == (1, 0)
     t = torch.ones(3)
-    assert dp_dist.allreduce_sum_(t, None) is t and dp_dist.gather_columns(t, None) is t
+    assert dp_dist.allreduce_sum_(t, None) is t and dp_dist.broadcast_object({"a": 1}, None) == {"a": 1}
