@@ -15,9 +15,12 @@ ranks the per-GPU work is fixed (weak scaling: S = 32*N masks per image, 32 per 
 exchange one all-reduce of the (64,3,224,224) patch gradient per step (RCCL).
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
-  "roofline":     dp_apply_fwd, algorithmic bytes (602 112 B/sample @224) / HIP-event time, vs 8 TB/s
+  "roofline":     dp_apply_fwd, algorithmic bytes (602 112 B/sample @224) / HIP-event time, vs 8 TB/s;
+                  "traffic" = HBM bytes per launch from rocprofv3 PMC passes run live (a child process
+                  replays the same launch through tools/kbench under `rocprofv3 --pmc`), or null
   "cpu_baseline": the CPU oracle (a port of the reference step) timed on this host's cores on a
-                  bounded sample (1 image x 16 masks per step), N = 1 only.
+                  bounded sample (1 image x 32 masks per step, >= 3 warm-up + >= 5 timed
+                  steps, backbone weights trainable as the reference leaves them AND frozen), N = 1 only.
 """
 import argparse
 import json
@@ -58,6 +61,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0: min(cores, 32))")
     ap.add_argument("--patch-budget", type=float, default=0.0204, help="32x32 px @224 (SURVEY §0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC passes (roofline.traffic = null)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the separately-timed collect_failure sweep")
     ap.add_argument("--stage", type=int, default=0)
     ap.add_argument("--find", type=int, default=0,
@@ -87,62 +91,96 @@ def build_model(device):
     return NormModel(net, get_normalize("imagenet", "resnetv2")).to(device).eval()
 
 
-def cpu_baseline(size, n_masks=16, max_steps=3, budget_s=25.0, threads=None):
-    """The reference step restated on the CPU (oracle/restatement.py), weights left trainable as the
-    reference leaves them, B = 1 (the only batch the reference supports).  Bounded: stops
-    after `max_steps` timed steps or `budget_s` seconds, whichever comes first.  `threads` defaults to
-    min(host cores, 32): oneDNN convolutions at batch 16 do not scale past one CCD-group of a big
-    2-socket host (256 threads measured 0.13 samples/s on a 2x64-core EPYC 9575F)."""
+def cpu_baseline(size, n_masks=32, warm=3, timed=5, budget_s=40.0, threads=None):
+    """the reference step restated on the CPU (oracle/restatement.eot_step), B = 1 (the only
+    batch the reference supports), S = `n_masks` sampled double-masks, `warm` warm-up steps discarded, then
+    `timed` steps, MEDIAN step time; two variants: "as-is" (backbone weights keep requires_grad=True, the
+    reference's real behaviour — it computes and discards their gradients every step) and "frozen".
+    `value` is the as-is figure.  Bounded: a variant stops early once `budget_s` / 2 is spent (never below one
+    timed step; the sample string says what was actually run).  `threads` defaults to min(host cores, 32):
+    oneDNN convolutions at batch 32 do not scale past one CCD-group of a big 2-socket host (256 threads
+    measured 0.13 samples/s on a 2x64-core EPYC 9575F).  profiles/r02_cpu_reference_vs_port.json shows this port
+    and the UNMODIFIED reference (through oracle/ref_shim.py) step at the same rate in the build container."""
     from oracle import restatement as R
     cores = os.cpu_count() or 1
     threads = int(threads or min(cores, 32))
     torch.set_num_threads(threads)
     model = build_model("cpu")
-    for p in model.parameters():
-        p.requires_grad_(True)            # as-is: the reference never freezes the backbone
     g = torch.Generator().manual_seed(1234)
     x = torch.rand(1, 3, size, size, generator=g)
     mask, pattern = torch.rand(1, 1, size, size, generator=g), torch.rand(1, 3, size, size, generator=g)
     y = torch.randint(0, 1000, (1,), generator=g)
     universe = R.mask_universe(size, 2)
-    rng = np.random.RandomState(1234)
     lvx = R.local_variance(x)[0].mean(1)
+    out = {}
+    for variant, trainable in (("as_is", True), ("frozen", False)):
+        for p in model.parameters():
+            p.requires_grad_(trainable)
+        rng = np.random.RandomState(1234)
 
-    def one():
-        keep = universe[torch.from_numpy(rng.choice(universe.shape[0], n_masks, replace=False))]
-        R.eot_step(model, x, mask, pattern, y, keep, stage=0, targeted=True, n_classes=1000, lr=0.01,
-                   local_var_x=lvx)
-        model.zero_grad(set_to_none=True)
-    t0 = time.perf_counter()
-    one()                                  # warm-up (oneDNN primitive creation)
-    t_warm = time.perf_counter() - t0
-    done, t0 = 0, time.perf_counter()
-    while done < max_steps and (time.perf_counter() - t0) + t_warm < budget_s:
-        one()
-        done += 1
-    dt = time.perf_counter() - t0
-    if done == 0:                          # the warm-up alone exhausted the budget: report it
-        done, dt = 1, t_warm
-    return {"value": round(n_masks * done / dt, 3), "unit": "EOT-samples/s", "cores": threads,
-            "host_cores": cores, "kind": "port",
-            "sample": "oracle/restatement.eot_step (reference step, backbone weights trainable as in the "
-                      "reference), B=1 x %d masks x %d steps @%dx%d fp32, %d threads, 1 warm-up step "
-                      "(%.1f s)" % (n_masks, done, size, size, threads, t_warm)}
+        def one():
+            keep = universe[torch.from_numpy(rng.choice(universe.shape[0], n_masks, replace=False))]
+            t0 = time.perf_counter()
+            R.eot_step(model, x, mask, pattern, y, keep, stage=0, targeted=True, n_classes=1000, lr=0.01,
+                       local_var_x=lvx)
+            model.zero_grad(set_to_none=True)
+            return time.perf_counter() - t0
+        t_begin = time.perf_counter()
+        warm_t = [one() for _ in range(warm)]
+        steps = []
+        while len(steps) < timed and (not steps or time.perf_counter() - t_begin < budget_s / 2):
+            steps.append(one())
+        out[variant] = dict(samples_per_s=round(n_masks / float(np.median(steps)), 3), timed_steps=len(steps),
+                            median_step_s=round(float(np.median(steps)), 3), warmup_s=round(sum(warm_t), 2))
+    return {"value": out["as_is"]["samples_per_s"], "unit": "EOT-samples/s", "cores": threads, "host_cores": cores,
+            "kind": "port", "value_frozen": out["frozen"]["samples_per_s"],
+            "sample": "oracle/restatement.eot_step (the reference step, attack.py:184-342), B=1 x %d masks @%dx%d fp32, "
+                      "%d threads, %d warm-up steps discarded, median of %d (as-is: backbone weights trainable as in "
+                      "the reference) / %d (frozen) timed steps; collect_failure sweep excluded"
+                      % (n_masks, size, size, threads, warm, out["as_is"]["timed_steps"], out["frozen"]["timed_steps"]),
+            "detail": out}
 
 
-def pmc_traffic(B, S, H):
-    """HBM bytes per dp_apply_fwd launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
-    --pmc WRITE_SIZE runs of tools/kbench; FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM, WRITE_SIZE
-    verified exact against the fill/copy calibration kernels).  None when no pass matches this geometry."""
-    path = os.path.join(ROOT, "profiles", "pmc_apply_fwd.json")
-    try:
-        with open(path) as f:
-            for rec in json.load(f)["records"]:
-                if (rec["B"], rec["S"], rec["H"]) == (B, S, H):
-                    return rec["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+def pmc_traffic_live(B, S, H, timeout_s=150):
+    """HBM bytes of ONE dp_apply_fwd launch of this run's geometry, measured now: a child process replays
+    the launch (tools/kbench, same kernel, same grid) under `rocprofv3 --pmc WRITE_SIZE` and, in a second
+    pass, `--pmc FETCH_SIZE` (MI355X_MICROARCH.md: the two do not fit one pass).  Corrections per that guide's
+    HBM section: both counters are in KiB; on gfx950 FETCH_SIZE tallies the 128-B requests of a wide coalesced
+    read at 64 B, so it is doubled; WRITE_SIZE is exact (calibrated on fill/copy kernels of known size,
+    profiles/r01b_pmc_kbench_cfg2_raw.json).  -> (bytes or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "tools", "kbench")
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not (os.path.exists(exe) and os.path.exists(rocprof)):
+        return None, "tools/kbench or rocprofv3 missing"
+    kib = {}
+    for ctr in ("WRITE_SIZE", "FETCH_SIZE"):
+        d = tempfile.mkdtemp(prefix="dp_pmc_", dir="/tmp")
+        cmd = [rocprof, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "kb", "--",
+               exe, str(B), str(S), str(H), "2", "dp_apply_fwd (default"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            vals = []
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if "k_apply_fwd" in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
+                            vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, "no %s rows for k_apply_fwd in the rocprofv3 output" % ctr
+            kib[ctr] = float(np.mean(vals))
+        except (subprocess.SubprocessError, OSError, ValueError, KeyError) as e:
+            return None, "%s pass failed: %r" % (ctr, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    total = int(round(kib["WRITE_SIZE"] * 1024 + 2 * kib["FETCH_SIZE"] * 1024))
+    return total, ("rocprofv3 --pmc, separate passes, this run: WRITE_SIZE %.1f KiB + 2 x FETCH_SIZE %.1f KiB per launch "
+                   "(tools/kbench replay of the same launch)" % (kib["WRITE_SIZE"], kib["FETCH_SIZE"]))
 
 
 def note(msg):
@@ -197,8 +235,9 @@ def main():
         clean = torch.cat([model(x[i:i + 64]).argmax(-1) for i in range(0, B, 64)])
     y = (clean + 1 + torch.randint(0, 998, (B,), generator=torch.Generator().manual_seed(7)).to(dev)) % 1000
     owner = DorPatch(micro_batch=args.micro_batch, process_group=pg, verbose=False)
+    # failure_refresh: the every-100-steps collect_failure sweep is timed apart below, never inside the timed steps
     loop = HotLoop(owner, model, x, args.patch_budget, 1000, "bench_out/cfg/sub", 0, y, True, 1e-2, 1e-1,
-                   0, 1, 10 ** 9, 7, 'topk', 2, S, 1e-3, 1e-3, 4.0, False, {})
+                   0, 1, 10 ** 9, 7, 'topk', 2, S, 1e-3, 1e-3, 4.0, False, dict(failure_refresh=10 ** 12))
     loop.stage = args.stage
 
     def barrier():
@@ -211,7 +250,7 @@ def main():
             torch.cuda.synchronize()
 
     note("model + loop ready (B=%d S=%d H=%d world=%d)" % (B, S, H, world))
-    i = 1                                        # i % 100 != 0: the periodic failure sweep is timed apart
+    i = 1
     for _ in range(args.warmup):
         loop.step(i)
         i += 1
@@ -227,6 +266,9 @@ def main():
     note("timed region done: %.3f s for %d steps" % (dt, args.steps))
     events = loop.kernel_events
     loop.kernel_events = None
+    apply_ms = float(np.mean([t.ms() for t in events]))   # kernel-begin -> kernel-end (dp_apply_fwd_timed)
+    for t in events:
+        t.close()
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -246,12 +288,12 @@ def main():
 
     if rank == 0:
         P = H * H
-        apply_ms = float(np.mean([t.ms() for t in events]))   # kernel-begin -> kernel-end (dp_apply_fwd_timed)
-        for t in events:
-            t.close()
         algo_bytes = B * S_local * 3 * P * 4          # 3*P*4 B written per EOT sample
         achieved = algo_bytes / (apply_ms * 1e-3) / 1e9
         value = B * S * args.steps / dt
+        traffic, traffic_note = (None, "skipped (--no-pmc)") if (args.no_pmc or DEVICE_OVERRIDE is not None) \
+            else pmc_traffic_live(B, S_local, H)
+        note("PMC passes done: %s" % traffic_note)
         out = {
             "metric": "EOT-samples/sec", "value": round(value, 2), "unit": "EOT-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -269,7 +311,8 @@ def main():
                        "parallelism": "eot-sample sharding x%d, 1 all-reduce of the patch gradient per step" % world},
             "roofline": {"kernel": "k_apply_fwd (dp_apply_fwd)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(B, S_local, H),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(apply_ms, 4)},
         }
         if dt_sweep is not None:

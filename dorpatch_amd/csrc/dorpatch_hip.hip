@@ -715,63 +715,106 @@ __device__ __forceinline__ int chan_of(int e, float inv_hw) {
   return (int)(((float)e + 0.5f) * inv_hw);
 }
 
-// affine + relu of one float4 whose first element is group-element e
-__device__ __forceinline__ void gn_coeffs(const GnArgs &A, int cbase, int e, bool uniform, float mean,
-                                          float rstd, float a[4], float b[4]) {
+constexpr int kGnLdsCh = 64;  // channels per group whose gamma / beta are staged in LDS (ResNetV2-50: <= 64)
+
+// affine + relu coefficients of one float4 whose first element is group-element e.  ga / be point at the
+// group's gamma / beta: the LDS copy (LC, indexed from 0) or global memory (indexed from cbase).
+__device__ __forceinline__ void gn_coeffs(const float *ga, const float *be, float inv_hw, int e,
+                                          bool uniform, float mean, float rstd, float a[4], float b[4]) {
   if (uniform) {  // HW % 4 == 0: the 4 lanes of a float4 share one channel
-    const int c = cbase + chan_of(e, A.inv_hw);
-    const float aa = rstd * A.gamma[c];
-    const float bb = A.beta[c] - mean * aa;
+    const int c = chan_of(e, inv_hw);
+    const float aa = rstd * ga[c];
+    const float bb = be[c] - mean * aa;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { a[j] = aa; b[j] = bb; }
   } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int c = cbase + chan_of(e + j, A.inv_hw);
-      a[j] = rstd * A.gamma[c];
-      b[j] = A.beta[c] - mean * a[j];
+      const int c = chan_of(e + j, inv_hw);
+      a[j] = rstd * ga[c];
+      b[j] = be[c] - mean * a[j];
     }
   }
 }
 
+template <bool NT>
+__device__ __forceinline__ f4 ld4(const f4 *p) {
+  if (NT) return __builtin_nontemporal_load(p);
+  return *p;
+}
+
+template <bool NT>
+__device__ __forceinline__ void st4(f4 *p, f4 v) {
+  if (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
 // One workgroup per (sample, group); the group (L = Cg*HW floats, L % 4 == 0) lives in
 // registers: V float4 per thread, T threads, V*T*4 >= L.
-template <int V, int T>
-__global__ __launch_bounds__(T) void k_gn_relu_fwd(GnArgs A, float *__restrict__ y,
-                                                   float *__restrict__ mean_out,
-                                                   float *__restrict__ rstd_out) {
+//
+// Memory-level parallelism is the whole game here (the kernels are pure HBM streams with two block
+// reductions in the middle): every load of a phase is issued BEFORE the first use of any of them — no
+// per-element `if (i < L4)` around a load (a branch per element makes the compiler wait for each load
+// before issuing the next: one 1 KiB request in flight per wave).  Out-of-range lanes load element 0
+// (always valid) and are masked out of the sums / skipped by the stores.
+//   NT: non-temporal loads / stores (every tensor here is >> the caches and is next touched by a
+//       different kernel);
+//   LC: the group's gamma / beta are staged in LDS once per workgroup (needs Cg <= kGnLdsCh) instead
+//       of 2 global gathers per float4 in the store phase;
+//   MW: minimum waves per SIMD asked of the register allocator.
+template <int V, int T, bool NT, bool LC, int MW>
+__global__ __launch_bounds__(T, MW) void k_gn_relu_fwd(GnArgs A, float *__restrict__ y,
+                                                       float *__restrict__ mean_out,
+                                                       float *__restrict__ rstd_out) {
   __shared__ float sm1[T / 64], sm2[T / 64];
+  __shared__ float s_gb[LC ? 2 * kGnLdsCh : 2];
   const int ng = blockIdx.x;
   const int G = A.C / A.Cg;
   const int cbase = (ng % G) * A.Cg;
   const int L = A.Cg * A.HW, L4 = L >> 2;
+  if (LC && (int)threadIdx.x < A.Cg) {  // visible after the first reduction's barrier
+    s_gb[threadIdx.x] = A.gamma[cbase + threadIdx.x];
+    s_gb[kGnLdsCh + threadIdx.x] = A.beta[cbase + threadIdx.x];
+  }
   const f4 *x4 = reinterpret_cast<const f4 *>(A.x + (size_t)ng * L);
   f4 *y4 = reinterpret_cast<f4 *>(y + (size_t)ng * L);
-  const f4 *r4 = A.res ? reinterpret_cast<const f4 *>(A.res + (size_t)ng * L) : nullptr;
-  f4 *s4 = A.res ? reinterpret_cast<f4 *>(A.sum_out + (size_t)ng * L) : nullptr;
   f4 v[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    const int i = threadIdx.x + k * T;
+    v[k] = ld4<NT>(x4 + (i < L4 ? i : 0));
+  }
+  if (A.res) {  // fused residual add (block output + shortcut): one extra read, one extra write
+    const f4 *r4 = reinterpret_cast<const f4 *>(A.res + (size_t)ng * L);
+    f4 *s4 = reinterpret_cast<f4 *>(A.sum_out + (size_t)ng * L);
+    f4 r[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const int i = threadIdx.x + k * T;
+      r[k] = ld4<NT>(r4 + (i < L4 ? i : 0));
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const int i = threadIdx.x + k * T;
+      v[k] += r[k];
+      if (i < L4) st4<NT>(s4 + i, v[k]);
+    }
+  }
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < V; ++k) {
     const int i = threadIdx.x + k * T;
-    if (i < L4) {
-      v[k] = x4[i];
-      if (r4) {  // fused residual add (block output + shortcut): one extra read, one extra write
-        v[k] += r4[i];
-        s4[i] = v[k];
-      }
-      s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
-    }
+    const float t = (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    s += (i < L4) ? t : 0.f;
   }
   const float mean = block_allsum<T>(s, sm1) / (float)L;
   float q = 0.f;
 #pragma unroll
   for (int k = 0; k < V; ++k) {
     const int i = threadIdx.x + k * T;
-    if (i < L4) {
-      const f4 d = v[k] - mean;
-      q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
-    }
+    const f4 d = v[k] - mean;
+    const float t = (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    q += (i < L4) ? t : 0.f;
   }
   const float var = block_allsum<T>(q, sm2) / (float)L;  // biased, exact two-pass
   const float rstd = 1.f / sqrtf(var + A.eps);
@@ -780,31 +823,33 @@ __global__ __launch_bounds__(T) void k_gn_relu_fwd(GnArgs A, float *__restrict__
     rstd_out[ng] = rstd;
   }
   const bool uniform = (A.HW & 3) == 0;
+  const float *ga = LC ? s_gb : A.gamma + cbase;
+  const float *be = LC ? s_gb + kGnLdsCh : A.beta + cbase;
 #pragma unroll
   for (int k = 0; k < V; ++k) {
     const int i = threadIdx.x + k * T;
-    if (i < L4) {
-      float a[4], b[4];
-      gn_coeffs(A, cbase, i << 2, uniform, mean, rstd, a, b);
-      f4 o;
-      o.x = fmaxf(v[k].x * a[0] + b[0], 0.f);
-      o.y = fmaxf(v[k].y * a[1] + b[1], 0.f);
-      o.z = fmaxf(v[k].z * a[2] + b[2], 0.f);
-      o.w = fmaxf(v[k].w * a[3] + b[3], 0.f);
-      y4[i] = o;
-    }
+    float a[4], b[4];
+    gn_coeffs(ga, be, A.inv_hw, (i < L4 ? i : 0) << 2, uniform, mean, rstd, a, b);
+    f4 o;
+    o.x = fmaxf(v[k].x * a[0] + b[0], 0.f);
+    o.y = fmaxf(v[k].y * a[1] + b[1], 0.f);
+    o.z = fmaxf(v[k].z * a[2] + b[2], 0.f);
+    o.w = fmaxf(v[k].w * a[3] + b[3], 0.f);
+    if (i < L4) st4<NT>(y4 + i, o);
   }
 }
 
 // dx = rstd * (dxh - mean_L(dxh) - xh * mean_L(dxh * xh)),  dxh = dy * [z > 0] * gamma,
 // xh = (x - mean) * rstd,  z = x * a + b (the forward's own expression, so the gate is
-// bit-consistent with the y the forward wrote).
-template <int V, int T>
-__global__ __launch_bounds__(T) void k_gn_relu_bwd(GnArgs A, const float *__restrict__ dy,
-                                                   const float *__restrict__ mean_in,
-                                                   const float *__restrict__ rstd_in,
-                                                   float *__restrict__ dx) {
+// bit-consistent with the y the forward wrote).  x and dy are requested up front (2V loads in flight per
+// lane); the shortcut gradient, if present, is fetched after the reductions in batches of <= 4 float4.
+template <int V, int T, bool NT, bool LC, int MW>
+__global__ __launch_bounds__(T, MW) void k_gn_relu_bwd(GnArgs A, const float *__restrict__ dy,
+                                                       const float *__restrict__ mean_in,
+                                                       const float *__restrict__ rstd_in,
+                                                       float *__restrict__ dx) {
   __shared__ float sm1[T / 64], sm2[T / 64];
+  __shared__ float s_gb[LC ? 2 * kGnLdsCh : 2];
   const int ng = blockIdx.x;
   const int G = A.C / A.Cg;
   const int cbase = (ng % G) * A.Cg;
@@ -812,44 +857,76 @@ __global__ __launch_bounds__(T) void k_gn_relu_bwd(GnArgs A, const float *__rest
   const f4 *x4 = reinterpret_cast<const f4 *>(A.x + (size_t)ng * L);
   const f4 *g4 = reinterpret_cast<const f4 *>(dy + (size_t)ng * L);
   f4 *o4 = reinterpret_cast<f4 *>(dx + (size_t)ng * L);
+  f4 xh[V], dh[V];  // raw x / dy first, transformed in place below
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    const int i = threadIdx.x + k * T;
+    const int ic = i < L4 ? i : 0;
+    xh[k] = ld4<NT>(x4 + ic);
+    dh[k] = ld4<NT>(g4 + ic);
+  }
+  if (LC) {
+    if ((int)threadIdx.x < A.Cg) {
+      s_gb[threadIdx.x] = A.gamma[cbase + threadIdx.x];
+      s_gb[kGnLdsCh + threadIdx.x] = A.beta[cbase + threadIdx.x];
+    }
+    __syncthreads();  // the coefficients are needed before the first reduction
+  }
+  const float *ga = LC ? s_gb : A.gamma + cbase;
+  const float *be = LC ? s_gb + kGnLdsCh : A.beta + cbase;
   const float mean = mean_in[ng], rstd = rstd_in[ng];
   const bool uniform = (A.HW & 3) == 0;
-  f4 xh[V], dh[V];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int k = 0; k < V; ++k) {
     const int i = threadIdx.x + k * T;
-    if (i < L4) {
-      const f4 xv = x4[i];
-      const f4 gv = g4[i];
-      float a[4], b[4];
-      gn_coeffs(A, cbase, i << 2, uniform, mean, rstd, a, b);
-      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-      const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
-      float xo[4], go[4];
+    const bool ok = i < L4;
+    float a[4], b[4];
+    gn_coeffs(ga, be, A.inv_hw, (ok ? i : 0) << 2, uniform, mean, rstd, a, b);
+    const float xs[4] = {xh[k].x, xh[k].y, xh[k].z, xh[k].w};
+    const float gs[4] = {dh[k].x, dh[k].y, dh[k].z, dh[k].w};
+    float xo[4], go[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float z = xs[j] * a[j] + b[j];
-        xo[j] = (xs[j] - mean) * rstd;
-        // a = rstd * gamma  =>  dz * gamma = dz * a / rstd; keep gamma explicit via a * (1/rstd)
-        go[j] = (z > 0.f) ? gs[j] * a[j] : 0.f;  // = dxh * rstd
-        s1 += go[j];
-        s2 += go[j] * xo[j];
-      }
-      xh[k] = f4{xo[0], xo[1], xo[2], xo[3]};
-      dh[k] = f4{go[0], go[1], go[2], go[3]};
+    for (int j = 0; j < 4; ++j) {
+      const float z = xs[j] * a[j] + b[j];
+      xo[j] = (xs[j] - mean) * rstd;
+      // a = rstd * gamma  =>  dz * gamma = dz * a / rstd; keep gamma explicit via a * (1/rstd)
+      go[j] = (ok && z > 0.f) ? gs[j] * a[j] : 0.f;  // = dxh * rstd
+      s1 += go[j];
+      s2 += go[j] * xo[j];
     }
+    xh[k] = f4{xo[0], xo[1], xo[2], xo[3]};
+    dh[k] = f4{go[0], go[1], go[2], go[3]};
   }
   const float m1 = block_allsum<T>(s1, sm1) / (float)L;
   const float m2 = block_allsum<T>(s2, sm2) / (float)L;
-  const f4 *d4 = A.dres ? reinterpret_cast<const f4 *>(A.dres + (size_t)ng * L) : nullptr;
+  if (A.dres) {  // gradient arriving through the shortcut (fused autograd add)
+    const f4 *d4 = reinterpret_cast<const f4 *>(A.dres + (size_t)ng * L);
+    constexpr int CH = V > 4 ? 4 : V;
 #pragma unroll
-  for (int k = 0; k < V; ++k) {
-    const int i = threadIdx.x + k * T;
-    if (i < L4) {
-      f4 o = (dh[k] - m1) - xh[k] * m2;  // rstd already folded into dh (a = rstd*gamma)
-      if (d4) o += d4[i];                // gradient arriving through the shortcut (fused autograd add)
-      o4[i] = o;
+    for (int k0 = 0; k0 < V; k0 += CH) {
+      f4 dr[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int i = threadIdx.x + (k0 + c) * T;
+        if (k0 + c < V) dr[c] = ld4<NT>(d4 + (i < L4 ? i : 0));
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int k = k0 + c;
+        if (k < V) {
+          const int i = threadIdx.x + k * T;
+          const f4 o = ((dh[k] - m1) - xh[k] * m2) + dr[c];  // rstd already folded into dh (a = rstd*gamma)
+          if (i < L4) st4<NT>(o4 + i, o);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const int i = threadIdx.x + k * T;
+      const f4 o = (dh[k] - m1) - xh[k] * m2;
+      if (i < L4) st4<NT>(o4 + i, o);
     }
   }
 }
@@ -901,7 +978,7 @@ __global__ __launch_bounds__(kGnStreamT) void k_gn_relu_fwd_stream(GnArgs A, flo
   for (int i = threadIdx.x; i < L4; i += T) {
     const f4 v = x4[i];
     float a[4], b[4];
-    gn_coeffs(A, cbase, i << 2, uniform, mean, rstd, a, b);
+    gn_coeffs(A.gamma + cbase, A.beta + cbase, A.inv_hw, i << 2, uniform, mean, rstd, a, b);
     f4 o;
     o.x = fmaxf(v.x * a[0] + b[0], 0.f);
     o.y = fmaxf(v.y * a[1] + b[1], 0.f);
@@ -929,7 +1006,7 @@ __global__ __launch_bounds__(kGnStreamT) void k_gn_relu_bwd_stream(
   for (int i = threadIdx.x; i < L4; i += T) {
     const f4 xv = x4[i], gv = g4[i];
     float a[4], b[4];
-    gn_coeffs(A, cbase, i << 2, uniform, mean, rstd, a, b);
+    gn_coeffs(A.gamma + cbase, A.beta + cbase, A.inv_hw, i << 2, uniform, mean, rstd, a, b);
     const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
     const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
@@ -945,7 +1022,7 @@ __global__ __launch_bounds__(kGnStreamT) void k_gn_relu_bwd_stream(
   for (int i = threadIdx.x; i < L4; i += T) {
     const f4 xv = x4[i], gv = g4[i];
     float a[4], b[4];
-    gn_coeffs(A, cbase, i << 2, uniform, mean, rstd, a, b);
+    gn_coeffs(A.gamma + cbase, A.beta + cbase, A.inv_hw, i << 2, uniform, mean, rstd, a, b);
     const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
     const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
     float o[4];
@@ -1167,15 +1244,70 @@ inline void gn_pick(int L4, int &V, int &T) {
   T = kGnStreamT;
 }
 
-#define DP_GN_DISPATCH(KERNEL, V_, T_, ...)                                                        \
-  do {                                                                                             \
-    if (T_ == 256 && V_ == 1) hipLaunchKernelGGL((KERNEL<1, 256>), grid, dim3(256), 0, st, __VA_ARGS__);      \
-    else if (T_ == 256 && V_ == 2) hipLaunchKernelGGL((KERNEL<2, 256>), grid, dim3(256), 0, st, __VA_ARGS__); \
-    else if (T_ == 256) hipLaunchKernelGGL((KERNEL<4, 256>), grid, dim3(256), 0, st, __VA_ARGS__);            \
-    else if (T_ == 512) hipLaunchKernelGGL((KERNEL<4, 512>), grid, dim3(512), 0, st, __VA_ARGS__);            \
-    else if (V_ == 4) hipLaunchKernelGGL((KERNEL<4, 1024>), grid, dim3(1024), 0, st, __VA_ARGS__);            \
-    else hipLaunchKernelGGL((KERNEL<7, 1024>), grid, dim3(1024), 0, st, __VA_ARGS__);                         \
+// GroupNorm kernel variant bits (tools/kbench.cpp sweeps them; the C ABI uses kGnDefaultVariant):
+//   1 = NT loads/stores, 2 = gamma/beta through LDS, 4 = forward V=7 kernel compiled for 8 waves/SIMD.
+constexpr int kGnNT = 1, kGnLC = 2, kGnMW8 = 4;
+constexpr int kGnDefaultVariant = 0;
+
+#define DP_GN_FWD_VT(V_, T_, NT_, LC_, MW_) \
+  hipLaunchKernelGGL((k_gn_relu_fwd<V_, T_, NT_, LC_, MW_>), grid, dim3(T_), 0, st, A, y, mean, rstd)
+#define DP_GN_FWD_FLAGS(V_, T_, MW_)                                   \
+  do {                                                                 \
+    if (nt && lc) DP_GN_FWD_VT(V_, T_, true, true, MW_);               \
+    else if (nt) DP_GN_FWD_VT(V_, T_, true, false, MW_);               \
+    else if (lc) DP_GN_FWD_VT(V_, T_, false, true, MW_);               \
+    else DP_GN_FWD_VT(V_, T_, false, false, MW_);                      \
   } while (0)
+
+int launch_gn_fwd(int variant, const GnArgs &A, int N, float *y, float *mean, float *rstd, hipStream_t st) {
+  const int L4 = (A.Cg * A.HW) >> 2;
+  int V, T;
+  gn_pick(L4, V, T);
+  const dim3 grid((unsigned)(N * (A.C / A.Cg)));
+  if (V == 0) {
+    hipLaunchKernelGGL(k_gn_relu_fwd_stream, grid, dim3(kGnStreamT), 0, st, A, y, mean, rstd);
+    return launch_status();
+  }
+  const bool nt = (variant & kGnNT) != 0, lc = (variant & kGnLC) != 0 && A.Cg <= kGnLdsCh;
+  if (T == 256 && V == 1) DP_GN_FWD_FLAGS(1, 256, 1);
+  else if (T == 256 && V == 2) DP_GN_FWD_FLAGS(2, 256, 1);
+  else if (T == 256) DP_GN_FWD_FLAGS(4, 256, 1);
+  else if (T == 512) DP_GN_FWD_FLAGS(4, 512, 1);
+  else if (V == 4) DP_GN_FWD_FLAGS(4, 1024, 1);
+  else if (variant & kGnMW8) DP_GN_FWD_FLAGS(7, 1024, 8);
+  else DP_GN_FWD_FLAGS(7, 1024, 1);
+  return launch_status();
+}
+
+#define DP_GN_BWD_VT(V_, T_, NT_, LC_) \
+  hipLaunchKernelGGL((k_gn_relu_bwd<V_, T_, NT_, LC_, 1>), grid, dim3(T_), 0, st, A, dy, mean, rstd, dx)
+#define DP_GN_BWD_FLAGS(V_, T_)                                        \
+  do {                                                                 \
+    if (nt && lc) DP_GN_BWD_VT(V_, T_, true, true);                    \
+    else if (nt) DP_GN_BWD_VT(V_, T_, true, false);                    \
+    else if (lc) DP_GN_BWD_VT(V_, T_, false, true);                    \
+    else DP_GN_BWD_VT(V_, T_, false, false);                           \
+  } while (0)
+
+int launch_gn_bwd(int variant, const GnArgs &A, int N, const float *dy, const float *mean, const float *rstd,
+                  float *dx, hipStream_t st) {
+  const int L4 = (A.Cg * A.HW) >> 2;
+  int V, T;
+  gn_pick(L4, V, T);
+  const dim3 grid((unsigned)(N * (A.C / A.Cg)));
+  if (V == 0) {
+    hipLaunchKernelGGL(k_gn_relu_bwd_stream, grid, dim3(kGnStreamT), 0, st, A, dy, mean, rstd, dx);
+    return launch_status();
+  }
+  const bool nt = (variant & kGnNT) != 0, lc = (variant & kGnLC) != 0 && A.Cg <= kGnLdsCh;
+  if (T == 256 && V == 1) DP_GN_BWD_FLAGS(1, 256);
+  else if (T == 256 && V == 2) DP_GN_BWD_FLAGS(2, 256);
+  else if (T == 256) DP_GN_BWD_FLAGS(4, 256);
+  else if (T == 512) DP_GN_BWD_FLAGS(4, 512);
+  else if (V == 4) DP_GN_BWD_FLAGS(4, 1024);
+  else DP_GN_BWD_FLAGS(7, 1024);
+  return launch_status();
+}
 
 // Variant = G (float4 groups per thread: 1, 2 or 4) + 8 * NT (non-temporal stores).
 // dp_apply_fwd uses kApplyFwdDefaultVariant; tools/kbench.cpp sweeps the others.
@@ -1435,14 +1567,7 @@ int dp_gn_relu_fwd(const float *x, const float *res, float *sum_out, const float
   DP_REQUIRE(!res || (sum_out && aligned16(res) && aligned16(sum_out)));
   A.res = res;
   A.sum_out = res ? sum_out : nullptr;
-  const int L4 = (A.Cg * HW) >> 2;
-  int V, T;
-  gn_pick(L4, V, T);
-  const dim3 grid((unsigned)(N * G));
-  hipStream_t st = as_stream(stream);
-  if (V == 0) hipLaunchKernelGGL(k_gn_relu_fwd_stream, grid, dim3(kGnStreamT), 0, st, A, y, mean, rstd);
-  else DP_GN_DISPATCH(k_gn_relu_fwd, V, T, A, y, mean, rstd);
-  return launch_status();
+  return launch_gn_fwd(kGnDefaultVariant, A, N, y, mean, rstd, as_stream(stream));
 }
 
 int dp_gn_relu_bwd(const float *dy, const float *dres, const float *x, const float *gamma,
@@ -1454,14 +1579,7 @@ int dp_gn_relu_bwd(const float *dy, const float *dres, const float *x, const flo
   DP_REQUIRE(dy && mean && rstd && dx && aligned16(dy) && aligned16(dx));
   DP_REQUIRE(!dres || aligned16(dres));
   A.dres = dres;
-  const int L4 = (A.Cg * HW) >> 2;
-  int V, T;
-  gn_pick(L4, V, T);
-  const dim3 grid((unsigned)(N * G));
-  hipStream_t st = as_stream(stream);
-  if (V == 0) hipLaunchKernelGGL(k_gn_relu_bwd_stream, grid, dim3(kGnStreamT), 0, st, A, dy, mean, rstd, dx);
-  else DP_GN_DISPATCH(k_gn_relu_bwd, V, T, A, dy, mean, rstd, dx);
-  return launch_status();
+  return launch_gn_bwd(kGnDefaultVariant, A, N, dy, mean, rstd, dx, as_stream(stream));
 }
 
 int dp_pad_maxpool_fwd(const float *x, int64_t NC, int Hin, int Win, float *y, uint8_t *code,

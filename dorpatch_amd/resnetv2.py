@@ -230,10 +230,19 @@ def resnetv2_50x1_bit(num_classes=1000):
 
 
 @torch.no_grad()
-def seeded_init_(model, seed=1234):
+def seeded_init_(model, seed=1234, gn_bias=0.0):
     """Deterministic stand-in weights (no checkpoint is available offline):
-    conv ~ N(0, 2/fan_in) before standardisation, GN gamma=1 beta=0, head ~ N(0, 0.01).
-    Drawn on the CPU generator so CPU oracle and GPU product share the weights."""
+    conv ~ N(0, 2/fan_in) before standardisation, GN gamma=1 beta=``gn_bias``, head ~ N(0, 0.01).
+    Drawn on the CPU generator so CPU oracle and GPU product share the weights.
+
+    ``gn_bias = 0`` (default; the benchmark's weights) gives a network that is chaotic in fp32: half of all
+    pre-activations sit within a rounding error's reach of a ReLU gate somewhere along 50 layers, and its
+    input gradient differs between two correct fp32 evaluations (or fp32 vs fp64) by ~1e-2 relative.
+    ``gn_bias = 3.5`` is the WELL-CONDITIONED set used by the tight whole-network parity tests: every
+    GroupNorm output is shifted 3.5 sigma into the linear side of its ReLU (0.02 % of the gates stay closed,
+    so gating is still exercised), gate flips under re-ordered fp32 sums become rare, and fp32 agrees with
+    fp64 to ~2e-6 of the gradient scale — tight enough to see a 1e-4 error anywhere in the
+    GroupNorm / stem / conv1x1 / pooling path (tests/test_backbone_parity_gpu.py, smoke())."""
     gen = torch.Generator(device="cpu").manual_seed(seed)
     for name, p in model.named_parameters():
         if p.dim() == 4 and not name.startswith("head."):
@@ -243,7 +252,12 @@ def seeded_init_(model, seed=1234):
             v = torch.randn(p.shape, generator=gen) * 0.01
         elif name.endswith("norm.weight") or ".norm" in name and name.endswith("weight"):
             v = torch.ones(p.shape)
+        elif "norm" in name and name.endswith("bias"):
+            v = torch.full(p.shape, float(gn_bias))
         else:
             v = torch.zeros(p.shape)
         p.copy_(v.to(p.device))
     return model
+
+
+WELL_CONDITIONED_GN_BIAS = 3.5

@@ -28,6 +28,11 @@ Fixtures
 ``patchcleanser_56.npz``  records of the reference PatchCleanser.robust_predict(certify=True) on a
                    location-sensitive toy net (all four decision branches) + n_patch=2 mask checksums.
 ``geometry.npz``   MaskWindow geometry for 56/224/384 and mask-universe checksums.
+``end_metric_56.npz``  8 images x full two-stage reference runs (300 iterations per stage, S = 8, toy nets whose
+                   gain sweeps the range where the attack goes from certifiably succeeding to failing): the
+                   returned mask / pattern, the failure count over the 2520-mask universe and the reference
+                   PatchCleanser records at the 4 ratios of main.py:61 — the inputs of main.py:168-184's
+                   certified-ASR / certified-ACC figures.
 """
 import contextlib
 import io
@@ -256,8 +261,51 @@ def make_patchcleanser_fixture(path, H=56):
     return out
 
 
+END_METRIC_GAINS = (1.0, 1.05, 1.1, 1.15, 1.2, 1.25, 1.3, 1.12)
+END_METRIC_RATIOS = (0.015, 0.03, 0.06, 0.12)          # main.py:61
+
+
+def make_end_metric_fixture(path, H=56, S=8, max_iterations=300, eps=4.0):
+    """The end metric of main.py:168-184 for 8 single-image problems, produced by the UNMODIFIED reference:
+    DorPatch.generate (both stages) -> clip -> PatchCleanser.robust_predict(img, True) at 4 ratios."""
+    from . import restatement as R
+    ref = ref_shim.load_reference()
+    uni = R.mask_universe(H, 2)
+    out = dict(H=H, S=S, max_iterations=max_iterations, eps=eps, gains=np.array(END_METRIC_GAINS),
+               ratios=np.array(END_METRIC_RATIOS), patch_budget=0.12)
+    xs, ys, masks_, patterns, n_fail, pc_pred, pc_cert, clean, adv_pred, steps = [], [], [], [], [], [], [], [], [], []
+    for k, gain in enumerate(END_METRIC_GAINS):
+        net, x, y = toy_problem(H, seed_x=20 + k, gain=float(gain))
+        cap, mask, pattern, _ = run_reference(net, x, y, sampling_size=S, max_iterations=max_iterations, eps=eps,
+                                              keep=lambda s, i: False, seed=1234 + k)
+        adv = x + R.clip(mask, pattern, x, eps)
+        preds, certs = [], []
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            for r in END_METRIC_RATIOS:
+                pc = ref.PatchCleanser.PatchCleanser(ref.PatchCleanser.MaskWindow(H, r, 1), net)
+                rec = pc.robust_predict(adv[0], True)                          # main.py:150-151
+                preds.append(int(rec.prediction))
+                certs.append(bool(rec.certification))
+            clean.append(int(net(x).argmax(-1)))
+            adv_pred.append(int(net(adv).argmax(-1)))
+        xs.append(x.numpy()[0]); ys.append(int(y)); masks_.append(mask.numpy()[0]); patterns.append(pattern.numpy()[0])
+        n_fail.append(len(R.collect_failure(net, adv, y, uni, True)))
+        pc_pred.append(preds); pc_cert.append(certs)
+        steps.append([sum(1 for r in cap.records if r["stage"] == st) for st in (0, 1)])
+    out.update(x=np.stack(xs), target=np.array(ys), final_mask=np.stack(masks_), final_pattern=np.stack(patterns),
+               n_fail=np.array(n_fail), pc_pred=np.array(pc_pred), pc_cert=np.array(pc_cert), clean=np.array(clean),
+               adv_pred=np.array(adv_pred), steps=np.array(steps))
+    np.savez_compressed(path, **out)
+    return out
+
+
 def main():
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    if "--only-end-metric" in sys.argv:
+        o = make_end_metric_fixture(os.path.join(GOLDEN_DIR, "end_metric_56.npz"))
+        print({k: o[k].tolist() for k in ("target", "clean", "adv_pred", "n_fail", "pc_pred", "pc_cert", "steps")})
+        return
+    make_end_metric_fixture(os.path.join(GOLDEN_DIR, "end_metric_56.npz"))
     make_patchcleanser_fixture(os.path.join(GOLDEN_DIR, "patchcleanser_56.npz"))
     make_geometry_fixture(os.path.join(GOLDEN_DIR, "geometry.npz"))
     make_steps_fixture(56, 8, 1.0, os.path.join(GOLDEN_DIR, "steps_56.npz"))

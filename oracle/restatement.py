@@ -103,13 +103,13 @@ def struct_loss(adv_x, local_var_x):
 def density_loss(mask):
     """attack.py:77-80, 237: unbiased variance of the (W//8)-window sums of the mask."""
     win = int(mask.shape[-1] // 8)
-    sums = F.conv2d(mask, torch.ones(1, 1, win, win), stride=win)
+    sums = F.conv2d(mask, torch.ones(1, 1, win, win, dtype=mask.dtype), stride=win)
     return sums.flatten(1).var(1)
 
 
 def group_lasso(mask, unit=7):
     """attack.py:72-74, 243-244."""
-    cell = F.conv2d(mask ** 2, torch.ones(1, 1, unit, unit), stride=unit)
+    cell = F.conv2d(mask ** 2, torch.ones(1, 1, unit, unit, dtype=mask.dtype), stride=unit)
     return unit * cell.sqrt().sum((1, 2, 3))
 
 
@@ -157,7 +157,7 @@ def eot_step(model, x, mask, pattern, y, keep, *, stage, targeted, n_classes, co
     loss_adv = torch.stack(rows)                                            # :224-225
     loss_struc = struct_loss(adv_x, local_var_x)                            # :227-228
     coef_s = torch.as_tensor(np.broadcast_to(np.asarray(structured, dtype=np.float64), (B,)).copy(),
-                             dtype=torch.float32)
+                             dtype=x.dtype)
     loss = loss_adv.mean(1) + coef_s * loss_struc                           # :230-233
     out = dict(adv_x=adv_x.detach(), logits=logits.detach(), loss_adv=loss_adv.detach(),
                loss_struc=loss_struc.detach(), scale=None)
@@ -165,7 +165,7 @@ def eot_step(model, x, mask, pattern, y, keep, *, stage, targeted, n_classes, co
         dens = density_loss(mask)                                           # :237
         gl = group_lasso(mask, unit)                                        # :243-244
         coef_g = torch.as_tensor(np.broadcast_to(np.asarray(coeff_group_lasso, dtype=np.float64), (B,)).copy(),
-                                 dtype=torch.float32)
+                                 dtype=x.dtype)
         loss = loss + density * dens + coef_g * gl                          # :239-245
         out.update(density=dens.detach(), group_lasso=gl.detach())
     loss.sum().backward()                                                   # :247
@@ -173,7 +173,7 @@ def eot_step(model, x, mask, pattern, y, keep, *, stage, targeted, n_classes, co
     out["grad_pattern"] = pattern.grad.detach().clone()
     out["grad_mask"] = mask.grad.detach().clone() if stage == 0 else torch.zeros_like(mask)
     if lr is not None:                                                      # :333-342
-        lr_t = torch.as_tensor(np.broadcast_to(np.asarray(lr, dtype=np.float32), (B,)).copy()).view(B, 1, 1, 1)
+        lr_t = torch.as_tensor(np.broadcast_to(np.asarray(lr, dtype=np.float32), (B,)).copy()).to(x.dtype).view(B, 1, 1, 1)
         with torch.no_grad():
             new_pattern = (pattern - lr_t * pattern.grad.sign()).clamp(clip_min, clip_max)
             new_mask = (mask - lr_t * mask.grad.sign()).clamp(clip_min, clip_max) if stage == 0 else mask.detach()

@@ -141,7 +141,12 @@ def test_generate_trajectory_tracks_reference(golden_trace, tmp_path, monkeypatc
                                                 torch.from_numpy(t["x"]), float(t["eps"]))
     fails_ref = R.collect_failure(_toy(float(t["gain"]), "cpu"), adv_ref, torch.from_numpy(t["y0"]),
                                   R.mask_universe(H, 2), True)
-    assert abs(len(fails) - len(fails_ref)) <= 0.1 * 2520, (len(fails), len(fails_ref))
+    # same bands as tests/test_end_metric_gpu.py (which compares the certified-ASR figures themselves on 8 images):
+    # broken stays broken, unbroken stays unbroken, never further than 15 % of the universe apart
+    n, n_ref = len(fails), len(fails_ref)
+    assert abs(n - n_ref) <= 0.15 * 2520, (n, n_ref)
+    assert not (n_ref < 0.05 * 2520) or n < 0.15 * 2520, (n, n_ref)
+    assert not (n_ref > 0.85 * 2520) or n > 0.70 * 2520, (n, n_ref)
 
 
 def test_generate_short_run_both_stages(tmp_path, monkeypatch):

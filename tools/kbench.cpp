@@ -4,7 +4,7 @@
 // achievable HBM ceilings.  No Python / torch: starts in milliseconds on the GPU box.
 //
 //   build:  python -m dorpatch_amd.build  &&  make -C tools        (or __graft_entry__.build())
-//   run:    tools/kbench [B S H iters]
+//   run:    tools/kbench [B S H iters [name-filter]]     e.g. tools/kbench 64 32 224 2 "dp_apply_fwd (default"
 //
 // Output: one line per kernel: name, avg ms (hipEvent on the launch stream), algorithmic
 // bytes per launch, GB/s, fraction of the 8 TB/s spec.
@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <random>
 #include <string>
@@ -51,6 +52,29 @@ __global__ __launch_bounds__(256) void k_copy(const f4 *__restrict__ in, f4 *__r
     __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
 }
 
+// U independent 16-B loads in flight per lane before the first store (block-contiguous chunks of U KiB per wave)
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_copy_u(const f4 *__restrict__ in, f4 *__restrict__ out, size_t n4) {
+  const size_t per_block = (size_t)256 * U;
+  for (size_t base = (size_t)blockIdx.x * per_block; base < n4; base += (size_t)gridDim.x * per_block) {
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = base + (size_t)u * 256 + threadIdx.x;
+      const size_t ic = i < n4 ? i : 0;
+      v[u] = NT ? __builtin_nontemporal_load(in + ic) : in[ic];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = base + (size_t)u * 256 + threadIdx.x;
+      if (i < n4) {
+        if (NT) __builtin_nontemporal_store(v[u], out + i);
+        else out[i] = v[u];
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_readsum(const f4 *__restrict__ in, float *__restrict__ out, size_t n4) {
   f4 acc = {0.f, 0.f, 0.f, 0.f};
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
@@ -58,7 +82,10 @@ __global__ __launch_bounds__(256) void k_readsum(const f4 *__restrict__ in, floa
   if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = 1.f;  // keep the loads alive
 }
 
+static const char *g_filter = nullptr;  // 5th argument: run only the entries whose name contains it
+
 static double bench(const char *name, double bytes, int iters, hipStream_t st, const std::function<void()> &fn) {
+  if (g_filter && !strstr(name, g_filter)) return 0.0;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
@@ -84,6 +111,7 @@ int main(int argc, char **argv) {
   const int S = argc > 2 ? atoi(argv[2]) : 32;
   const int H = argc > 3 ? atoi(argv[3]) : 224;
   const int iters = argc > 4 ? atoi(argv[4]) : 20;
+  g_filter = argc > 5 ? argv[5] : nullptr;
   const int W = H, P = H * W, N = B * S;
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
@@ -176,6 +204,16 @@ int main(int argc, char **argv) {
         [&] { hipLaunchKernelGGL(k_readsum, dim3(2048), dim3(256), 0, st, (const f4 *)big2, loss, n4_big); });
   bench("calib: copy (read+write)", 2 * out_bytes, iters, st,
         [&] { hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, st, (const f4 *)big2, (f4 *)big, n4_big); });
+  // what can a copy reach on this box?  (grid size, loads in flight per lane, temporal hints)
+  bench("calib: copy x4 in flight, NT", 2 * out_bytes, iters, st, [&] {
+    hipLaunchKernelGGL((k_copy_u<4, true>), dim3(4096), dim3(256), 0, st, (const f4 *)big2, (f4 *)big, n4_big); });
+  bench("calib: copy x4 in flight, plain", 2 * out_bytes, iters, st, [&] {
+    hipLaunchKernelGGL((k_copy_u<4, false>), dim3(4096), dim3(256), 0, st, (const f4 *)big2, (f4 *)big, n4_big); });
+  bench("calib: copy x8 in flight, NT", 2 * out_bytes, iters, st, [&] {
+    hipLaunchKernelGGL((k_copy_u<8, true>), dim3(2048), dim3(256), 0, st, (const f4 *)big2, (f4 *)big, n4_big); });
+  bench("calib: copy x8, NT, 1 WG per 32 KiB", 2 * out_bytes, iters, st, [&] {
+    hipLaunchKernelGGL((k_copy_u<8, true>), dim3((unsigned)((n4_big + 2047) / 2048)), dim3(256), 0, st,
+                       (const f4 *)big2, (f4 *)big, n4_big); });
 
   // ---- a-2
   bench("dp_sumsq_partials", (double)B * P * 28, iters, st,
@@ -227,7 +265,7 @@ int main(int argc, char **argv) {
           });
   }
   // ---- a-8: backbone element-wise kernels at the training micro-batch (256 samples)
-  if (H == 224) {
+  if (H == 224 && (!g_filter || strstr(g_filter, "gn_relu") || strstr(g_filter, "maxpool") || strstr(g_filter, "stem"))) {
     const int Nb = 256;
     struct Shape { int C, HW; const char *what; };
     const Shape shapes[] = {{64, 3136, "64ch@56x56"}, {256, 3136, "256ch@56x56"}, {512, 784, "512ch@28x28"},
@@ -256,6 +294,32 @@ int main(int argc, char **argv) {
       snprintf(name, sizeof name, "dp_gn_relu_bwd +dres %s", sh.what);
       bench(name, e * 16, iters, st,
             [&] { DP(dp_gn_relu_bwd(gy, gr, gx, gam, bet, gmean, grstd, Nb, sh.C, sh.HW, 32, gs, st)); });
+    }
+    // variant sweep of the register-resident GroupNorm kernels (bits: 1 NT, 2 LDS coefficients, 4 fwd V=7 @ 8 waves)
+    if (g_filter && strstr(g_filter, "gn_relu")) {
+      for (const Shape &sh : shapes) {
+        const double e = (double)Nb * sh.C * sh.HW;
+        for (int variant = 0; variant < 8; ++variant) {
+          if ((variant & 4) && !(sh.C == 256 && sh.HW == 3136)) continue;  // MW8 only exists for the V = 7 forward
+          GnArgs A;
+          DP(gn_check(gx, gam, bet, Nb, sh.C, sh.HW, 32, A, 1e-5f));
+          char name[96];
+          snprintf(name, sizeof name, "  gn_relu_fwd v%d %s", variant, sh.what);
+          bench(name, e * 8, iters, st, [&] { DP(launch_gn_fwd(variant, A, Nb, gy, gmean, grstd, st)); });
+          GnArgs Ar = A;
+          Ar.res = gr;
+          Ar.sum_out = gs;
+          snprintf(name, sizeof name, "  gn_relu_fwd+res v%d %s", variant, sh.what);
+          bench(name, e * 16, iters, st, [&] { DP(launch_gn_fwd(variant, Ar, Nb, gy, gmean, grstd, st)); });
+          if (variant & 4) continue;
+          snprintf(name, sizeof name, "  gn_relu_bwd v%d %s", variant, sh.what);
+          bench(name, e * 12, iters, st, [&] { DP(launch_gn_bwd(variant, A, Nb, gy, gmean, grstd, gs, st)); });
+          GnArgs Ad = A;
+          Ad.dres = gr;
+          snprintf(name, sizeof name, "  gn_relu_bwd+dres v%d %s", variant, sh.what);
+          bench(name, e * 16, iters, st, [&] { DP(launch_gn_bwd(variant, Ad, Nb, gy, gmean, grstd, gs, st)); });
+        }
+      }
     }
     // stem: pad + maxpool on (256, 64, 112, 112) and the 7x7/2 input gradient
     const int64_t NC = (int64_t)Nb * 64;
