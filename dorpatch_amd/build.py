@@ -17,7 +17,11 @@ LIB_PATH = os.path.join(LIB_DIR, "libdorpatch_hip.so")
 
 # -ffp-contract=off: keep mul/add un-fused so results track the fp32 CPU
 # reference op for op (the kernels are HBM-bound; FMA buys nothing).
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+# -fno-slp-vectorize: the SLP pass pairs independent scalar fp32 ops into v_pk_* instructions; on gfx950 a
+# v_pk_fma_f32 costs as much as two v_fma_f32 plus the moves that build its 64-bit operand pairs — in the one
+# VALU-bound kernel here (k_stem_dgrad) that is 233 moves for 168 FMA instructions (explicit float4 arithmetic
+# is vector IR already and unaffected).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
                "-fPIC", "-shared", "-Wall"]
 
 

@@ -1157,28 +1157,39 @@ __global__ __launch_bounds__(kBlock) void k_pad_maxpool_bwd(const float *__restr
 // fmaf is used explicitly (one rounding per MAC; the file is built with -ffp-contract=off).
 // ----------------------------------------------------------------------------
 
-constexpr int SQ = 16;            // quads per tile side -> 256 threads
+constexpr int SQ = 16;            // quads per tile side; a thread owns 2 vertically adjacent quads -> 128 threads
 constexpr int ST = SQ + 3;        // dy tile side (halo: 1 before, 2 after)
+constexpr int STP = 24;           // LDS row pitch: 2 * STP mod 32 == 16 -> the 4 quad-row pairs of a wave hit disjoint banks
+constexpr int kStemBlock = (SQ / 2) * SQ;
 
-__global__ __launch_bounds__(kBlock) void k_stem_dgrad(const float *__restrict__ dy,
-                                                       const float *__restrict__ w, int K, int Ho,
-                                                       int Wo, float *__restrict__ dx) {
-  __shared__ float tile[2][ST][ST + 1];
+// Thread (ta, tb) owns output quads (2ta, tb) and (2ta + 1, tb) of the tile x 3 channels x 2 x 2 parities =
+// 24 accumulators, fed from a 5 x 4 patch of the dy tile (20 LDS reads per input channel k for 294 FMAs).
+// The filter taps are wave-uniform: they arrive through scalar loads and are SGPR operands of the FMAs.
+// One input channel's 147 taps exceed the ~100 SGPRs a wave has, and a compiler left to schedule them all at
+// once spills SGPRs into VGPR lanes (v_writelane / v_readlane: as many instructions as the FMAs themselves —
+// the r01 kernel, 24.9 % of the fp32 VALU peak); so the taps are consumed one output channel (49) at a time,
+// fenced by scheduling barriers.
+__global__ __launch_bounds__(kStemBlock) void k_stem_dgrad(const float *__restrict__ dy,
+                                                           const float *__restrict__ w, int K, int Ho,
+                                                           int Wo, float *__restrict__ dx) {
+  __shared__ float tile[2][ST][STP];
   const int n = blockIdx.z;
   const int a0 = blockIdx.y * SQ, b0 = blockIdx.x * SQ;
-  const int ta = threadIdx.x / SQ, tb = threadIdx.x % SQ;
+  const int ta = threadIdx.x / SQ, tb = threadIdx.x % SQ;  // ta: pair of quad rows 2ta, 2ta + 1
   const float *dyn = dy + (size_t)n * K * Ho * Wo;
-  float acc[3][2][2];
+  float acc[2][3][2][2];
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
+  for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int ph = 0; ph < 2; ++ph)
+    for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int pw = 0; pw < 2; ++pw) acc[c][ph][pw] = 0.f;
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int pw = 0; pw < 2; ++pw) acc[u][c][ph][pw] = 0.f;
 
   auto stage = [&](int k, int buf) {
     const float *plane = dyn + (size_t)k * Ho * Wo;
-    for (int e = threadIdx.x; e < ST * ST; e += kBlock) {
+    for (int e = threadIdx.x; e < ST * ST; e += kStemBlock) {
       const int r = e / ST, c = e - r * ST;
       const int oh = a0 - 1 + r, ow = b0 - 1 + c;
       float v = 0.f;
@@ -1192,41 +1203,54 @@ __global__ __launch_bounds__(kBlock) void k_stem_dgrad(const float *__restrict__
   for (int k = 0; k < K; ++k) {
     const int buf = k & 1;
     if (k + 1 < K) stage(k + 1, buf ^ 1);  // the other buffer was last read two barriers ago
-    float p[4][4];
+    float p[5][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 5; ++r)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) p[r][q] = tile[buf][ta + r][tb + q];
+      for (int q = 0; q < 4; ++q) p[r][q] = tile[buf][2 * ta + r][tb + q];
     const float *wk = w + (size_t)k * 147;  // wave-uniform: scalar loads
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < 3; ++c) {
+      __builtin_amdgcn_sched_barrier(0);
+      float wc[49];
 #pragma unroll
-      for (int ph = 0; ph < 2; ++ph)
+      for (int t = 0; t < 49; ++t) wc[t] = wk[c * 49 + t];
 #pragma unroll
-        for (int pw = 0; pw < 2; ++pw)
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
+        for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int i = ph + 5 - 2 * r, j = pw + 5 - 2 * q;
-              if (i >= 0 && i <= 6 && j >= 0 && j <= 6)
-                acc[c][ph][pw] = __builtin_fmaf(p[r][q], wk[c * 49 + i * 7 + j], acc[c][ph][pw]);
-            }
+          for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int i = ph + 5 - 2 * r, j = pw + 5 - 2 * q;
+                if (i >= 0 && i <= 6 && j >= 0 && j <= 6)
+                  acc[u][c][ph][pw] = __builtin_fmaf(p[u + r][q], wc[i * 7 + j], acc[u][c][ph][pw]);
+              }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   }
-  const int a = a0 + ta, b = b0 + tb;
-  if (a >= Ho || b >= Wo) return;
+  const int b = b0 + tb;
+  if (b >= Wo) return;
   const int H = 2 * Ho, W = 2 * Wo;
   float *dxn = dx + (size_t)n * 3 * H * W;
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
+  for (int u = 0; u < 2; ++u) {
+    const int a = a0 + 2 * ta + u;
+    if (a >= Ho) continue;
 #pragma unroll
-    for (int ph = 0; ph < 2; ++ph) {
-      float2 o;
-      o.x = acc[c][ph][0];
-      o.y = acc[c][ph][1];
-      *reinterpret_cast<float2 *>(dxn + ((size_t)c * H + 2 * a + ph) * W + 2 * b) = o;
-    }
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        float2 o;
+        o.x = acc[u][c][ph][0];
+        o.y = acc[u][c][ph][1];
+        *reinterpret_cast<float2 *>(dxn + ((size_t)c * H + 2 * a + ph) * W + 2 * b) = o;
+      }
+  }
 }
 
 // (V float4 per thread, T threads) combinations that are instantiated, smallest first; the
@@ -1610,7 +1634,7 @@ int dp_stem_dgrad(const float *dy, const float *w, int N, int K, int Ho, int Wo,
                   dp_stream_t stream) {
   DP_REQUIRE(dy && w && dx && N > 0 && N <= 65535 && K > 0 && Ho > 0 && Wo > 0);
   DP_REQUIRE((reinterpret_cast<uintptr_t>(dx) & 7u) == 0);
-  hipLaunchKernelGGL(k_stem_dgrad, dim3(cdiv(Wo, SQ), cdiv(Ho, SQ), N), dim3(kBlock), 0,
+  hipLaunchKernelGGL(k_stem_dgrad, dim3(cdiv(Wo, SQ), cdiv(Ho, SQ), N), dim3(kStemBlock), 0,
                      as_stream(stream), dy, w, K, Ho, Wo, dx);
   return launch_status();
 }

@@ -31,6 +31,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __shared__ static
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)   /* scheduling hint: no meaning on the host */
 
 using std::max;
 using std::min;

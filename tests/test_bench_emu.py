@@ -58,11 +58,21 @@ def test_presets_name_the_baseline_configs(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--config", "2"])
     a = bench.parse()
     assert (a.batch, a.samples, a.size, a.patch_budget) == (1, 64, 384, 0.015625)
-    assert bench.pmc_traffic(64, 32, 224) == 1274372598 and bench.pmc_traffic(1, 2, 32) is None
+
+
+def test_live_pmc_traffic_degrades_to_null_without_a_gpu_toolchain(monkeypatch):
+    """roofline.traffic is measured in the run (a rocprofv3 --pmc child process) or null with the reason — never a
+    number replayed from an earlier session."""
+    import bench
+    monkeypatch.setattr(bench, "ROOT", "/nonexistent")
+    traffic, why = bench.pmc_traffic_live(1, 2, 32)
+    assert traffic is None and "missing" in why
 
 
 def test_cpu_baseline_leg_is_bounded_and_labelled():
     import bench
-    out = bench.cpu_baseline(64, n_masks=2, max_steps=1, budget_s=20.0, threads=2)
+    out = bench.cpu_baseline(64, n_masks=2, warm=1, timed=2, budget_s=20.0, threads=2)
     assert out["kind"] == "port" and out["unit"] == "EOT-samples/s" and out["cores"] == 2 and out["value"] > 0
     assert "oracle/restatement.eot_step" in out["sample"] and "64x64" in out["sample"]
+    # BASELINE.md §3: both the reference's real behaviour (weights trainable) and the frozen variant, median of timed steps
+    assert out["value_frozen"] > 0 and out["detail"]["as_is"]["timed_steps"] == 2 and out["detail"]["frozen"]["timed_steps"] == 2
