@@ -1172,7 +1172,7 @@ constexpr int kStemBlock = (SQ / 2) * SQ;
 __global__ __launch_bounds__(kStemBlock) void k_stem_dgrad(const float *__restrict__ dy,
                                                            const float *__restrict__ w, int K, int Ho,
                                                            int Wo, float *__restrict__ dx) {
-  __shared__ float tile[2][ST][STP];
+  __shared__ float tile[2][ST + 1][STP];  // + 1 row: the dummy slot of lanes that stage nothing
   const int n = blockIdx.z;
   const int a0 = blockIdx.y * SQ, b0 = blockIdx.x * SQ;
   const int ta = threadIdx.x / SQ, tb = threadIdx.x % SQ;  // ta: pair of quad rows 2ta, 2ta + 1
@@ -1187,22 +1187,44 @@ __global__ __launch_bounds__(kStemBlock) void k_stem_dgrad(const float *__restri
 #pragma unroll
         for (int pw = 0; pw < 2; ++pw) acc[u][c][ph][pw] = 0.f;
 
-  auto stage = [&](int k, int buf) {
+  // Staging of the 19 x 19 dy tile: a thread moves up to 3 elements per input channel.  Their tile / plane
+  // offsets do not depend on k, so they are computed once; the loads for channel k + 1 are issued BEFORE the
+  // FMAs of channel k and only written to LDS after them (software pipeline: their latency hides behind 294 FMAs
+  // instead of stalling the wave three times per channel).
+  constexpr int kStage = (ST * ST + kStemBlock - 1) / kStemBlock;  // 3
+  // Branch-free on purpose (one basic block per channel, so the order loads -> FMAs -> LDS stores survives the
+  // compiler): lanes with nothing to stage write a dummy slot behind the tile, halo lanes read element 0 of the
+  // plane and select 0.
+  int lds_off[kStage], g_off[kStage];
+  bool g_ok[kStage];
+#pragma unroll
+  for (int j = 0; j < kStage; ++j) {
+    const int e = threadIdx.x + j * kStemBlock;
+    const int r = e / ST, c = e - r * ST;
+    const int oh = a0 - 1 + r, ow = b0 - 1 + c;
+    lds_off[j] = e < ST * ST ? r * STP + c : ST * STP;
+    g_ok[j] = e < ST * ST && oh >= 0 && oh < Ho && ow >= 0 && ow < Wo;
+    g_off[j] = g_ok[j] ? oh * Wo + ow : 0;
+  }
+  float pre[kStage];
+  auto stage_load = [&](int k) {
     const float *plane = dyn + (size_t)k * Ho * Wo;
-    for (int e = threadIdx.x; e < ST * ST; e += kStemBlock) {
-      const int r = e / ST, c = e - r * ST;
-      const int oh = a0 - 1 + r, ow = b0 - 1 + c;
-      float v = 0.f;
-      if (oh >= 0 && oh < Ho && ow >= 0 && ow < Wo) v = plane[(size_t)oh * Wo + ow];
-      tile[buf][r][c] = v;
-    }
+#pragma unroll
+    for (int j = 0; j < kStage; ++j) pre[j] = plane[g_off[j]];
+  };
+  auto stage_store = [&](int buf) {
+    float *t = &tile[buf][0][0];
+#pragma unroll
+    for (int j = 0; j < kStage; ++j) t[lds_off[j]] = g_ok[j] ? pre[j] : 0.f;
   };
 
-  stage(0, 0);
+  stage_load(0);
+  stage_store(0);
   __syncthreads();
   for (int k = 0; k < K; ++k) {
     const int buf = k & 1;
-    if (k + 1 < K) stage(k + 1, buf ^ 1);  // the other buffer was last read two barriers ago
+    stage_load(k + 1 < K ? k + 1 : k);  // in flight during this channel's FMAs (last channel: a harmless re-read)
+    __builtin_amdgcn_sched_barrier(0);
     float p[5][4];
 #pragma unroll
     for (int r = 0; r < 5; ++r)
@@ -1231,6 +1253,7 @@ __global__ __launch_bounds__(kStemBlock) void k_stem_dgrad(const float *__restri
               }
     }
     __builtin_amdgcn_sched_barrier(0);
+    stage_store(buf ^ 1);  // the other buffer was last read before the previous barrier
     __syncthreads();
   }
   const int b = b0 + tb;
@@ -1253,6 +1276,66 @@ __global__ __launch_bounds__(kStemBlock) void k_stem_dgrad(const float *__restri
   }
 }
 
+// ----------------------------------------------------------------------------
+// a-8 (backbone, strided 1x1 downsample convolutions): even-pixel subsampling and its accumulating adjoint.
+// One thread per pair of output pixels of one row: a 16-byte load of 4 input pixels yields outputs (.x, .z)
+// (W % 4 == 0), or one thread per output pixel with an 8-byte load (W % 4 == 2).
+// ----------------------------------------------------------------------------
+template <bool WIDE>
+__global__ __launch_bounds__(kBlock) void k_subsample2(const float *__restrict__ x, int H, int W, long total,
+                                                       float *__restrict__ y) {
+  const long tid = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (tid >= total) return;
+  const int Ho = H >> 1, Wo = W >> 1;
+  if (WIDE) {
+    const int Wp = Wo >> 1;  // output pairs per row
+    const int t = (int)(tid % Wp);
+    const long row = tid / Wp;  // nc * Ho + oh
+    const long nc = row / Ho;
+    const int oh = (int)(row - nc * Ho);
+    const f4 v = *reinterpret_cast<const f4 *>(x + (nc * H + 2 * oh) * (long)W + 4 * t);
+    float2 o;
+    o.x = v.x;
+    o.y = v.z;
+    *reinterpret_cast<float2 *>(y + row * Wo + 2 * t) = o;
+  } else {
+    const int t = (int)(tid % Wo);
+    const long row = tid / Wo;
+    const long nc = row / Ho;
+    const int oh = (int)(row - nc * Ho);
+    const float2 v = *reinterpret_cast<const float2 *>(x + (nc * H + 2 * oh) * (long)W + 2 * t);
+    y[row * Wo + t] = v.x;
+  }
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(kBlock) void k_subsample2_add(const float *__restrict__ dy, int H, int W,
+                                                           long total, float *__restrict__ g) {
+  const long tid = (long)blockIdx.x * kBlock + threadIdx.x;
+  if (tid >= total) return;
+  const int Ho = H >> 1, Wo = W >> 1;
+  if (WIDE) {
+    const int Wp = Wo >> 1;
+    const int t = (int)(tid % Wp);
+    const long row = tid / Wp;
+    const long nc = row / Ho;
+    const int oh = (int)(row - nc * Ho);
+    const float2 d = *reinterpret_cast<const float2 *>(dy + row * Wo + 2 * t);
+    f4 *p = reinterpret_cast<f4 *>(g + (nc * H + 2 * oh) * (long)W + 4 * t);
+    f4 v = *p;
+    v.x += d.x;
+    v.z += d.y;
+    *p = v;
+  } else {
+    const int t = (int)(tid % Wo);
+    const long row = tid / Wo;
+    const long nc = row / Ho;
+    const int oh = (int)(row - nc * Ho);
+    float *p = g + (nc * H + 2 * oh) * (long)W + 2 * t;
+    *p = *p + dy[row * Wo + t];
+  }
+}
+
 // (V float4 per thread, T threads) combinations that are instantiated, smallest first; the
 // group must fit: V*T >= L4.  V = 7 only with T = 1024 (launch bounds cap it at 128 VGPRs; at
 // T = 256/512 the compiler spends > 160 VGPRs on V = 7).  V = 0 => streaming kernel.
@@ -1270,8 +1353,11 @@ inline void gn_pick(int L4, int &V, int &T) {
 
 // GroupNorm kernel variant bits (tools/kbench.cpp sweeps them; the C ABI uses kGnDefaultVariant):
 //   1 = NT loads/stores, 2 = gamma/beta through LDS, 4 = forward V=7 kernel compiled for 8 waves/SIMD.
+// Measured on MI355X (profiles/r02b_kbench_gn_variants.txt, 256 samples): NT + LC is fastest on 17 of the 20
+// (shape, direction, residual) cases, by 8-21 % over neither; MW8 wins only for the forward without residual
+// (256ch@56x56: 0.270 vs 0.284 ms) and loses with it, so it is applied to that case alone.
 constexpr int kGnNT = 1, kGnLC = 2, kGnMW8 = 4;
-constexpr int kGnDefaultVariant = 0;
+constexpr int kGnDefaultVariant = kGnNT | kGnLC;
 
 #define DP_GN_FWD_VT(V_, T_, NT_, LC_, MW_) \
   hipLaunchKernelGGL((k_gn_relu_fwd<V_, T_, NT_, LC_, MW_>), grid, dim3(T_), 0, st, A, y, mean, rstd)
@@ -1298,7 +1384,7 @@ int launch_gn_fwd(int variant, const GnArgs &A, int N, float *y, float *mean, fl
   else if (T == 256) DP_GN_FWD_FLAGS(4, 256, 1);
   else if (T == 512) DP_GN_FWD_FLAGS(4, 512, 1);
   else if (V == 4) DP_GN_FWD_FLAGS(4, 1024, 1);
-  else if (variant & kGnMW8) DP_GN_FWD_FLAGS(7, 1024, 8);
+  else if ((variant & kGnMW8) || (variant == kGnDefaultVariant && !A.res)) DP_GN_FWD_FLAGS(7, 1024, 8);
   else DP_GN_FWD_FLAGS(7, 1024, 1);
   return launch_status();
 }
@@ -1636,6 +1722,38 @@ int dp_stem_dgrad(const float *dy, const float *w, int N, int K, int Ho, int Wo,
   DP_REQUIRE((reinterpret_cast<uintptr_t>(dx) & 7u) == 0);
   hipLaunchKernelGGL(k_stem_dgrad, dim3(cdiv(Wo, SQ), cdiv(Ho, SQ), N), dim3(kStemBlock), 0,
                      as_stream(stream), dy, w, K, Ho, Wo, dx);
+  return launch_status();
+}
+
+static int subsample_geometry(int64_t NC, int H, int W, bool &wide, long &total) {
+  DP_REQUIRE(NC > 0 && H >= 2 && W >= 2 && (H & 1) == 0 && (W & 1) == 0);
+  wide = (W & 3) == 0;
+  total = NC * (H >> 1) * (wide ? (W >> 2) : (W >> 1));
+  DP_REQUIRE((total + kBlock - 1) / kBlock <= 0x7fffffffL);
+  return 0;
+}
+
+int dp_subsample2(const float *x, int64_t NC, int H, int W, float *y, dp_stream_t stream) {
+  DP_REQUIRE(x && y && aligned16(x) && (reinterpret_cast<uintptr_t>(y) & 7u) == 0);
+  bool wide;
+  long total;
+  const int rc = subsample_geometry(NC, H, W, wide, total);
+  if (rc) return rc;
+  const dim3 grid((unsigned)((total + kBlock - 1) / kBlock));
+  if (wide) hipLaunchKernelGGL((k_subsample2<true>), grid, dim3(kBlock), 0, as_stream(stream), x, H, W, total, y);
+  else hipLaunchKernelGGL((k_subsample2<false>), grid, dim3(kBlock), 0, as_stream(stream), x, H, W, total, y);
+  return launch_status();
+}
+
+int dp_subsample2_add(const float *dy, int64_t NC, int H, int W, float *g, dp_stream_t stream) {
+  DP_REQUIRE(dy && g && aligned16(g) && (reinterpret_cast<uintptr_t>(dy) & 7u) == 0);
+  bool wide;
+  long total;
+  const int rc = subsample_geometry(NC, H, W, wide, total);
+  if (rc) return rc;
+  const dim3 grid((unsigned)((total + kBlock - 1) / kBlock));
+  if (wide) hipLaunchKernelGGL((k_subsample2_add<true>), grid, dim3(kBlock), 0, as_stream(stream), dy, H, W, total, g);
+  else hipLaunchKernelGGL((k_subsample2_add<false>), grid, dim3(kBlock), 0, as_stream(stream), dy, H, W, total, g);
   return launch_status();
 }
 

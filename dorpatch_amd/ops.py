@@ -445,3 +445,79 @@ class StemConvFunction(torch.autograd.Function):
     def backward(ctx, dy):
         (weight,) = ctx.saved_tensors
         return stem_dgrad(dy.contiguous(), weight.contiguous()), None
+
+
+# ---------------------------------------------------------------- a-8: strided 1x1 (downsample) convolutions
+def subsample2_supported(x):
+    return (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.is_contiguous())
+
+
+def subsample2(x):
+    """x[:, :, ::2, ::2] as a dense tensor (even pixels only: what a stride-2 1x1 convolution reads)."""
+    lib = _lib.load()
+    _chk(x, torch.float32, "x")
+    N, C, H, W = x.shape
+    y = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    _lib.check(lib.dp_subsample2(_p(x), N * C, H, W, _p(y), _stream()), "dp_subsample2")
+    return y
+
+
+def subsample2_add_(g, dy):
+    """g[:, :, ::2, ::2] += dy, in place: the adjoint of subsample2 accumulated into an existing gradient."""
+    lib = _lib.load()
+    _chk(g, torch.float32, "g"), _chk(dy, torch.float32, "dy")
+    N, C, H, W = g.shape
+    assert dy.shape == (N, C, H // 2, W // 2)
+    _lib.check(lib.dp_subsample2_add(_p(dy), N * C, H, W, _p(g), _stream()), "dp_subsample2_add")
+    return g
+
+
+class DualConv1x1Function(torch.autograd.Function):
+    """The two frozen 1x1 convolutions that read the pre-activation of a bottleneck's first block —
+    ``conv1`` (stride 1) and ``downsample.conv`` (stride ``s`` in {1, 2}) — as ONE autograd node:
+
+    forward   branch = conv1x1(pre, w1);  shortcut = conv1x1(subsample_s(pre), wd)
+    backward  g = conv1x1_bwd(d_branch, w1);  g[even pixels] += conv1x1_bwd(d_shortcut, wd)   (in place)
+
+    Replaces, per first block of stages 1-3: MIOpen's NCHW<->NHWC transposes of the FULL-resolution
+    activation around its strided kernel, the zero-fill + scatter of the full-resolution gradient, and
+    autograd's accumulation add of the two branch gradients.  The arithmetic is the
+    reference's: a stride-2 1x1 convolution reads exactly the even pixels."""
+
+    @staticmethod
+    def forward(ctx, pre, w1, wd, stride):
+        from . import conv1x1
+        pre = pre.contiguous()
+        branch = conv1x1._run("fwd", pre, w1)
+        small = pre if stride == 1 else subsample2(pre)
+        shortcut = conv1x1._run("fwd", small, wd)
+        # `pre` / `small`: shape references for MIOpen's backward-data only, never re-read
+        ctx.save_for_backward(w1, wd, pre, small if stride != 1 else pre)
+        ctx.stride = stride
+        ctx.set_materialize_grads(False)
+        return branch, shortcut
+
+    @staticmethod
+    def backward(ctx, d_branch, d_short):
+        from . import conv1x1
+        w1, wd, pre, small = ctx.saved_tensors
+        g = None
+        if d_branch is not None:
+            g = conv1x1._run("bwd", d_branch.contiguous(), w1, pre)
+        if d_short is not None:
+            d_short = d_short.contiguous()
+            if ctx.stride == 1:
+                if g is None:
+                    g = conv1x1._run("bwd", d_short, wd, pre)
+                else:       # accumulate inside the GEMM (beta = 1): no separate add pass
+                    N, O, H, W = d_short.shape
+                    C = wd.shape[1]
+                    g.view(N, C, H * W).baddbmm_(wd.view(O, C).t().unsqueeze(0).expand(N, C, O),
+                                                 d_short.view(N, O, H * W))
+            else:
+                gs = conv1x1._run("bwd", d_short, wd, small)
+                if g is None:
+                    g = torch.zeros_like(pre)
+                subsample2_add_(g, gs)
+        return g, None, None, None

@@ -114,12 +114,25 @@ class PreActBottleneck(nn.Module):
         self.norm3 = GroupNormAct(mid)
         self.conv3 = StdConv2d(mid, out_ch, 1)
 
+    def _dual_ok(self, pre):
+        """Frozen, folded first block on fp32 NCHW GPU tensors with the fused kernels enabled."""
+        from . import conv1x1, ops
+        ds, c1 = self.downsample.conv, self.conv1
+        return (GroupNormAct.fused and conv1x1.MODE != "miopen" and ds.folded and c1.folded
+                and not (ds.weight.requires_grad or c1.weight.requires_grad)
+                and ds.stride[0] in (1, 2) and ds.stride[0] == ds.stride[1] and ops.subsample2_supported(pre))
+
     def forward_pair(self, x, res=None):
         """Block input is ``x + res`` (``res`` = the previous block's un-added branch, or None);
         returns this block's ``(branch, shortcut)`` un-added, so the add can fuse into the next norm."""
         x, pre = self.norm1.add_forward(x, res)
-        shortcut = self.downsample(pre) if self.downsample is not None else x
-        out = self.conv1(pre)
+        if self.downsample is not None and self._dual_ok(pre):
+            from . import ops        # conv1 + strided downsample of the same tensor: one autograd node
+            out, shortcut = ops.DualConv1x1Function.apply(pre, self.conv1.weight, self.downsample.conv.weight,
+                                                          self.downsample.conv.stride[0])
+        else:
+            shortcut = self.downsample(pre) if self.downsample is not None else x
+            out = self.conv1(pre)
         out = self.conv2(self.norm2(out))
         out = self.conv3(self.norm3(out))
         return out, shortcut

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DP_ABI_VERSION 2
+#define DP_ABI_VERSION 3
 #define DP_MAX_RECTS 4 /* occlusion windows per mask-table entry */
 
 typedef void *dp_stream_t; /* hipStream_t */
@@ -224,6 +224,20 @@ int dp_pad_maxpool_bwd(const float *dy, const uint8_t *code, int64_t NC, int Hin
  * Direct fp32 gather on the VALU (2*K*147 flop per 2x2 output quad); compute-bound. */
 int dp_stem_dgrad(const float *dy, const float *w, int N, int K, int Ho, int Wo, float *dx,
                   dp_stream_t stream);
+
+/* ---- a-8  stride-2 pixel subsampling around the backbone's strided 1x1 (downsample) convolutions ----
+ * (timm 0.6.7 PreActBottleneck.downsample = StdConv2d(1x1, stride 2), first block of stages 1-3; executed at
+ * reference attack.py:222, 247.)  A 1x1 convolution with stride 2 reads only the even pixels: it IS the
+ * stride-1 1x1 convolution (a GEMM on NCHW memory, dorpatch_amd/conv1x1.py) of the subsampled tensor.
+ * Libraries instead transpose the full-resolution activation to NHWC and back, zero-fill the full-resolution
+ * gradient and scatter into it, and autograd then adds that to the sibling branch's gradient.
+ *   dp_subsample2     y[nc,h,w] = x[nc,2h,2w]                 x (NC,H,W) -> y (NC,H/2,W/2); H, W even
+ *   dp_subsample2_add g[nc,2h,2w] += dy[nc,h,w]  (in place)   the adjoint, accumulated into the gradient the
+ *                     sibling stride-1 branch already produced (replaces zero-fill + scatter + autograd's add)
+ * Traffic: reads the even rows of the large tensor (4 B per output element x 2, half of each line unused),
+ * dp_subsample2_add also writes them back. */
+int dp_subsample2(const float *x, int64_t NC, int H, int W, float *y, dp_stream_t stream);
+int dp_subsample2_add(const float *dy, int64_t NC, int H, int W, float *g, dp_stream_t stream);
 
 /* ---- measurement support (bench.py "roofline"): kernel-precise duration of dp_apply_fwd ----
  * dp_apply_fwd_timed is dp_apply_fwd launched through hipExtLaunchKernelGGL, which stamps `start` /

@@ -55,6 +55,11 @@ def _pool_supported(x):
             and x.shape[2] % 2 == 0 and x.shape[3] % 8 == 0)
 
 
+def _sub_supported(x):
+    return (isinstance(x, torch.Tensor) and x.dtype == torch.float32 and x.dim() == 4
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.is_contiguous())
+
+
 def _stem_supported(x, weight, stride, padding):
     return (isinstance(x, torch.Tensor) and x.dtype == torch.float32 and x.dim() == 4
             and tuple(weight.shape[1:]) == (3, 7, 7) and tuple(stride) == (2, 2) and tuple(padding) == (3, 3)
@@ -66,15 +71,17 @@ def emulated_ops():
     lib = emu_lib()
     assert lib is not None, "no host clang++: cannot build the emulation library"
     saved = dict(lib=_lib._lib, req=ops.require_gpu, chk=ops._chk, stream=ops._stream, gn=ops.gn_relu_supported,
-                 pool=ops.pad_maxpool_supported, stem=ops.stem_dgrad_supported)
+                 pool=ops.pad_maxpool_supported, stem=ops.stem_dgrad_supported, sub=ops.subsample2_supported)
     _lib._lib = lib
     ops._chk = _chk_cpu
     ops.require_gpu = lambda t, what: t
     ops._stream = lambda: None
     ops.gn_relu_supported, ops.pad_maxpool_supported, ops.stem_dgrad_supported = _gn_supported, _pool_supported, _stem_supported
+    ops.subsample2_supported = _sub_supported
     try:
         yield lib
     finally:
         _lib._lib = saved["lib"]
         ops._chk, ops._stream, ops.require_gpu = saved["chk"], saved["stream"], saved["req"]
         ops.gn_relu_supported, ops.pad_maxpool_supported, ops.stem_dgrad_supported = saved["gn"], saved["pool"], saved["stem"]
+        ops.subsample2_supported = saved["sub"]

@@ -466,3 +466,49 @@ def test_stem_dgrad_matches_torch(N, K, H):
     xa = torch.rand(N, 3, H, H, generator=g).to(DEV).requires_grad_(True)
     (ga,) = torch.autograd.grad(ops.StemConvFunction.apply(xa, w.to(DEV)), xa, dy.to(DEV))
     assert torch.equal(ga.cpu().double(), got)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 56, 56), (3, 5, 28, 28), (2, 4, 14, 14), (1, 3, 6, 10)])
+def test_subsample2_and_its_accumulating_adjoint(shape):
+    """dp_subsample2 / dp_subsample2_add vs torch strided slicing (exact: pure data movement + one add)."""
+    N, C, H, W = shape
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.randn(N, C, H, W, generator=g).to(DEV)
+    y = ops.subsample2(x)
+    assert torch.equal(y, x[:, :, ::2, ::2])
+    base = torch.randn(N, C, H, W, generator=g).to(DEV)
+    dy = torch.randn(N, C, H // 2, W // 2, generator=g).to(DEV)
+    want = base.clone()
+    want[:, :, ::2, ::2] += dy
+    got = ops.subsample2_add_(base.clone(), dy)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("stride,N,C,mid,O,H", [(2, 3, 16, 8, 32, 28), (1, 2, 8, 8, 32, 12), (2, 2, 12, 4, 24, 14)])
+def test_dual_conv1x1_matches_two_convolutions(stride, N, C, mid, O, H):
+    """conv1 + (strided) downsample of the same pre-activation as one autograd node: outputs and the summed
+    input gradient equal F.conv2d + autograd (fp32 dot products in another order: rtol 1e-5 of the scale);
+    unused outputs are handled (None gradients)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(stride * 100 + H)
+    pre = torch.randn(N, C, H, H, generator=g).to(DEV)
+    w1 = (torch.randn(mid, C, 1, 1, generator=g) / C ** 0.5).to(DEV)
+    wd = (torch.randn(O, C, 1, 1, generator=g) / C ** 0.5).to(DEV)
+    Ho = H // stride
+    d1, dd = torch.randn(N, mid, H, H, generator=g).to(DEV), torch.randn(N, O, Ho, Ho, generator=g).to(DEV)
+    pr = pre.clone().requires_grad_(True)
+    b_ref, s_ref = F.conv2d(pr, w1), F.conv2d(pr, wd, stride=stride)
+    (g_ref,) = torch.autograd.grad([b_ref, s_ref], pr, [d1, dd])
+    pa = pre.clone().requires_grad_(True)
+    b, s = ops.DualConv1x1Function.apply(pa, w1, wd, stride)
+    (g_got,) = torch.autograd.grad([b, s], pa, [d1, dd])
+    for got, want in ((b, b_ref), (s, s_ref), (g_got, g_ref)):
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-5,
+                                   atol=1e-5 * float(want.detach().abs().max()))
+    # only one of the two outputs used downstream
+    b, s = ops.DualConv1x1Function.apply(pa, w1, wd, stride)
+    (g_b,) = torch.autograd.grad(b, pa, d1)
+    b, s = ops.DualConv1x1Function.apply(pa, w1, wd, stride)
+    (g_s,) = torch.autograd.grad(s, pa, dd)
+    np.testing.assert_allclose((g_b + g_s).cpu().numpy(), g_ref.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(g_ref.abs().max()))
