@@ -161,11 +161,20 @@ class DorPatch(object):
     Extra constructor arguments (all optional, defaults reproduce the reference):
     ``micro_batch`` — max EOT samples per backbone forward/backward (activation
     memory bound); ``process_group`` — a ``torch.distributed`` group whose ranks
-    each hold a replica and process 1/world of the S sampled masks; ``verbose``.
+    each hold a replica and process 1/world of the S sampled masks; ``verbose``;
+    ``deterministic`` (default True) — run the backbone's library convolutions with
+    ``torch.backends.cudnn.deterministic = True`` while ``generate`` runs: at small batches
+    MIOpen otherwise picks split-K implicit-GEMM kernels that accumulate with float atomics
+    (5 of ResNetV2-50's 23 convolution shapes at 8 samples, ``profiles/r02c_determinism_probe.jsonl``),
+    and the optimiser takes ``sign(grad)`` — two runs from identical seeds would drift apart.  With
+    it (and the table-routed 1x1 convolutions, every reduction of the HIP kernels in a fixed order)
+    identical inputs give identical bits.  The reference sets ``cudnn.benchmark = True``
+    (``utils.py:17``) and is not run-to-run reproducible on a GPU.
     """
 
-    def __init__(self, micro_batch=512, process_group=None, verbose=True):
+    def __init__(self, micro_batch=512, process_group=None, verbose=True, deterministic=True):
         self.micro_batch = int(micro_batch)
+        self.deterministic = bool(deterministic)
         self.pg = process_group
         self.verbose = verbose
         self.criterion = None
@@ -346,6 +355,9 @@ class HotLoop(object):
         self._frozen = [(p, p.requires_grad) for p in self.net.parameters()]
         for p, _ in self._frozen:
             p.requires_grad_(False)
+        self._cudnn_det = torch.backends.cudnn.deterministic
+        if owner.deterministic:
+            torch.backends.cudnn.deterministic = True
 
         owner.criterion = CW_loss(n_classes, targeted, confidence)     # attack.py:57
         # attack.py:59-60 — CPU generator, mask first then pattern
@@ -427,6 +439,7 @@ class HotLoop(object):
     def close(self):
         for p, flag in self._frozen:
             p.requires_grad_(flag)
+        torch.backends.cudnn.deterministic = self._cudnn_det
 
     def _forward_plain(self, imgs):
         """model(imgs) for un-occluded images in [0,1] (NormModel applied if it was peeled)."""

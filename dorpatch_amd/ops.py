@@ -391,6 +391,8 @@ def pad_maxpool_fwd(x):
 def pad_maxpool_bwd(dy, code, H, W):
     lib = _lib.load()
     _chk(dy, torch.float32, "dy"), _chk(code, torch.uint8, "code")
+    if dy.data_ptr() % 16:          # a dense view at an odd storage offset: the kernel reads dy in 16-byte words
+        dy = dy.clone()
     N, C = dy.shape[0], dy.shape[1]
     dx = torch.empty((N, C, H, W), dtype=torch.float32, device=dy.device)
     _lib.check(lib.dp_pad_maxpool_bwd(_p(dy), _p(code), N * C, H, W, _p(dx), _stream()), "dp_pad_maxpool_bwd")

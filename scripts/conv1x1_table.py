@@ -35,16 +35,30 @@ def shapes(size):
     return out
 
 
+def downsample_shapes(size):
+    """The strided downsample convolutions as DualConv1x1Function runs them: stride-1 1x1 on the subsampled
+    pre-activation, (C_in, C_out, HW_out) for stages 1-3."""
+    hw = (size // 4) ** 2
+    return {(256, 512, hw // 4): 1, (512, 1024, hw // 16): 1, (1024, 2048, hw // 64): 1}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=512)
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--find", type=int, default=0, help="1: MIOpen exhaustive find for the MIOpen route")
+    ap.add_argument("--blas", default="default", help="torch.backends.cuda.preferred_blas_library: default | hipblaslt | cublas (= rocBLAS)")
+    ap.add_argument("--only-downsample", action="store_true")
     args = ap.parse_args()
+    if args.blas != "default":
+        torch.backends.cuda.preferred_blas_library(args.blas)
     torch.backends.cudnn.benchmark = bool(args.find)
     conv1x1.MODE = "auto"
     dev = torch.device("cuda", 0)
-    todo = sorted(shapes(args.size).items(), key=lambda kv: -kv[1] * kv[0][0] * kv[0][1] * kv[0][2])
+    todo = {} if args.only_downsample else dict(shapes(args.size))
+    for k, v in downsample_shapes(args.size).items():
+        todo.setdefault(k, v)
+    todo = sorted(todo.items(), key=lambda kv: -kv[1] * kv[0][0] * kv[0][1] * kv[0][2])
     for (C, O, HW), mult in todo:
         H = int(round(HW ** 0.5))
         w = torch.randn(O, C, 1, 1, device=dev) / C ** 0.5

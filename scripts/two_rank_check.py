@@ -1,0 +1,93 @@
+#!/usr/bin/env python
+"""The product's sample-sharded step on REAL kernels with 2 ranks, runnable on a 1-GPU box:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 \
+        scripts/two_rank_check.py [--backend gloo]
+
+Both ranks use cuda:0 (gloo moves the all-reduce through the host; with `--backend nccl` and 2 GPUs it is
+RCCL).  Each rank runs HotLoop.step with the process group (S = 16 masks per image, 8 per rank, B = 4 images,
+ResNetV2-50x1-BiT, 224x224, well-conditioned weights so that the S-summation order is the only difference),
+then rank 0 repeats the same step unsharded and compares: identical mask draws, loss columns in sample order,
+the all-reduced patch gradient against the unsharded one, bit-identical state on both ranks.
+Prints one JSON line (rank 0)."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", default="gloo")
+    ap.add_argument("--steps", type=int, default=3)
+    args = ap.parse_args()
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dev = torch.device("cuda", 0 if args.backend == "gloo" else int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(args.backend)
+    pg = dist.group.WORLD
+    from dorpatch_amd.attack import DorPatch, HotLoop
+    from dorpatch_amd.resnetv2 import WELL_CONDITIONED_GN_BIAS, resnetv2_50x1_bit, seeded_init_
+    from dorpatch_amd.utils import NormModel, get_normalize
+    B, S, H = 4, 16, 224
+    net = seeded_init_(resnetv2_50x1_bit(1000), gn_bias=WELL_CONDITIONED_GN_BIAS).fold_weight_standardization().freeze()
+    model = NormModel(net, get_normalize("imagenet", "resnetv2")).to(dev).eval()
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(B, 3, H, H, generator=g).to(dev)
+    m0, p0 = torch.rand(B, 1, H, H, generator=g), torch.rand(B, 3, H, H, generator=g)
+    y = torch.randint(0, 1000, (B,), generator=g).to(dev)
+
+    def run(group, seed):
+        np.random.seed(seed + (0 if group is None else rank * 1000))   # sharded: ranks start from DIFFERENT states
+        seen = []
+        hook = lambda d: seen.append(dict(idx=d["idx"].copy(), loss_adv=d["loss_adv"].copy(), g_adv=d["g_adv"].clone(),
+                                          pattern=d["pattern"].clone()))
+        loop = HotLoop(DorPatch(process_group=group, verbose=False), model, x, 0.0204, 1000, "chk/cfg/sub", 0, y, True,
+                       1e-2, 1e-1, 0, 1, 10 ** 6, 7, 'topk', 2, S, 1e-3, 1e-3, 4.0, False,
+                       dict(init_mask=m0, init_pattern=p0, failure_refresh=10 ** 9, step_hook=hook))
+        for i in range(1, args.steps + 1):
+            loop.step(i)
+        torch.cuda.synchronize()
+        out = dict(seen=seen, pattern=loop.adv_pattern.clone(), mask=loop.adv_mask.clone(), s_local=loop.S_local)
+        loop.close()
+        return out
+
+    sharded = run(pg, 5)
+    # bit-identical state on both ranks after the sharded steps
+    mine = torch.cat([sharded["pattern"].reshape(-1), sharded["mask"].reshape(-1)]).cpu()
+    both = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    lockstep = all(torch.equal(both[0], t) for t in both[1:])
+    if rank == 0:
+        # rank 0's generator state was the one broadcast: replay it unsharded
+        single = run(None, 5)
+        rep = dict(world=world, backend=args.backend, B=B, S=S, s_local=sharded["s_local"], steps=args.steps,
+                   ranks_bit_identical=bool(lockstep), idx_equal=[], loss_adv_max_abs_diff=[], g_adv_rel_l2=[],
+                   g_adv_max_err_over_scale=[])
+        for a, w in zip(sharded["seen"], single["seen"]):
+            rep["idx_equal"].append(bool(np.array_equal(a["idx"], w["idx"])))
+            rep["loss_adv_max_abs_diff"].append(float(np.abs(a["loss_adv"] - w["loss_adv"]).max()))
+            ga, gw = a["g_adv"].double().cpu(), w["g_adv"].double().cpu()
+            rep["g_adv_rel_l2"].append(float((ga - gw).norm() / gw.norm()))
+            rep["g_adv_max_err_over_scale"].append(float((ga - gw).abs().max() / gw.abs().max()))
+        rep["updated_pixels_differing"] = float(((sharded["pattern"] - single["pattern"]).abs() > 1e-6).float().mean())
+        ok = rep["ranks_bit_identical"] and all(rep["idx_equal"]) and rep["g_adv_rel_l2"][0] < 1e-4
+        rep["ok"] = bool(ok)
+        print(json.dumps(rep), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,29 @@ __global__ __launch_bounds__(256) void k_copy(const f4 *__restrict__ in, f4 *__r
     __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
 }
 
+// write-only fill with the gfx950 store flavours (MI355X_MICROARCH.md, "stores of each flavour"): which one gives the
+// best pure-write HBM rate?  F: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 nt sc1, 5 nt sc0 sc1.  One WG per 32 KiB.
+template <int F>
+__device__ __forceinline__ void store_flavour(f4 *p, f4 v) {
+  if (F == 0) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+  if (F == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+  if (F == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  if (F == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  if (F == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory");
+  if (F == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+}
+
+template <int F>
+__global__ __launch_bounds__(256) void k_fill_flavour(f4 *__restrict__ out, size_t n4, float v) {
+  const f4 val = {v, v, v, v};
+  const size_t base = (size_t)blockIdx.x * 2048;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const size_t i = base + (size_t)u * 256 + threadIdx.x;
+    if (i < n4) store_flavour<F>(out + i, val);
+  }
+}
+
 // U independent 16-B loads in flight per lane before the first store (block-contiguous chunks of U KiB per wave)
 template <int U, bool NT>
 __global__ __launch_bounds__(256) void k_copy_u(const f4 *__restrict__ in, f4 *__restrict__ out, size_t n4) {
@@ -200,6 +223,15 @@ int main(int argc, char **argv) {
   // ---- calibration: what this box's HBM does for the same footprint
   bench("calib: fill (write-only)", out_bytes, iters, st,
         [&] { hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, st, (f4 *)big, n4_big, 1.f); });
+  {
+    const unsigned gb = (unsigned)((n4_big + 2047) / 2048);
+    bench("calib: fill 32KiB/WG plain", out_bytes, iters, st, [&] { hipLaunchKernelGGL((k_fill_flavour<0>), dim3(gb), dim3(256), 0, st, (f4 *)big, n4_big, 1.f); });
+    bench("calib: fill 32KiB/WG nt", out_bytes, iters, st, [&] { hipLaunchKernelGGL((k_fill_flavour<1>), dim3(gb), dim3(256), 0, st, (f4 *)big, n4_big, 1.f); });
+    bench("calib: fill 32KiB/WG sc1", out_bytes, iters, st, [&] { hipLaunchKernelGGL((k_fill_flavour<2>), dim3(gb), dim3(256), 0, st, (f4 *)big, n4_big, 1.f); });
+    bench("calib: fill 32KiB/WG sc0 sc1", out_bytes, iters, st, [&] { hipLaunchKernelGGL((k_fill_flavour<3>), dim3(gb), dim3(256), 0, st, (f4 *)big, n4_big, 1.f); });
+    bench("calib: fill 32KiB/WG sc1 nt", out_bytes, iters, st, [&] { hipLaunchKernelGGL((k_fill_flavour<4>), dim3(gb), dim3(256), 0, st, (f4 *)big, n4_big, 1.f); });
+    bench("calib: fill 32KiB/WG sc0 sc1 nt", out_bytes, iters, st, [&] { hipLaunchKernelGGL((k_fill_flavour<5>), dim3(gb), dim3(256), 0, st, (f4 *)big, n4_big, 1.f); });
+  }
   bench("calib: read-sum (read-only)", out_bytes, iters, st,
         [&] { hipLaunchKernelGGL(k_readsum, dim3(2048), dim3(256), 0, st, (const f4 *)big2, loss, n4_big); });
   bench("calib: copy (read+write)", 2 * out_bytes, iters, st,
