@@ -235,6 +235,57 @@ __global__ __launch_bounds__(kBlock) void k_apply_fwd(
   }
 }
 
+// Channel-split variant: grid z = image * 3 + channel, a workgroup owns kBlock * G consecutive float4 groups of ONE
+// channel plane and streams, per sample, G * 4 KiB of contiguous output (G = 7: 28 KiB; 12544 groups per 224 x 224
+// plane = 7 tiles exactly).  Rationale (profiles/r02d_kbench_calibration_store_flavours.txt): a write-only stream
+// reaches 5.6-5.7 TB/s on this GPU when every workgroup writes one contiguous 32 KiB run, 4.2 TB/s when workgroups
+// interleave 4 KiB pieces; the store flavour (plain / nt / sc1 ...) moves it by < 3 %.
+template <int G, bool NT>
+__global__ __launch_bounds__(kBlock) void k_apply_fwd_ch(
+    const float *__restrict__ adv_x, const int32_t *__restrict__ table, int R,
+    const int32_t *__restrict__ idx, const int32_t *__restrict__ idx2, int idx_bstride,
+    int S, int H, int W, int s_per_block, NormDev nd, float *__restrict__ out) {
+  const int P = H * W, P4 = P >> 2;
+  const int g0 = blockIdx.x * (kBlock * G) + threadIdx.x;
+  const int b = blockIdx.z / 3, c = blockIdx.z - 3 * b;
+  const int s_begin = blockIdx.y * s_per_block;
+  const int s_end = min(S, s_begin + s_per_block);
+  const f4 *src = reinterpret_cast<const f4 *>(adv_x + ((size_t)b * 3 + c) * P);
+  const float mean = nd.mean[c], stdv = nd.std[c], fill = nd.fill[c];
+  f4 v[G];
+  int hh[G], ww[G];
+#pragma unroll
+  for (int k = 0; k < G; ++k) {
+    const int g = g0 + k * kBlock;
+    const int gc = g < P4 ? g : P4 - 1;
+    const int pix = gc << 2;
+    hh[k] = pix / W;
+    ww[k] = pix - hh[k] * W;
+    f4 t = src[gc];
+    if (nd.enable) t = (t - mean) / stdv;  // reference NormModel: true division
+    v[k] = t;
+  }
+  const int32_t *ib = idx + (size_t)b * idx_bstride;
+  const int32_t *ib2 = idx2 ? idx2 + (size_t)b * idx_bstride : nullptr;
+  f4 *dst = reinterpret_cast<f4 *>(out + (((size_t)b * S + s_begin) * 3 + c) * P);
+  for (int s = s_begin; s < s_end; ++s) {
+    const int m1 = ib[s];
+    const int m2 = ib2 ? ib2[s] : -1;
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const int g = g0 + k * kBlock;
+      unsigned occ = occluded4(table, R, m1, hh[k], ww[k]);
+      if (m2 >= 0) occ |= occluded4(table, R, m2, hh[k], ww[k]);
+      const f4 o = select4(occ, v[k], fill);
+      if (g < P4) {
+        if (NT) __builtin_nontemporal_store(o, dst + g);
+        else dst[g] = o;
+      }
+    }
+    dst += 3 * P4;
+  }
+}
+
 // grid: x = float4-group tiles, y = S-slab, z = image.  Reads G once, skips the
 // 16 B of fully occluded groups, reduces over the slab's samples in s order.
 __global__ __launch_bounds__(kBlock) void k_apply_bwd(
@@ -1051,17 +1102,20 @@ __global__ __launch_bounds__(kGnStreamT) void k_gn_relu_bwd_stream(
 // Requires Hin even, Win % 8 == 0 (so an output row is whole float4s and no bottom/right pad).
 // ----------------------------------------------------------------------------
 
-__global__ __launch_bounds__(kBlock) void k_pad_maxpool_fwd(const float *__restrict__ x, int Hin,
-                                                            int Win, long total /* NC*Ho*Wo/4 */,
-                                                            float *__restrict__ y,
-                                                            uint32_t *__restrict__ code4) {
-  const long tid = (long)blockIdx.x * kBlock + threadIdx.x;
-  if (tid >= total) return;
+// Launch geometry of both pooling kernels: blockDim (16, 16), grid (NC, rows / 16): a thread's plane, row and
+// 8-pixel column group come straight from the block / thread indices.  (A flat 1-D index needs two 64-bit
+// divisions per thread, which made these kernels instruction-bound: ~550 instructions per 32 bytes stored.)
+constexpr int kPoolTX = 16, kPoolTY = 16;
+
+__global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_fwd(const float *__restrict__ x, int Hin,
+                                                                       int Win, float *__restrict__ y,
+                                                                       uint32_t *__restrict__ code4) {
   const int Ho = Hin >> 1, Wq = Win >> 3;  // Wo/4 quads per output row
-  const int q = (int)(tid % Wq);
-  const long t2 = tid / Wq;
-  const int oh = (int)(t2 % Ho);
-  const long nc = t2 / Ho;
+  const int oh = blockIdx.y * kPoolTY + threadIdx.y;
+  if (oh >= Ho) return;
+  const long nc = blockIdx.x;
+  for (int q = threadIdx.x; q < Wq; q += kPoolTX) {
+  const long tid = (nc * Ho + oh) * Wq + q;
   const float *xp = x + nc * (long)Hin * Win;
   float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   unsigned code[4] = {0u, 0u, 0u, 0u};
@@ -1094,24 +1148,23 @@ __global__ __launch_bounds__(kBlock) void k_pad_maxpool_fwd(const float *__restr
   }
   reinterpret_cast<f4 *>(y)[tid] = f4{best[0], best[1], best[2], best[3]};
   code4[tid] = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+  }
 }
 
 // One thread = 8 consecutive input pixels of one row (two float4 stores).  They are covered by the 5 windows
 // ow = 4t .. 4t + 4 of each of the (1 or 2) output rows whose window contains the input row: per output row one
 // aligned float4 of dy + one aligned 4-byte word of codes + the halo element of each (3x fewer memory
 // instructions per byte than a thread per float4 with scalar dy / byte-wide code loads).
-__global__ __launch_bounds__(kBlock) void k_pad_maxpool_bwd(const float *__restrict__ dy,
-                                                            const uint8_t *__restrict__ code,
-                                                            int Hin, int Win,
-                                                            long total /* NC*Hin*Win/8 */,
-                                                            float *__restrict__ dx) {
-  const long tid = (long)blockIdx.x * kBlock + threadIdx.x;
-  if (tid >= total) return;
+__global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_bwd(const float *__restrict__ dy,
+                                                                       const uint8_t *__restrict__ code,
+                                                                       int Hin, int Win,
+                                                                       float *__restrict__ dx) {
   const int Ho = Hin >> 1, Wo = Win >> 1, W8 = Win >> 3;
-  const int t = (int)(tid % W8);
-  const long t2 = tid / W8;
-  const int h = (int)(t2 % Hin);
-  const long nc = t2 / Hin;
+  const int h = blockIdx.y * kPoolTY + threadIdx.y;
+  if (h >= Hin) return;
+  const long nc = blockIdx.x;
+  for (int t = threadIdx.x; t < W8; t += kPoolTX) {
+  const long tid = (nc * Hin + h) * W8 + t;
   const float *dyp = dy + nc * (long)Ho * Wo;
   const uint8_t *cp = code + nc * (long)Ho * Wo;
   float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1143,6 +1196,7 @@ __global__ __launch_bounds__(kBlock) void k_pad_maxpool_bwd(const float *__restr
   f4 *dst = reinterpret_cast<f4 *>(dx) + 2 * tid;
   __builtin_nontemporal_store(f4{o[0], o[1], o[2], o[3]}, dst);
   __builtin_nontemporal_store(f4{o[4], o[5], o[6], o[7]}, dst + 1);
+  }
 }
 
 
@@ -1433,8 +1487,30 @@ int launch_apply_fwd(int variant, const float *adv_x, const int32_t *table, int 
                      hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
   const int G = variant & 7;
   const bool nt = (variant & 8) != 0;
-  DP_REQUIRE(G == 1 || G == 2 || G == 4);
   const int P4 = (H * W) >> 2;
+  if (variant & 16) {  // channel-split kernel: G in {4, 7} float4 groups of one channel per thread
+    DP_REQUIRE((G == 4 || G == 7) && B <= 65535 / 3);
+    const int tiles = cdiv(P4, kBlock * G);
+    int nchunk = cdiv(2048, tiles * B * 3);
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > S) nchunk = S;
+    const int s_per_block = cdiv(S, nchunk);
+    nchunk = cdiv(S, s_per_block);
+    DP_REQUIRE(nchunk <= 65535);
+    const dim3 grid(tiles, nchunk, B * 3), block(kBlock);
+    const NormDev nd = make_norm(norm);
+    hipStream_t st = as_stream(stream);
+#define DP_LAUNCH_FWD_CH(G_, NT_)                                                                       \
+  hipExtLaunchKernelGGL((k_apply_fwd_ch<G_, NT_>), grid, block, 0, st, ev_start, ev_stop, 0, adv_x, table, \
+                        R, idx, idx2, idx_bstride, S, H, W, s_per_block, nd, out)
+    if (G == 4 && nt) DP_LAUNCH_FWD_CH(4, true);
+    else if (G == 4) DP_LAUNCH_FWD_CH(4, false);
+    else if (nt) DP_LAUNCH_FWD_CH(7, true);
+    else DP_LAUNCH_FWD_CH(7, false);
+#undef DP_LAUNCH_FWD_CH
+    return launch_status();
+  }
+  DP_REQUIRE(G == 1 || G == 2 || G == 4);
   const int tiles = cdiv(P4, kBlock * G);
   // >= ~2048 workgroups (8 per CU) so the store stream covers all 8 XCDs evenly
   int nchunk = cdiv(2048, tiles * B);
@@ -1700,11 +1776,10 @@ int dp_pad_maxpool_fwd(const float *x, int64_t NC, int Hin, int Win, float *y, u
                        dp_stream_t stream) {
   DP_REQUIRE(x && y && code && aligned16(x) && aligned16(y) && aligned16(code));
   DP_REQUIRE(NC > 0 && Hin >= 2 && Win >= 8 && (Hin & 1) == 0 && (Win & 7) == 0);
-  const long total = NC * (Hin >> 1) * (Win >> 3);
-  const long blocks = (total + kBlock - 1) / kBlock;
-  DP_REQUIRE(blocks <= 0x7fffffffL);
-  hipLaunchKernelGGL(k_pad_maxpool_fwd, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), x,
-                     Hin, Win, total, y, reinterpret_cast<uint32_t *>(code));
+  DP_REQUIRE(NC <= 0x7fffffffL);
+  const dim3 grid((unsigned)NC, (unsigned)cdiv(Hin >> 1, kPoolTY));
+  hipLaunchKernelGGL(k_pad_maxpool_fwd, grid, dim3(kPoolTX, kPoolTY), 0, as_stream(stream), x, Hin, Win, y,
+                     reinterpret_cast<uint32_t *>(code));
   return launch_status();
 }
 
@@ -1712,11 +1787,9 @@ int dp_pad_maxpool_bwd(const float *dy, const uint8_t *code, int64_t NC, int Hin
                        dp_stream_t stream) {
   DP_REQUIRE(dy && dx && code && aligned16(dx) && aligned16(dy) && (reinterpret_cast<uintptr_t>(code) & 3u) == 0);
   DP_REQUIRE(NC > 0 && Hin >= 2 && Win >= 8 && (Hin & 1) == 0 && (Win & 7) == 0);
-  const long total = NC * Hin * (Win >> 3);
-  const long blocks = (total + kBlock - 1) / kBlock;
-  DP_REQUIRE(blocks <= 0x7fffffffL);
-  hipLaunchKernelGGL(k_pad_maxpool_bwd, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), dy,
-                     code, Hin, Win, total, dx);
+  DP_REQUIRE(NC <= 0x7fffffffL);
+  const dim3 grid((unsigned)NC, (unsigned)cdiv(Hin, kPoolTY));
+  hipLaunchKernelGGL(k_pad_maxpool_bwd, grid, dim3(kPoolTX, kPoolTY), 0, as_stream(stream), dy, code, Hin, Win, dx);
   return launch_status();
 }
 

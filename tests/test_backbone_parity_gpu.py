@@ -91,7 +91,8 @@ def test_step_through_resnetv2_matches_fp64_oracle(stage):
     want = _oracle(model, x, mask, pattern, y, idx, stage, torch.float64)
     got = _product(model, x, mask, pattern, y, idx, stage)
     assert (want["loss_adv"] > 0).all()                        # every sample's margin is active: all 8 carry gradient
-    np.testing.assert_allclose(got["loss_adv"].reshape(-1), want["loss_adv"].numpy().reshape(-1), rtol=2e-5, atol=2e-6)
+    # the margin is a difference of two fp32 logits of magnitude ~5: a few 1e-5 absolute
+    np.testing.assert_allclose(got["loss_adv"].reshape(-1), want["loss_adv"].numpy().reshape(-1), rtol=1e-4, atol=5e-5)
     np.testing.assert_allclose(got["loss_struc"], want["loss_struc"].numpy(), rtol=2e-5)
     names = ["grad_pattern"] + (["grad_mask"] if stage == 0 else [])
     for name in names:

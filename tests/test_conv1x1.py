@@ -72,12 +72,13 @@ def test_backbone_uses_it_only_for_frozen_folded_1x1_stride1_gpu_tensors():
 
 def test_default_is_the_committed_table_and_it_is_deterministic():
     """no timing race decides which kernel runs.  The table lists every stride-1 1x1
-    shape of ResNetV2-50 at 224x224, both directions; anything else goes to MIOpen."""
+    shape of ResNetV2-50 at 224x224 (incl. the subsampled downsample convolutions of DualConv1x1Function), both
+    directions; anything else goes to MIOpen."""
     import importlib
     import os
     assert os.environ.get("DORPATCH_CONV1X1") is None and importlib.reload(conv1x1).MODE == "table"
-    from scripts.conv1x1_table import shapes
-    want = {(d, C, O, HW) for (C, O, HW) in shapes(224) for d in ("fwd", "bwd")}
+    from scripts.conv1x1_table import downsample_shapes, shapes
+    want = {(d, C, O, HW) for (C, O, HW) in list(shapes(224)) + list(downsample_shapes(224)) for d in ("fwd", "bwd")}
     assert set(conv1x1.TABLE) == want and set(conv1x1.TABLE.values()) <= {"gemm", "miopen"}
     w = torch.randn(256, 64, 1, 1)
     x = torch.randn(2, 64, 56, 56)

@@ -98,6 +98,13 @@ __global__ __launch_bounds__(256) void k_copy_u(const f4 *__restrict__ in, f4 *_
   }
 }
 
+__global__ __launch_bounds__(256) void k_count_diff(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, size_t n,
+                                                    int *__restrict__ count) {
+  int local = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) local += a[i] != b[i];
+  if (local) atomicAdd(count, local);
+}
+
 __global__ __launch_bounds__(256) void k_readsum(const f4 *__restrict__ in, float *__restrict__ out, size_t n4) {
   f4 acc = {0.f, 0.f, 0.f, 0.f};
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
@@ -255,12 +262,28 @@ int main(int argc, char **argv) {
   // ---- a-4 forward / backward
   bench("dp_apply_fwd (default variant)", out_bytes + (double)B * img, iters, st,
         [&] { DP(dp_apply_fwd(adv, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, big, st)); });
-  for (int variant : {1, 2, 4, 9, 10, 12}) {
+  for (int variant : {1, 2, 4, 9, 10, 12, 16 + 4, 16 + 7, 16 + 8 + 4, 16 + 8 + 7}) {
     char name[64];
-    snprintf(name, sizeof name, "  k_apply_fwd<G=%d,NT=%d>", variant & 7, variant >> 3);
+    snprintf(name, sizeof name, "  k_apply_fwd%s<G=%d,NT=%d>", (variant & 16) ? "_ch" : "", variant & 7, (variant >> 3) & 1);
     bench(name, out_bytes + (double)B * img, iters, st, [&] {
       DP(launch_apply_fwd(variant, adv, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, big, st));
     });
+  }
+  if (!g_filter || strstr("k_apply_fwd check", g_filter) || strstr(g_filter, "apply_fwd")) {
+    // every variant must produce the default variant's bytes
+    int *d_diff = (int *)dmalloc(4);
+    DP(dp_apply_fwd(adv, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, big, st));
+    for (int variant : {2, 12, 16 + 4, 16 + 7, 16 + 8 + 4, 16 + 8 + 7}) {
+      CK(hipMemsetAsync(d_diff, 0, 4, st));
+      DP(launch_apply_fwd(variant, adv, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, big2, st));
+      hipLaunchKernelGGL(k_count_diff, dim3(2048), dim3(256), 0, st, (const uint32_t *)big, (const uint32_t *)big2,
+                         (size_t)N * 3 * P, d_diff);
+      int h_diff = -1;
+      CK(hipMemcpyAsync(&h_diff, d_diff, 4, hipMemcpyDeviceToHost, st));
+      CK(hipStreamSynchronize(st));
+      printf("  k_apply_fwd check: variant %2d vs default: %d differing words\n", variant, h_diff);
+    }
+    hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, st, (f4 *)big2, n4_big, 0.25f);
   }
   bench("dp_apply_bwd (+dp_sum_slabs)", out_bytes + (double)B * img, iters, st, [&] {
     DP(dp_apply_bwd(big2, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, nslab == 1 ? g_adv : slabs, st));
