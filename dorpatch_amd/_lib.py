@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
-DP_ABI_VERSION = 3
+DP_ABI_VERSION = 4
 DP_MAX_RECTS = 4
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
@@ -63,6 +63,7 @@ PROTOTYPES = {
     "dp_pad_maxpool_fwd": (_I, [_P, _L, _I, _I, _P, _P, _P]),
     "dp_pad_maxpool_bwd": (_I, [_P, _P, _L, _I, _I, _P, _P]),
     "dp_stem_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "dp_stem_dgrad_reduce": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, ctypes.POINTER(DpNorm), _P, _P]),
     "dp_subsample2": (_I, [_P, _L, _I, _I, _P, _P]),
     "dp_subsample2_add": (_I, [_P, _L, _I, _I, _P, _P]),
     "dp_event_create": (_I, [ctypes.POINTER(ctypes.c_void_p)]),

@@ -201,7 +201,8 @@ class DorPatch(object):
         ``init_pattern`` (override the ``torch.rand`` init), ``rngs`` (one legacy
         ``np.random.RandomState`` per image), ``step_hook`` (callable receiving a dict
         of per-step internals — used by the parity tests), ``switch_iteration`` (500),
-        ``failure_refresh`` (100), ``failure_sampling_start`` (1000), ``log_every`` (20).
+        ``failure_refresh`` (100), ``failure_sampling_start`` (1000), ``log_every`` (20), ``stem_split`` (True: with
+        dorpatch_amd's own ResNetV2 the stem's input gradient and the S-reduction run as one kernel).
         """
         run = HotLoop(self, model, x, patch_budget, n_classes, save_dir, batch_id, y, targeted, lr,
                       confidence, clip_min, clip_max, max_iterations, basic_unit, selection, dropout,
@@ -434,6 +435,11 @@ class HotLoop(object):
         self.samples_done = 0
         self.kernel_events = None
         self._conv_shared = False
+        # dorpatch_amd's own ResNetV2 with a frozen stem: the backward stops at the stem-convolution OUTPUT and
+        # dp_stem_dgrad_reduce turns that gradient into the S-reduced patch gradient in one launch (the per-sample
+        # (N,3,H,W) input gradient is never written); any other model: autograd down to the input + dp_apply_bwd
+        probe = getattr(self.net, "stem_split_supported", None)
+        self._stem_split = bool(probe is not None and extras.get("stem_split", True) and probe(self.x))
 
     # ---------------------------------------------------------------- plumbing
     def close(self):
@@ -723,8 +729,8 @@ class HotLoop(object):
                 b1 = min(B, b0 + ipm)
                 G = self._fb_chunk(inp_all[b0 * Sl:b1 * Sl], self.y[b0:b1], crit_flags[b0:b1], Sl,
                                    upstream, loss_flat[b0 * Sl:b1 * Sl], self.pred[b0 * Sl:b1 * Sl])
-                ops.apply_bwd(G, self.table, idx[b0:b1], None if idx2 is None else idx2[b0:b1],
-                              self.dn, B=b1 - b0, out=self.g_adv[b0:b1])
+                self._reduce_over_samples(G, idx[b0:b1], None if idx2 is None else idx2[b0:b1], b1 - b0,
+                                          self.g_adv[b0:b1], False)
         else:
             for b in range(B):
                 for k, s0 in enumerate(range(0, Sl, mb)):
@@ -732,15 +738,27 @@ class HotLoop(object):
                     n0, n1 = b * Sl + s0, b * Sl + s1
                     G = self._fb_chunk(inp_all[n0:n1], self.y[b:b + 1], crit_flags[b:b + 1], s1 - s0,
                                        upstream, loss_flat[n0:n1], self.pred[n0:n1])
-                    ops.apply_bwd(G, self.table, idx[b:b + 1, s0:s1].contiguous(),
-                                  None if idx2 is None else idx2[b:b + 1, s0:s1].contiguous(),
-                                  self.dn, B=1, out=self.g_adv[b:b + 1], accumulate=(k > 0))
+                    self._reduce_over_samples(G, idx[b:b + 1, s0:s1].contiguous(),
+                                              None if idx2 is None else idx2[b:b + 1, s0:s1].contiguous(), 1,
+                                              self.g_adv[b:b + 1], k > 0)
         self._own_pred.copy_(self.pred)            # int32 -> fp32 (class ids are exact), rides in the same buffer
 
+    def _reduce_over_samples(self, G, idx, idx2, B, out, accumulate):
+        """sum_S keep * d loss/d masked-input (/ std) -> d loss/d adv_x for B images (autograd of attack.py:206-220)."""
+        if self._stem_split:     # G = d loss / d stem-conv output: stem input gradient + S-reduction in one launch
+            ops.stem_dgrad_reduce(G, self.net.stem.conv.weight, self.table, idx, idx2, self.dn, B=B, out=out,
+                                  accumulate=accumulate)
+        else:
+            ops.apply_bwd(G, self.table, idx, idx2, self.dn, B=B, out=out, accumulate=accumulate)
+
     def _fb_chunk(self, inp, y, flags, S_chunk, upstream, loss_out, pred_out):
+        if self._stem_split:
+            conv = self.net.stem.conv
+            with torch.no_grad():
+                inp = torch.nn.functional.conv2d(inp, conv.weight, None, conv.stride, conv.padding)
         inp = inp.detach().requires_grad_(True)
         with torch.enable_grad():
-            logits = self.net(inp)
+            logits = self.net.forward_after_stem_conv(inp) if self._stem_split else self.net(inp)
         lg = logits.detach().float().contiguous()
         _, dlogits, pred = ops.cw_loss(lg, y.contiguous(), flags.contiguous(), S_chunk, self.confidence,
                                        upstream, loss_out=loss_out)

@@ -1102,10 +1102,10 @@ __global__ __launch_bounds__(kGnStreamT) void k_gn_relu_bwd_stream(
 // Requires Hin even, Win % 8 == 0 (so an output row is whole float4s and no bottom/right pad).
 // ----------------------------------------------------------------------------
 
-// Launch geometry of both pooling kernels: blockDim (16, 16), grid (NC, rows / 16): a thread's plane, row and
+// Launch geometry of both pooling kernels: blockDim (16, 8), grid (NC, rows / 8): a thread's plane, row and
 // 8-pixel column group come straight from the block / thread indices.  (A flat 1-D index needs two 64-bit
 // divisions per thread, which made these kernels instruction-bound: ~550 instructions per 32 bytes stored.)
-constexpr int kPoolTX = 16, kPoolTY = 16;
+constexpr int kPoolTX = 16, kPoolTY = 8;   // 8 rows: 56 and 112 are multiples (a 16-row block idles 1/8 of the forward)
 
 __global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_fwd(const float *__restrict__ x, int Hin,
                                                                        int Win, float *__restrict__ y,
@@ -1330,6 +1330,166 @@ __global__ __launch_bounds__(kStemBlock) void k_stem_dgrad(const float *__restri
         o.x = acc[u][c][ph][0];
         o.y = acc[u][c][ph][1];
         *reinterpret_cast<float2 *>(dxn + ((size_t)c * H + 2 * a + ph) * W + 2 * b) = o;
+      }
+  }
+}
+
+// ----------------------------------------------------------------------------
+// a-8 + a-4 backward, fused: the stem input gradient of every EOT sample of an image, occlusion-masked and summed
+// over the samples in the same launch (k_stem_dgrad followed by k_apply_bwd, without the (N,3,H,W) per-sample
+// gradient ever reaching HBM: 602 112 B written + read per sample @224 saved, reference attack.py:247 through
+// the autograd of attack.py:206-220).  grid z = image * nslab + slab; a workgroup walks the slab's samples in
+// ascending order, runs k_stem_dgrad's channel loop for each (the dy planes of consecutive samples are
+// consecutive in memory, so the staging pipeline runs straight through), then adds the sample's 24 per-thread
+// results into the image accumulators where the pixel is not occluded.  Arithmetic and summation order are
+// exactly those of the two separate kernels (same slab partition): results are bit-identical.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(kStemBlock, 5) void k_stem_dgrad_reduce(
+    const float *__restrict__ dy, const float *__restrict__ w, const int32_t *__restrict__ table, int R,
+    const int32_t *__restrict__ idx, const int32_t *__restrict__ idx2, int idx_bstride, int B, int S,
+    int s_per_slab, int K, int Ho, int Wo, NormDev nd, float *__restrict__ slabs) {
+  __shared__ float tile[2][ST + 1][STP];
+  const int nslab = (S + s_per_slab - 1) / s_per_slab;
+  const int b = blockIdx.z / nslab, z = blockIdx.z - b * nslab;
+  const int s_begin = z * s_per_slab;
+  const int s_end = min(S, s_begin + s_per_slab);
+  const int a0 = blockIdx.y * SQ, b0 = blockIdx.x * SQ;
+  const int ta = threadIdx.x / SQ, tb = threadIdx.x % SQ;
+  const size_t plane_sz = (size_t)Ho * Wo;
+  const float *plane0 = dy + ((size_t)b * S + s_begin) * K * plane_sz;  // plane j of the slab = plane0 + j * plane_sz
+  const int n_planes = (s_end - s_begin) * K;
+  float acc[2][3][2][2], img[2][3][2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int pw = 0; pw < 2; ++pw) acc[u][c][ph][pw] = img[u][c][ph][pw] = 0.f;
+
+  constexpr int kStage = (ST * ST + kStemBlock - 1) / kStemBlock;
+  int lds_off[kStage], g_off[kStage];
+  bool g_ok[kStage];
+#pragma unroll
+  for (int j = 0; j < kStage; ++j) {
+    const int e = threadIdx.x + j * kStemBlock;
+    const int r = e / ST, c = e - r * ST;
+    const int oh = a0 - 1 + r, ow = b0 - 1 + c;
+    lds_off[j] = e < ST * ST ? r * STP + c : ST * STP;
+    g_ok[j] = e < ST * ST && oh >= 0 && oh < Ho && ow >= 0 && ow < Wo;
+    g_off[j] = g_ok[j] ? oh * Wo + ow : 0;
+  }
+  float pre[kStage];
+  auto stage_load = [&](int j) {
+    const float *plane = plane0 + (size_t)j * plane_sz;
+#pragma unroll
+    for (int q = 0; q < kStage; ++q) pre[q] = plane[g_off[q]];
+  };
+  auto stage_store = [&](int buf) {
+    float *t = &tile[buf][0][0];
+#pragma unroll
+    for (int q = 0; q < kStage; ++q) t[lds_off[q]] = g_ok[q] ? pre[q] : 0.f;
+  };
+
+  const int32_t *ib = idx + (size_t)b * idx_bstride;
+  const int32_t *ib2 = idx2 ? idx2 + (size_t)b * idx_bstride : nullptr;
+  const int h_base = 2 * (a0 + 2 * ta), w_base = 2 * (b0 + tb);  // pixel (h_base + 2u + ph, w_base + pw)
+
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+  int k = 0, s = s_begin;
+  for (int j = 0; j < n_planes; ++j) {
+    const int buf = j & 1;
+    stage_load(j + 1 < n_planes ? j + 1 : j);
+    __builtin_amdgcn_sched_barrier(0);
+    float p[5][4];
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) p[r][q] = tile[buf][2 * ta + r][tb + q];
+    const float *wk = w + (size_t)k * 147;  // wave-uniform: scalar loads
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      __builtin_amdgcn_sched_barrier(0);
+      float wc[49];
+#pragma unroll
+      for (int t = 0; t < 49; ++t) wc[t] = wk[c * 49 + t];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+          for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int i = ph + 5 - 2 * r, jj = pw + 5 - 2 * q;
+                if (i >= 0 && i <= 6 && jj >= 0 && jj <= 6)
+                  acc[u][c][ph][pw] = __builtin_fmaf(p[u + r][q], wc[i * 7 + jj], acc[u][c][ph][pw]);
+              }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (++k == K) {  // sample s complete: occlusion-masked accumulation into the image gradient (a-4 backward)
+      const int32_t *t1 = table + (size_t)ib[s] * R * 4;
+      const int32_t *t2 = ib2 ? table + (size_t)ib2[s] * R * 4 : nullptr;
+      unsigned occ = 0u;  // bit (u*2 + ph)*2 + pw
+      for (int pass = 0; pass < 2; ++pass) {
+        const int32_t *t = pass == 0 ? t1 : t2;
+        if (!t) continue;
+        for (int r = 0; r < R; ++r) {
+          const int r0 = t[4 * r + 0], r1 = t[4 * r + 1], c0 = t[4 * r + 2], c1 = t[4 * r + 3];
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+              for (int pw = 0; pw < 2; ++pw) {
+                const int h = h_base + 2 * u + ph, ww = w_base + pw;
+                occ |= (unsigned)((h >= r0) & (h < r1) & (ww >= c0) & (ww < c1)) << ((u * 2 + ph) * 2 + pw);
+              }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int pw = 0; pw < 2; ++pw) {
+              const bool o = (occ >> ((u * 2 + ph) * 2 + pw)) & 1u;
+              img[u][c][ph][pw] += o ? 0.f : acc[u][c][ph][pw];
+              acc[u][c][ph][pw] = 0.f;
+            }
+      k = 0;
+      ++s;
+    }
+    stage_store(buf ^ 1);
+    __syncthreads();
+  }
+  const int bq = b0 + tb;
+  if (bq >= Wo) return;
+  const int H = 2 * Ho, W = 2 * Wo;
+  float *dst = slabs + ((size_t)z * B + b) * 3 * H * W;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int a = a0 + 2 * ta + u;
+    if (a >= Ho) continue;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        float2 o;
+        o.x = img[u][c][ph][0];
+        o.y = img[u][c][ph][1];
+        if (nd.enable) {  // d/dx (x - mean)/std = 1/std, applied once after the S-sum like k_apply_bwd
+          o.x = o.x / nd.std[c];
+          o.y = o.y / nd.std[c];
+        }
+        *reinterpret_cast<float2 *>(dst + ((size_t)c * H + 2 * a + ph) * W + 2 * bq) = o;
       }
   }
 }
@@ -1799,6 +1959,22 @@ int dp_stem_dgrad(const float *dy, const float *w, int N, int K, int Ho, int Wo,
   DP_REQUIRE((reinterpret_cast<uintptr_t>(dx) & 7u) == 0);
   hipLaunchKernelGGL(k_stem_dgrad, dim3(cdiv(Wo, SQ), cdiv(Ho, SQ), N), dim3(kStemBlock), 0,
                      as_stream(stream), dy, w, K, Ho, Wo, dx);
+  return launch_status();
+}
+
+int dp_stem_dgrad_reduce(const float *dy, const float *w, const int32_t *table, int R, const int32_t *idx,
+                         const int32_t *idx2, int idx_bstride, int B, int S, int K, int Ho, int Wo,
+                         const dp_norm_t *norm, float *slabs, dp_stream_t stream) {
+  DP_REQUIRE(dy && w && slabs && K > 0 && Ho > 0 && Wo > 0);
+  DP_REQUIRE((reinterpret_cast<uintptr_t>(slabs) & 7u) == 0);
+  const int rc = check_occlusion_args(table, R, idx, idx_bstride, B, S, 2 * Ho, 2 * Wo, norm);
+  if (rc) return rc;
+  const int s_per_slab = bwd_s_per_slab(B, S, 4 * Ho * Wo);  // the partition dp_apply_bwd uses: identical sums
+  const int nslab = cdiv(S, s_per_slab);
+  DP_REQUIRE((long)B * nslab <= 65535);
+  hipLaunchKernelGGL(k_stem_dgrad_reduce, dim3(cdiv(Wo, SQ), cdiv(Ho, SQ), B * nslab), dim3(kStemBlock), 0,
+                     as_stream(stream), dy, w, table, R, idx, idx2, idx_bstride, B, S, s_per_slab, K, Ho, Wo,
+                     make_norm(norm), slabs);
   return launch_status();
 }
 

@@ -434,6 +434,34 @@ def stem_dgrad(dy, weight):
     return dx
 
 
+def stem_dgrad_reduce(dy, weight, table, idx, idx2=None, norm=RAW_NORM, B=None, out=None, accumulate=False):
+    """apply_bwd(stem_dgrad(dy, weight), ...) in one launch: the per-sample (B*S,3,H,W) input gradient is never
+    materialised.  Same arguments / result as ``apply_bwd`` with ``G`` replaced by the stem-conv output gradient."""
+    lib = _lib.load()
+    _chk(dy, torch.float32, "dy"), _chk(weight, torch.float32, "weight"), _chk(table, torch.int32, "table")
+    N, K, Ho, Wo = dy.shape
+    assert tuple(weight.shape) == (K, 3, 7, 7)
+    if B is None:
+        B = idx.shape[0] if idx.dim() == 2 else None
+    assert B is not None, "B must be given when idx is shared across images"
+    S, bstride = _idx_args(idx, idx2, B)
+    assert N == B * S, (N, B, S)
+    H, W = 2 * Ho, 2 * Wo
+    nslab = lib.dp_apply_bwd_nslab(B, S, H * W)
+    if out is None:
+        assert not accumulate
+        out = torch.empty((B, 3, H, W), dtype=torch.float32, device=dy.device)
+    direct = (nslab == 1 and not accumulate)
+    slabs = out if direct else torch.empty((nslab, B, 3, H, W), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.dp_stem_dgrad_reduce(_p(dy), _p(weight), _p(table), table.shape[1], _p(idx), _p(idx2), bstride,
+                                        B, S, K, Ho, Wo, ctypes.byref(norm), _p(slabs), _stream()),
+               "dp_stem_dgrad_reduce")
+    if not direct:
+        _lib.check(lib.dp_sum_slabs(_p(slabs), nslab, B * 3 * H * W, _p(out), 1 if accumulate else 0, _stream()),
+                   "dp_sum_slabs")
+    return out
+
+
 class StemConvFunction(torch.autograd.Function):
     """Stem convolution with a frozen filter: forward through MIOpen, input gradient through
     dp_stem_dgrad (the 3-channel transposed convolution libraries handle poorly)."""

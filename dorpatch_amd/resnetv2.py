@@ -174,14 +174,16 @@ class _Stem(nn.Module):
                 return ops.StemConvFunction.apply(x, conv.weight)    # input gradient via dp_stem_dgrad
         return conv(x)
 
-    def forward(self, x):
-        x = self._conv(x)
+    def pool(self, x):
         if GroupNormAct.fused:
             from . import ops
             if ops.pad_maxpool_supported(x):      # GPU fp32 NCHW only (checks x.is_cuda)
                 return ops.PadMaxPoolFunction.apply(x)
         x = F.pad(x, (1, 1, 1, 1), value=0.0)
         return F.max_pool2d(x, kernel_size=3, stride=2, padding=0)
+
+    def forward(self, x):
+        return self.pool(self._conv(x))
 
 
 class _Head(nn.Module):
@@ -209,7 +211,21 @@ class ResNetV2(nn.Module):
         self.num_classes = num_classes
 
     def forward(self, x):
-        x, res = self.stem(x), None
+        return self.forward_after_stem_conv(self.stem._conv(x))
+
+    def stem_split_supported(self, x):
+        """True when the caller may run the stem convolution itself (``F.conv2d(x, stem.conv.weight, None, 2, 3)``,
+        no autograd), continue with ``forward_after_stem_conv`` and turn the gradient w.r.t. the stem-conv output
+        into the S-reduced patch gradient with ``ops.stem_dgrad_reduce`` (frozen folded stem, fused kernels on)."""
+        conv = self.stem.conv
+        if not (GroupNormAct.fused and conv.folded and not conv.weight.requires_grad):
+            return False
+        from . import ops
+        return ops.stem_dgrad_supported(x, conv.weight, conv.stride, conv.padding)
+
+    def forward_after_stem_conv(self, z):
+        """Everything after ``stem.conv``: pad + max-pool, the four stages, final norm, head."""
+        x, res = self.stem.pool(z), None
         for stage in self.stages:
             for block in stage.blocks:
                 x, res = block.forward_pair(x, res)     # residual adds ride along into the next norm

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DP_ABI_VERSION 3
+#define DP_ABI_VERSION 4
 #define DP_MAX_RECTS 4 /* occlusion windows per mask-table entry */
 
 typedef void *dp_stream_t; /* hipStream_t */
@@ -224,6 +224,17 @@ int dp_pad_maxpool_bwd(const float *dy, const uint8_t *code, int64_t NC, int Hin
  * Direct fp32 gather on the VALU (2*K*147 flop per 2x2 output quad); compute-bound. */
 int dp_stem_dgrad(const float *dy, const float *w, int N, int K, int Ho, int Wo, float *dx,
                   dp_stream_t stream);
+
+/* ---- a-8 + a-4 backward, fused: stem input gradient, occlusion-masked and reduced over the EOT samples ----
+ * dp_stem_dgrad followed by dp_apply_bwd in one launch: dy (B*S,K,Ho,Wo) = d loss / d stem-conv-out of the B*S
+ * masked copies (image-major, like dp_apply_fwd's output), w (K,3,7,7); slabs (nslab,B,3,2Ho,2Wo) with
+ * nslab = dp_apply_bwd_nslab(B, S, 4*Ho*Wo), to be reduced with dp_sum_slabs (nslab == 1: slabs IS the result):
+ *   slabs[z,b,c,h,w] = (1/std_c) * sum_{s in slab z} keep(idx[b,s])[h,w] * stem_dgrad(dy[b*S+s])[c,h,w]
+ * The per-sample (B*S,3,H,W) gradient never reaches HBM (602 112 B written + read per sample @224 saved).
+ * Same arithmetic and summation order as the two separate entry points: bit-identical results. */
+int dp_stem_dgrad_reduce(const float *dy, const float *w, const int32_t *table, int R, const int32_t *idx,
+                         const int32_t *idx2, int idx_bstride, int B, int S, int K, int Ho, int Wo,
+                         const dp_norm_t *norm, float *slabs, dp_stream_t stream);
 
 /* ---- a-8  stride-2 pixel subsampling around the backbone's strided 1x1 (downsample) convolutions ----
  * (timm 0.6.7 PreActBottleneck.downsample = StdConv2d(1x1, stride 2), first block of stages 1-3; executed at

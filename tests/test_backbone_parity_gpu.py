@@ -62,13 +62,13 @@ def _oracle(model, x, mask, pattern, y, idx, stage, dtype):
                       n_classes=1000, lr=0.01)
 
 
-def _product(model, x, mask, pattern, y, idx, stage):
+def _product(model, x, mask, pattern, y, idx, stage, **extras):
     got = {}
     hook = lambda d: got.update({k: (v.detach().cpu().clone() if torch.is_tensor(v) else v) for k, v in d.items()})
     loop = HotLoop(DorPatch(verbose=False), copy.deepcopy(model).to(DEV), x.to(DEV), 0.12, 1000, "t/cfg/sub", 0,
                    y.to(DEV), True, 1e-2, 1e-1, 0, 1, 10, 7, 'topk', 2, S, 1e-3, 1e-3, 4.0, False,
                    dict(init_mask=mask, init_pattern=pattern, rngs=[FixedDraw([idx])], failure_refresh=10 ** 9,
-                        step_hook=hook))
+                        step_hook=hook, **extras))
     loop.stage = stage
     loop.step(1)
     torch.cuda.synchronize()
@@ -129,3 +129,13 @@ def test_two_fresh_runs_are_bit_identical():
     b = _product(model, x, mask, pattern, y, idx, 0)
     assert torch.equal(a["g_adv"], b["g_adv"]) and torch.equal(a["grad_pattern"], b["grad_pattern"])
     assert np.array_equal(a["loss_adv"], b["loss_adv"])
+
+
+def test_fused_stem_reduction_is_bit_identical_to_the_autograd_path():
+    """HotLoop's default for dorpatch_amd's own ResNetV2 — backward stops at the stem-conv output, dp_stem_dgrad_reduce
+    produces the S-reduced patch gradient — against the generic path (autograd down to the masked input +
+    dp_apply_bwd): the same arithmetic in the same order, so the same bits."""
+    model, x, mask, pattern, y, idx = _problem(0.0)
+    a = _product(model, x, mask, pattern, y, idx, 0)
+    b = _product(model, x, mask, pattern, y, idx, 0, stem_split=False)
+    assert torch.equal(a["g_adv"], b["g_adv"]) and np.array_equal(a["loss_adv"], b["loss_adv"])

@@ -512,3 +512,26 @@ def test_dual_conv1x1_matches_two_convolutions(stride, N, C, mid, O, H):
     b, s = ops.DualConv1x1Function.apply(pa, w1, wd, stride)
     (g_s,) = torch.autograd.grad(s, pa, dd)
     np.testing.assert_allclose((g_b + g_s).cpu().numpy(), g_ref.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(g_ref.abs().max()))
+
+
+@pytest.mark.parametrize("B,S,K,H,dual", [(2, 8, 64, 224, False), (1, 5, 8, 40, True), (3, 4, 5, 36, False), (1, 16, 8, 56, False)])
+def test_stem_dgrad_reduce_equals_stem_dgrad_then_apply_bwd(B, S, K, H, dual):
+    """dp_stem_dgrad_reduce == dp_apply_bwd(dp_stem_dgrad(.)) bit for bit (same arithmetic, same slab partition),
+    with and without the fused 1/std, single and dual masks, accumulate, sizes that do not fill the tiles."""
+    g = torch.Generator().manual_seed(B * 100 + S + H)
+    w = (torch.randn(K, 3, 7, 7, generator=g) * 0.1).to(DEV)
+    dy = torch.randn(B * S, K, H // 2, H // 2, generator=g).to(DEV)
+    table_np = masks.universe_rects(H, 2)
+    table = ops.upload_table(table_np, DEV)
+    rng = np.random.RandomState(S)
+    idx = torch.from_numpy(np.stack([rng.choice(len(table_np), S, replace=False) for _ in range(B)])).int().to(DEV)
+    idx2 = torch.from_numpy(np.stack([rng.choice(len(table_np), S, replace=False) for _ in range(B)])).int().to(DEV) if dual else None
+    for norm in (ops.RAW_NORM, ops.make_norm([0.5, 0.4, 0.3], [0.5, 0.25, 0.2], 0.5)):
+        G = ops.stem_dgrad(dy, w)
+        want = ops.apply_bwd(G, table, idx, idx2, norm, B=B)
+        got = ops.stem_dgrad_reduce(dy, w, table, idx, idx2, norm, B=B)
+        assert torch.equal(got, want)
+        base = torch.randn(B, 3, H, H, generator=g).to(DEV)
+        want_acc = ops.apply_bwd(G, table, idx, idx2, norm, B=B, out=base.clone(), accumulate=True)
+        got_acc = ops.stem_dgrad_reduce(dy, w, table, idx, idx2, norm, B=B, out=base.clone(), accumulate=True)
+        assert torch.equal(got_acc, want_acc)
