@@ -72,8 +72,10 @@ def parse():
                     help="library route of the backbone's frozen 1x1/1 convolutions: the committed per-shape gfx950 "
                          "table (deterministic, default), measured per shape at first use (auto), always the batched "
                          "GEMM, or always MIOpen (dorpatch_amd/conv1x1.py)")
-    ap.add_argument("--nondeterministic", action="store_true",
-                    help="let MIOpen pick atomically-accumulating kernels (DorPatch(deterministic=False)); A/B only")
+    ap.add_argument("--deterministic", default="auto", choices=["auto", "on", "off"],
+                    help="DorPatch(deterministic=...): auto = verify on the first micro-batch that the library "
+                         "convolutions are bit-reproducible and only otherwise force deterministic kernels (default); "
+                         "on = always force them (5 %% slower at configs[1], where they change nothing); off = never")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for functional "
                                                        "multi-rank tests on a single GPU)")
     ap.add_argument("--same-device", action="store_true",
@@ -237,7 +239,7 @@ def main():
         clean = torch.cat([model(x[i:i + 64]).argmax(-1) for i in range(0, B, 64)])
     y = (clean + 1 + torch.randint(0, 998, (B,), generator=torch.Generator().manual_seed(7)).to(dev)) % 1000
     owner = DorPatch(micro_batch=args.micro_batch, process_group=pg, verbose=False,
-                     deterministic=not args.nondeterministic)
+                     deterministic={"auto": "auto", "on": True, "off": False}[args.deterministic])
     # failure_refresh: the every-100-steps collect_failure sweep is timed apart below, never inside the timed steps
     loop = HotLoop(owner, model, x, args.patch_budget, 1000, "bench_out/cfg/sub", 0, y, True, 1e-2, 1e-1,
                    0, 1, 10 ** 9, 7, 'topk', 2, S, 1e-3, 1e-3, 4.0, False, dict(failure_refresh=10 ** 12))
@@ -309,7 +311,7 @@ def main():
                                                           args.patch_budget),
                        "images": B, "masks_per_image_per_gpu": S_local, "masks_per_image_total": S,
                        "image_size": H, "micro_batch": args.micro_batch, "miopen_find": bool(args.find),
-                       "fused_gn_relu": not args.no_fused_gn, "deterministic": not args.nondeterministic,
+                       "fused_gn_relu": not args.no_fused_gn, "deterministic": "%s: %s" % (args.deterministic, loop.deterministic_in_effect),
                        "conv1x1": dict(mode=args.conv1x1, **conv1x1.report()),
                        "parallelism": "eot-sample sharding x%d, 1 all-reduce of the patch gradient per step" % world},
             "roofline": {"kernel": "k_apply_fwd (dp_apply_fwd)", "bound": "hbm",

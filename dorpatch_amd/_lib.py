@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
-DP_ABI_VERSION = 4
+DP_ABI_VERSION = 5
 DP_MAX_RECTS = 4
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
@@ -50,6 +50,8 @@ PROTOTYPES = {
     "dp_apply_bwd_nslab": (_I, [_I, _I, _I]),
     "dp_apply_bwd": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, ctypes.POINTER(DpNorm), _P, _P]),
     "dp_sum_slabs": (_I, [_P, _I, _L, _P, _I, _P]),
+    "dp_apply_affine_fwd": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, ctypes.POINTER(DpNorm), _P, _P]),
+    "dp_apply_affine_bwd": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, ctypes.POINTER(DpNorm), _P, _P]),
     "dp_cw_loss": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
     "dp_local_variance": (_I, [_P, _I, _I, _I, _P, _P]),
     "dp_struct_ntile": (_I, [_I, _I]),

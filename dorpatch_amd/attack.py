@@ -162,19 +162,24 @@ class DorPatch(object):
     ``micro_batch`` — max EOT samples per backbone forward/backward (activation
     memory bound); ``process_group`` — a ``torch.distributed`` group whose ranks
     each hold a replica and process 1/world of the S sampled masks; ``verbose``;
-    ``deterministic`` (default True) — run the backbone's library convolutions with
-    ``torch.backends.cudnn.deterministic = True`` while ``generate`` runs: at small batches
-    MIOpen otherwise picks split-K implicit-GEMM kernels that accumulate with float atomics
-    (5 of ResNetV2-50's 23 convolution shapes at 8 samples, ``profiles/r02c_determinism_probe.jsonl``),
-    and the optimiser takes ``sign(grad)`` — two runs from identical seeds would drift apart.  With
-    it (and the table-routed 1x1 convolutions, every reduction of the HIP kernels in a fixed order)
-    identical inputs give identical bits.  The reference sets ``cudnn.benchmark = True``
+    ``deterministic`` — run-to-run bit reproducibility of the backbone's library convolutions (the optimiser
+    takes ``sign(grad)``: two runs from identical seeds otherwise drift apart).  At small batches MIOpen's
+    immediate mode picks split-K implicit-GEMM kernels that accumulate with float atomics (5 of ResNetV2-50's
+    23 convolution shapes at 8 samples; none at 512 — ``profiles/r02c_determinism_probe.jsonl``).
+    ``True``: ``torch.backends.cudnn.deterministic = True`` while ``generate`` runs (costs 5 % at the benchmark
+    configuration, where it changes nothing: MIOpen then avoids kernels that were deterministic anyway);
+    ``False``: leave MIOpen alone; ``"auto"`` (default): MEASURE — the first micro-batch's forward/backward runs
+    twice, and only if the two input gradients differ in any bit is the flag switched on for this run.  With
+    the table-routed 1x1 convolutions and the fixed-order reductions of every HIP kernel, identical inputs
+    then give identical bits either way.  The reference sets ``cudnn.benchmark = True``
     (``utils.py:17``) and is not run-to-run reproducible on a GPU.
     """
 
-    def __init__(self, micro_batch=512, process_group=None, verbose=True, deterministic=True):
+    def __init__(self, micro_batch=512, process_group=None, verbose=True, deterministic="auto"):
         self.micro_batch = int(micro_batch)
-        self.deterministic = bool(deterministic)
+        if deterministic not in (True, False, "auto"):
+            raise ValueError("deterministic must be True, False or 'auto'")
+        self.deterministic = deterministic
         self.pg = process_group
         self.verbose = verbose
         self.criterion = None
@@ -357,8 +362,11 @@ class HotLoop(object):
         for p, _ in self._frozen:
             p.requires_grad_(False)
         self._cudnn_det = torch.backends.cudnn.deterministic
-        if owner.deterministic:
+        if owner.deterministic is True:
             torch.backends.cudnn.deterministic = True
+        self._det_pending = owner.deterministic == "auto" and not torch.backends.cudnn.deterministic
+        self.deterministic_in_effect = "on" if torch.backends.cudnn.deterministic else \
+            ("pending" if self._det_pending else "off")
 
         owner.criterion = CW_loss(n_classes, targeted, confidence)     # attack.py:57
         # attack.py:59-60 — CPU generator, mask first then pattern
@@ -752,6 +760,22 @@ class HotLoop(object):
             ops.apply_bwd(G, self.table, idx, idx2, self.dn, B=B, out=out, accumulate=accumulate)
 
     def _fb_chunk(self, inp, y, flags, S_chunk, upstream, loss_out, pred_out):
+        if self._det_pending:        # deterministic="auto": are the library kernels picked for this shape reproducible?
+            self._det_pending = False
+            first = self._fb_chunk_once(inp, y, flags, S_chunk, upstream, loss_out, pred_out)
+            again = self._fb_chunk_once(inp, y, flags, S_chunk, upstream, loss_out, pred_out)
+            differ = torch.tensor([0 if torch.equal(first, again) else 1], dtype=torch.int32, device=self.dev)
+            dp_dist.allreduce_max_(differ, self.o.pg)        # every replica takes the same decision
+            if int(differ.item()) == 0:
+                self.deterministic_in_effect = "off (verified: two runs of the first micro-batch bit-identical)"
+                return again
+            torch.backends.cudnn.deterministic = True      # restored by close()
+            self.deterministic_in_effect = "on (two runs of the first micro-batch differed)"
+            self.o._log(">> library convolutions are not run-to-run deterministic at this batch size: "
+                        "switching to deterministic kernels")
+        return self._fb_chunk_once(inp, y, flags, S_chunk, upstream, loss_out, pred_out)
+
+    def _fb_chunk_once(self, inp, y, flags, S_chunk, upstream, loss_out, pred_out):
         if self._stem_split:
             conv = self.net.stem.conv
             with torch.no_grad():

@@ -329,6 +329,147 @@ __global__ __launch_bounds__(kBlock) void k_apply_bwd(
   dst[2 * P4 + g] = a2;
 }
 
+// ----------------------------------------------------------------------------
+// EXTENSION (not in the reference; BASELINE.json north_star "random affine placement"): per-sample affine
+// placement of the patch perturbation, fused with the occlusion apply.  The reference blends the patch at identity
+// (adv_x = x + delta, attack.py:184-185); here sample (b, s) sees  x + warp(delta, theta[b,s]),  where theta is a
+// 2 x 3 map from OUTPUT pixel coordinates to SOURCE (delta) pixel coordinates, bilinear, zero outside
+// (torch: F.grid_sample(delta, F.affine_grid(theta_norm), 'bilinear', 'zeros', align_corners=False)).  Identity
+// theta reproduces dp_apply_fwd / dp_apply_bwd exactly.
+//   forward  out[b,s,c,o] = occluded ? fill : norm(x[b,c,o] + sum_{4 taps p} w(o,p) * delta[b,c,p])
+//   backward g_delta[b,c,p] = sum_s sum_{o : w(o,p) > 0, o kept} w(o,p) * G[b,s,c,o] / std_c
+// The backward is the exact adjoint written as a GATHER: the outputs whose tap footprint covers source pixel p
+// are the integer points of the parallelogram theta^-1([p-1, p+1]^2); its bounding box is walked in a fixed order
+// (no float atomics: the optimiser takes sign(grad)).
+// ----------------------------------------------------------------------------
+struct Affine {
+  float a00, a01, t0, a10, a11, t1;  // src_x = a00*ox + a01*oy + t0 ; src_y = a10*ox + a11*oy + t1
+};
+
+__device__ __forceinline__ Affine load_affine(const float *__restrict__ theta, size_t n) {
+  const float *t = theta + n * 6;  // wave-uniform: scalar loads
+  return Affine{t[0], t[1], t[2], t[3], t[4], t[5]};
+}
+
+__device__ __forceinline__ void affine_src(const Affine &A, int ox, int oy, float &sx, float &sy) {
+  sx = (A.a00 * (float)ox + A.a01 * (float)oy) + A.t0;
+  sy = (A.a10 * (float)ox + A.a11 * (float)oy) + A.t1;
+}
+
+__global__ __launch_bounds__(kBlock) void k_apply_affine_fwd(
+    const float *__restrict__ x, const float *__restrict__ delta, const float *__restrict__ theta,
+    const int32_t *__restrict__ table, int R, const int32_t *__restrict__ idx,
+    const int32_t *__restrict__ idx2, int idx_bstride, int S, int H, int W, NormDev nd,
+    float *__restrict__ out) {
+  const int P = H * W, P4 = P >> 2;
+  const int g = blockIdx.x * kBlock + threadIdx.x;
+  if (g >= P4) return;
+  const int s = blockIdx.y, b = blockIdx.z;
+  const int pix = g << 2;
+  const int h = pix / W, w = pix - h * W;
+  const Affine A = load_affine(theta, (size_t)b * S + s);
+  const int m1 = idx[(size_t)b * idx_bstride + s];
+  unsigned occ = occluded4(table, R, m1, h, w);
+  if (idx2) occ |= occluded4(table, R, idx2[(size_t)b * idx_bstride + s], h, w);
+  const float *xb = x + (size_t)b * 3 * P, *db = delta + (size_t)b * 3 * P;
+  float *ob = out + ((size_t)b * S + s) * 3 * P;
+  float v[3][4];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const f4 xv = reinterpret_cast<const f4 *>(xb + (size_t)c * P)[g];
+    v[c][0] = xv.x; v[c][1] = xv.y; v[c][2] = xv.z; v[c][3] = xv.w;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float sx, sy;
+    affine_src(A, w + j, h, sx, sy);
+    const float fx0 = floorf(sx), fy0 = floorf(sy);
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    const bool inx0 = x0 >= 0 && x0 < W, inx1 = x0 + 1 >= 0 && x0 + 1 < W;
+    const bool iny0 = y0 >= 0 && y0 < H, iny1 = y0 + 1 >= 0 && y0 + 1 < H;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float *dc = db + (size_t)c * P;
+      float acc = 0.f;  // tap order fixed: (y0,x0), (y0,x1), (y1,x0), (y1,x1)
+      if (iny0 && inx0) acc += (wy0 * wx0) * dc[y0 * W + x0];
+      if (iny0 && inx1) acc += (wy0 * wx1) * dc[y0 * W + x0 + 1];
+      if (iny1 && inx0) acc += (wy1 * wx0) * dc[(y0 + 1) * W + x0];
+      if (iny1 && inx1) acc += (wy1 * wx1) * dc[(y0 + 1) * W + x0 + 1];
+      v[c][j] += acc;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    f4 t = f4{v[c][0], v[c][1], v[c][2], v[c][3]};
+    if (nd.enable) t = (t - nd.mean[c]) / nd.std[c];
+    __builtin_nontemporal_store(select4(occ, t, nd.fill[c]), reinterpret_cast<f4 *>(ob + (size_t)c * P) + g);
+  }
+}
+
+// One thread per source pixel p = (py, px) x 3 channels; grid y = S-slab, z = image.  theta_inv (B,S,6) is the
+// inverse map (source -> output coordinates) supplied by the host; it only positions the search box.
+__global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
+    const float *__restrict__ G, const float *__restrict__ theta, const float *__restrict__ theta_inv,
+    const int32_t *__restrict__ table, int R, const int32_t *__restrict__ idx,
+    const int32_t *__restrict__ idx2, int idx_bstride, int B, int S, int H, int W, int s_per_slab,
+    NormDev nd, float *__restrict__ slabs) {
+  const int P = H * W;
+  const int p = blockIdx.x * kBlock + threadIdx.x;
+  if (p >= P) return;
+  const int b = blockIdx.z, z = blockIdx.y;
+  const int py = p / W, px = p - py * W;
+  const int s_begin = z * s_per_slab, s_end = min(S, s_begin + s_per_slab);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int s = s_begin; s < s_end; ++s) {
+    const Affine A = load_affine(theta, (size_t)b * S + s);
+    const Affine Ai = load_affine(theta_inv, (size_t)b * S + s);
+    float cx, cy;
+    affine_src(Ai, px, py, cx, cy);  // output-space centre of the footprint
+    const float ex = fabsf(Ai.a00) + fabsf(Ai.a01), ey = fabsf(Ai.a10) + fabsf(Ai.a11);
+    const int ox0 = max(0, (int)floorf(cx - ex) - 1), ox1 = min(W - 1, (int)ceilf(cx + ex) + 1);
+    const int oy0 = max(0, (int)floorf(cy - ey) - 1), oy1 = min(H - 1, (int)ceilf(cy + ey) + 1);
+    const int32_t *t1 = table + (size_t)idx[(size_t)b * idx_bstride + s] * R * 4;
+    const int32_t *t2 = idx2 ? table + (size_t)idx2[(size_t)b * idx_bstride + s] * R * 4 : nullptr;
+    const float *Gs = G + ((size_t)b * S + s) * 3 * P;
+    for (int oy = oy0; oy <= oy1; ++oy)
+      for (int ox = ox0; ox <= ox1; ++ox) {
+        float sx, sy;
+        affine_src(A, ox, oy, sx, sy);  // the forward's own expression: identical weights
+        const float fx0 = floorf(sx), fy0 = floorf(sy);
+        const int x0 = (int)fx0, y0 = (int)fy0;
+        float wgt;
+        if (px == x0) wgt = 1.f - (sx - fx0);
+        else if (px == x0 + 1) wgt = sx - fx0;
+        else continue;
+        if (py == y0) wgt = (1.f - (sy - fy0)) * wgt;
+        else if (py == y0 + 1) wgt = (sy - fy0) * wgt;
+        else continue;
+        bool occ = false;
+        for (int pass = 0; pass < 2; ++pass) {
+          const int32_t *t = pass == 0 ? t1 : t2;
+          if (!t) continue;
+          for (int r = 0; r < R; ++r)
+            occ |= (oy >= t[4 * r] && oy < t[4 * r + 1] && ox >= t[4 * r + 2] && ox < t[4 * r + 3]);
+        }
+        if (occ) continue;
+        const size_t o = (size_t)oy * W + ox;
+        a0 += wgt * Gs[o];
+        a1 += wgt * Gs[P + o];
+        a2 += wgt * Gs[2 * (size_t)P + o];
+      }
+  }
+  if (nd.enable) {
+    a0 = a0 / nd.std[0];
+    a1 = a1 / nd.std[1];
+    a2 = a2 / nd.std[2];
+  }
+  float *dst = slabs + ((size_t)z * B + b) * 3 * P;
+  dst[p] = a0;
+  dst[P + p] = a1;
+  dst[2 * (size_t)P + p] = a2;
+}
+
 __global__ __launch_bounds__(kBlock) void k_sum_slabs(const float *__restrict__ slabs,
                                                       int nslab, int64_t n4,
                                                       float *__restrict__ out,
@@ -1783,6 +1924,35 @@ int dp_apply_bwd(const float *G, const int32_t *table, int R, const int32_t *idx
   hipLaunchKernelGGL(k_apply_bwd, dim3(cdiv(P >> 2, kBlock), nslab, B), dim3(kBlock), 0,
                      as_stream(stream), G, table, R, idx, idx2, idx_bstride, B, S, H, W,
                      s_per_slab, make_norm(norm), slabs);
+  return launch_status();
+}
+
+int dp_apply_affine_fwd(const float *x, const float *delta, const float *theta, const int32_t *table, int R,
+                        const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
+                        const dp_norm_t *norm, float *out, dp_stream_t stream) {
+  DP_REQUIRE(x && delta && theta && out && aligned16(x) && aligned16(out));
+  const int rc = check_occlusion_args(table, R, idx, idx_bstride, B, S, H, W, norm);
+  if (rc) return rc;
+  DP_REQUIRE(S <= 65535);
+  hipLaunchKernelGGL(k_apply_affine_fwd, dim3(cdiv((H * W) >> 2, kBlock), S, B), dim3(kBlock), 0,
+                     as_stream(stream), x, delta, theta, table, R, idx, idx2, idx_bstride, S, H, W,
+                     make_norm(norm), out);
+  return launch_status();
+}
+
+int dp_apply_affine_bwd(const float *G, const float *theta, const float *theta_inv, const int32_t *table, int R,
+                        const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
+                        const dp_norm_t *norm, float *slabs, dp_stream_t stream) {
+  DP_REQUIRE(G && theta && theta_inv && slabs);
+  const int rc = check_occlusion_args(table, R, idx, idx_bstride, B, S, H, W, norm);
+  if (rc) return rc;
+  const int P = H * W;
+  const int s_per_slab = bwd_s_per_slab(B, S, P);
+  const int nslab = cdiv(S, s_per_slab);
+  DP_REQUIRE(nslab <= 65535);
+  hipLaunchKernelGGL(k_apply_affine_bwd, dim3(cdiv(P, kBlock), nslab, B), dim3(kBlock), 0, as_stream(stream), G,
+                     theta, theta_inv, table, R, idx, idx2, idx_bstride, B, S, H, W, s_per_slab, make_norm(norm),
+                     slabs);
   return launch_status();
 }
 

@@ -177,6 +177,51 @@ def apply_bwd(G, table, idx, idx2=None, norm=RAW_NORM, B=None, out=None, accumul
     return out
 
 
+# ---------------------------------------------------------------- extension: affine placement (dorpatch_amd/placement.py)
+def apply_affine_fwd(x, delta, theta, table, idx, idx2=None, norm=RAW_NORM, out=None):
+    """occlude(norm(x + warp(delta, theta[b,s]))) for B images x S samples -> (B*S,3,H,W); theta (B,S,2,3) fp32."""
+    lib = _lib.load()
+    _chk(x, torch.float32, "x"), _chk(delta, torch.float32, "delta"), _chk(theta, torch.float32, "theta")
+    _chk(table, torch.int32, "table")
+    B, C, H, W = x.shape
+    assert C == 3 and delta.shape == x.shape
+    S, bstride = _idx_args(idx, idx2, B)
+    assert tuple(theta.shape) == (B, S, 2, 3)
+    if out is None:
+        out = torch.empty((B * S, 3, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(lib.dp_apply_affine_fwd(_p(x), _p(delta), _p(theta), _p(table), table.shape[1], _p(idx), _p(idx2),
+                                       bstride, B, S, H, W, ctypes.byref(norm), _p(out), _stream()),
+               "dp_apply_affine_fwd")
+    return out
+
+
+def apply_affine_bwd(G, theta, theta_inv, table, idx, idx2=None, norm=RAW_NORM, B=None, out=None, accumulate=False):
+    """d loss / d delta: the exact adjoint of apply_affine_fwd w.r.t. delta, summed over the S samples."""
+    lib = _lib.load()
+    _chk(G, torch.float32, "G"), _chk(theta, torch.float32, "theta"), _chk(theta_inv, torch.float32, "theta_inv")
+    N, C, H, W = G.shape
+    assert C == 3
+    if B is None:
+        B = idx.shape[0] if idx.dim() == 2 else None
+    assert B is not None
+    S, bstride = _idx_args(idx, idx2, B)
+    assert N == B * S and tuple(theta.shape) == (B, S, 2, 3) and theta_inv.shape == theta.shape
+    P = H * W
+    nslab = lib.dp_apply_bwd_nslab(B, S, P)
+    if out is None:
+        assert not accumulate
+        out = torch.empty((B, 3, H, W), dtype=torch.float32, device=G.device)
+    direct = (nslab == 1 and not accumulate)
+    slabs = out if direct else torch.empty((nslab, B, 3, H, W), dtype=torch.float32, device=G.device)
+    _lib.check(lib.dp_apply_affine_bwd(_p(G), _p(theta), _p(theta_inv), _p(table), table.shape[1], _p(idx), _p(idx2),
+                                       bstride, B, S, H, W, ctypes.byref(norm), _p(slabs), _stream()),
+               "dp_apply_affine_bwd")
+    if not direct:
+        _lib.check(lib.dp_sum_slabs(_p(slabs), nslab, B * 3 * P, _p(out), 1 if accumulate else 0, _stream()),
+                   "dp_sum_slabs")
+    return out
+
+
 # ---------------------------------------------------------------- a-7
 def cw_loss(logits, y, targeted, S, confidence, upstream, loss_out=None, want_grad=True,
             want_pred=True):

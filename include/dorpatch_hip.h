@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DP_ABI_VERSION 4
+#define DP_ABI_VERSION 5
 #define DP_MAX_RECTS 4 /* occlusion windows per mask-table entry */
 
 typedef void *dp_stream_t; /* hipStream_t */
@@ -98,6 +98,25 @@ int dp_apply_bwd(const float *G, const int32_t *table, int R,
                  const int32_t *idx, const int32_t *idx2, int idx_bstride,
                  int B, int S, int H, int W, const dp_norm_t *norm,
                  float *slabs, dp_stream_t stream);
+
+/* ---- EXTENSION (absent from the reference): per-sample affine placement of the patch, fused with the apply ----
+ * BASELINE.json's north_star names "random affine placement"; the reference blends the patch at identity only
+ * (attack.py:184-185; its sole trace of transforms is the unused hook of collect_failure, attack.py:384, 395-396).
+ * theta (B,S,2,3) fp32 maps OUTPUT pixel coordinates (ox, oy) to SOURCE coordinates in delta:
+ *   sx = theta[0]*ox + theta[1]*oy + theta[2],  sy = theta[3]*ox + theta[4]*oy + theta[5]
+ * bilinear, zero outside the image — F.grid_sample(delta, F.affine_grid(theta_norm), align_corners=False); the host
+ * side (dorpatch_amd/placement.py) converts.  delta (B,3,H,W) = dp_blend(..., add_x = 0).
+ *   dp_apply_affine_fwd  out[b,s] = occlude(norm(x[b] + warp(delta[b], theta[b,s])))          (B*S,3,H,W)
+ *   dp_apply_affine_bwd  slabs[z,b] = (1/std) sum_{s in slab z} warp^T(keep(s) * G[b,s])      exact adjoint, gather
+ *                        form (fixed summation order, no atomics); theta_inv (B,S,2,3) = the inverse maps, used
+ *                        only to position the search window; nslab = dp_apply_bwd_nslab(B, S, H*W), then dp_sum_slabs.
+ * Identity theta reproduces dp_apply_fwd / dp_apply_bwd bit for bit. */
+int dp_apply_affine_fwd(const float *x, const float *delta, const float *theta, const int32_t *table, int R,
+                        const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
+                        const dp_norm_t *norm, float *out, dp_stream_t stream);
+int dp_apply_affine_bwd(const float *G, const float *theta, const float *theta_inv, const int32_t *table, int R,
+                        const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
+                        const dp_norm_t *norm, float *slabs, dp_stream_t stream);
 
 /* out[i] = (accumulate ? out[i] : 0) + sum_{z<nslab} slabs[z*n + i], z ascending. */
 int dp_sum_slabs(const float *slabs, int nslab, int64_t n, float *out,

@@ -120,10 +120,22 @@ def occlude(adv_x, keep):
     return adv_x[:, None] * keep + 0.5 * ~keep
 
 
+# ----------------------------------------------------------------------------- extension: affine placement
+def warp_delta(delta, theta_norm):
+    """EXTENSION oracle (nothing in the reference to follow — SURVEY §0): delta (B,3,H,W) placed under S affine maps per
+    image, theta_norm (B,S,2,3) in ``F.affine_grid`` convention -> (B,S,3,H,W).  bilinear, zeros outside,
+    align_corners=False."""
+    B, S = theta_norm.shape[:2]
+    _, C, H, W = delta.shape
+    grid = F.affine_grid(theta_norm.reshape(B * S, 2, 3).to(delta.dtype), (B * S, C, H, W), align_corners=False)
+    rep = delta[:, None].expand(B, S, C, H, W).reshape(B * S, C, H, W)
+    return F.grid_sample(rep, grid, mode="bilinear", padding_mode="zeros", align_corners=False).view(B, S, C, H, W)
+
+
 # ----------------------------------------------------------------------------- one step
 def eot_step(model, x, mask, pattern, y, keep, *, stage, targeted, n_classes, confidence=0.1,
              structured=1e-3, density=1e-3, coeff_group_lasso=1e-5, eps=4.0, lr=None,
-             clip_min=0.0, clip_max=1.0, unit=7, keep_dual=None, local_var_x=None):
+             clip_min=0.0, clip_max=1.0, unit=7, keep_dual=None, local_var_x=None, theta_norm=None):
     """One pass of attack.py:184-247 (+ the update of 333-342 when ``lr`` is given) for
     B >= 1 images treated as independent problems that share the sampled masks ``keep``
     (S,1,H,W) — or per-image masks when ``keep`` is (B,S,1,H,W).
@@ -138,7 +150,13 @@ def eot_step(model, x, mask, pattern, y, keep, *, stage, targeted, n_classes, co
         local_var_x = local_variance(x)[0].mean(1)                          # attack.py:100
     delta = clip(mask, pattern, x, eps)                                     # :184
     adv_x = delta + x                                                       # :185
-    if keep.dim() == 4:
+    if theta_norm is not None:              # EXTENSION (placement.py): each sample sees x + warp(delta, theta[b,s])
+        placed = x[:, None] + warp_delta(delta, theta_norm)
+        kk = keep if keep.dim() == 5 else keep[None]
+        masked = placed * kk + 0.5 * ~kk
+        if keep_dual is not None:
+            masked = masked * keep_dual + 0.5 * ~keep_dual
+    elif keep.dim() == 4:
         masked = occlude(adv_x, keep)                                       # :206
         if keep_dual is not None:
             masked = masked * keep_dual + 0.5 * ~keep_dual                  # :218

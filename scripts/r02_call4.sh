@@ -14,7 +14,7 @@ cd $R
 ( HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 scripts/two_rank_check.py ) > $O/two_rank_check.json 2> $O/two_rank_check.err; echo "2rank rc=$?" | tee -a $O/rc.txt
 ( time timeout 900 python -m pytest tests -m gpu -q -rf -s --durations=5 -p no:cacheprovider ) > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/rc.txt
 ( timeout 300 python bench.py --no-cpu-baseline --no-pmc --no-sweep --steps 10 --warmup 3 ) > $O/bench_det.json 2> $O/bench_det.err; echo "bench det rc=$?" | tee -a $O/rc.txt
-( timeout 300 python bench.py --no-cpu-baseline --no-pmc --no-sweep --steps 10 --warmup 3 --nondeterministic ) > $O/bench_nondet.json 2> $O/bench_nondet.err; echo "bench nondet rc=$?" | tee -a $O/rc.txt
+( timeout 300 python bench.py --no-cpu-baseline --no-pmc --no-sweep --steps 10 --warmup 3 --deterministic off ) > $O/bench_nondet.json 2> $O/bench_nondet.err; echo "bench nondet rc=$?" | tee -a $O/rc.txt
 for c in 2 3; do ( timeout 200 python bench.py --config $c --no-cpu-baseline --no-pmc --no-sweep --steps 10 --warmup 3 ) > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err; echo "bench cfg$c rc=$?" | tee -a $O/rc.txt; done
 cat $O/rc.txt; cat $O/kbench_calib.txt; cat $O/kbench_maxpool.txt | tail -3; cut -c1-700 $O/two_rank_check.json; tail -3 $O/two_rank_check.err; tail -6 $O/pytest_gpu.log
 for f in bench_det bench_nondet bench_cfg2 bench_cfg3; do cut -c1-200 $O/$f.json; done

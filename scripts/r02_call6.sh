@@ -10,7 +10,7 @@ for rep in 1 2; do
   ( cd .ab_r01 && timeout 300 python bench.py --no-cpu-baseline --no-sweep --steps 10 --warmup 3 ) > $O/ab_r01_$rep.json 2> $O/ab_r01_$rep.err; echo "ab r01 $rep rc=$?" | tee -a $O/rc.txt
   ( timeout 300 python bench.py --no-cpu-baseline --no-pmc --no-sweep --steps 10 --warmup 3 ) > $O/ab_cur_$rep.json 2> $O/ab_cur_$rep.err; echo "ab cur $rep rc=$?" | tee -a $O/rc.txt
 done
-( timeout 300 python bench.py --no-cpu-baseline --no-pmc --no-sweep --steps 10 --warmup 3 --nondeterministic ) > $O/ab_cur_nondet.json 2> $O/ab_cur_nondet.err; echo "ab cur nondet rc=$?" | tee -a $O/rc.txt
+( timeout 300 python bench.py --no-cpu-baseline --no-pmc --no-sweep --steps 10 --warmup 3 --deterministic off ) > $O/ab_cur_nondet.json 2> $O/ab_cur_nondet.err; echo "ab cur nondet rc=$?" | tee -a $O/rc.txt
 ( time timeout 900 python -m pytest tests -m gpu -q -rf -s --durations=5 -p no:cacheprovider ) > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/rc.txt
 ( timeout 100 tools/kbench 64 32 224 20 maxpool ) > $O/kbench_maxpool.txt 2>&1
 ( time timeout 700 python bench.py --no-cpu-baseline --no-pmc --no-sweep --steps 10 --warmup 3 --find 1 ) > $O/bench_find1.json 2> $O/bench_find1.err; echo "bench find1 rc=$?" | tee -a $O/rc.txt
