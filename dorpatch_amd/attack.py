@@ -207,7 +207,9 @@ class DorPatch(object):
         ``np.random.RandomState`` per image), ``step_hook`` (callable receiving a dict
         of per-step internals — used by the parity tests), ``switch_iteration`` (500),
         ``failure_refresh`` (100), ``failure_sampling_start`` (1000), ``log_every`` (20), ``stem_split`` (True: with
-        dorpatch_amd's own ResNetV2 the stem's input gradient and the S-reduction run as one kernel).
+        dorpatch_amd's own ResNetV2 the stem's input gradient and the S-reduction run as one kernel), ``placement``
+        (EXTENSION, not in the reference: e.g. ``dorpatch_amd.placement.RandomAffine()`` — every EOT sample sees the
+        patch under its own random affine placement; ``None`` = the reference's identity placement).
         """
         run = HotLoop(self, model, x, patch_budget, n_classes, save_dir, batch_id, y, targeted, lr,
                       confidence, clip_min, clip_max, max_iterations, basic_unit, selection, dropout,
@@ -355,6 +357,9 @@ class HotLoop(object):
         self.failure_start = extras.get("failure_sampling_start", 1000)  # attack.py:193
         self.log_every = extras.get("log_every", 20)                  # attack.py:318
         self.step_hook = extras.get("step_hook", None)
+        # EXTENSION (dorpatch_amd/placement.py; absent from the reference, which places the patch at identity):
+        # an object with .draw(rng, S, H, W) -> (S,2,3) output->source pixel maps, one draw per image per step
+        self.placement = extras.get("placement", None)
 
         self.net, self.norm = _unwrap_model(model)
         self.dn = _dp_norm(self.norm)
@@ -447,7 +452,9 @@ class HotLoop(object):
         # dp_stem_dgrad_reduce turns that gradient into the S-reduced patch gradient in one launch (the per-sample
         # (N,3,H,W) input gradient is never written); any other model: autograd down to the input + dp_apply_bwd
         probe = getattr(self.net, "stem_split_supported", None)
-        self._stem_split = bool(probe is not None and extras.get("stem_split", True) and probe(self.x))
+        self._stem_split = bool(probe is not None and extras.get("stem_split", True) and self.placement is None
+                                and probe(self.x))
+        self.theta_np = None
 
     # ---------------------------------------------------------------- plumbing
     def close(self):
@@ -587,6 +594,10 @@ class HotLoop(object):
             if self.dual:                                              # attack.py:208-216
                 self.idx2_np[b] = draw_indices(self.rngs[b], st.failed_idxs, self.n_fail[b], self.S,
                                                self.sampling_choices)
+            if self.placement is not None:                             # extension: after the reference's own draws
+                if self.theta_np is None:
+                    self.theta_np = np.zeros((self.B, self.S, 2, 3), dtype=np.float32)
+                self.theta_np[b] = self.placement.draw(self.rngs[b], self.S, self.H, self.W)
 
     def step(self, i):
         """One pass of attack.py:169-342 over the whole batch.  Returns False once every
@@ -681,6 +692,7 @@ class HotLoop(object):
                 cell_sumsq=cell, win_sum=wsum, unit=self.unit, win=self.win, density=self.density,
                 do_update=False, want_grads=True)
             self.step_hook(dict(i=i, stage=stage, idx=self.idx_np.copy(), adv_x=self.adv_x, scale=scale,
+                                theta=None if self.theta_np is None else self.theta_np.copy(),
                                 loss_adv=loss_adv_np, loss_struc=loss_struc_np, group_lasso=gl_np,
                                 density=dens_np, g_adv=self.g_adv, grad_pattern=gp, grad_mask=gm,
                                 mask=self.adv_mask, pattern=self.adv_pattern, lr=lr_now.copy(),
@@ -729,7 +741,17 @@ class HotLoop(object):
         if self.kernel_events is not None:   # bench.py: HIP events stamped by the dominant kernel itself
             timer = ops.KernelTimer()
             self.kernel_events.append(timer)
-        inp_all = ops.apply_fwd(self.adv_x, self.table, idx, idx2, self.dn, timer=timer)   # (B*Sl,3,H,W)
+        theta = theta_inv = delta = None
+        if self.placement is not None:     # extension: sample (b, s) sees x + warp(delta, theta[b, s])
+            from . import placement as dp_placement
+            th = np.ascontiguousarray(self.theta_np[:, self.s_lo:self.s_hi])
+            theta = torch.as_tensor(th, device=self.dev)
+            theta_inv = torch.as_tensor(dp_placement.invert(th), device=self.dev)
+            delta = ops.blend(self.adv_mask, self.adv_pattern, self.x, self.eps, add_x=False)[0]
+            inp_all = ops.apply_affine_fwd(self.x, delta, theta, self.table, idx, idx2, self.dn)
+        else:
+            inp_all = ops.apply_fwd(self.adv_x, self.table, idx, idx2, self.dn, timer=timer)   # (B*Sl,3,H,W)
+        self._placement_ctx = (theta, theta_inv)
         loss_flat = self._own_loss                 # this rank's (B, S_local) slab of the step's all-reduce buffer
         if Sl <= mb:
             ipm = max(1, mb // Sl)                 # whole images per micro-batch
@@ -738,7 +760,7 @@ class HotLoop(object):
                 G = self._fb_chunk(inp_all[b0 * Sl:b1 * Sl], self.y[b0:b1], crit_flags[b0:b1], Sl,
                                    upstream, loss_flat[b0 * Sl:b1 * Sl], self.pred[b0 * Sl:b1 * Sl])
                 self._reduce_over_samples(G, idx[b0:b1], None if idx2 is None else idx2[b0:b1], b1 - b0,
-                                          self.g_adv[b0:b1], False)
+                                          self.g_adv[b0:b1], False, (b0, b1, 0, Sl))
         else:
             for b in range(B):
                 for k, s0 in enumerate(range(0, Sl, mb)):
@@ -748,12 +770,18 @@ class HotLoop(object):
                                        upstream, loss_flat[n0:n1], self.pred[n0:n1])
                     self._reduce_over_samples(G, idx[b:b + 1, s0:s1].contiguous(),
                                               None if idx2 is None else idx2[b:b + 1, s0:s1].contiguous(), 1,
-                                              self.g_adv[b:b + 1], k > 0)
+                                              self.g_adv[b:b + 1], k > 0, (b, b + 1, s0, s1))
         self._own_pred.copy_(self.pred)            # int32 -> fp32 (class ids are exact), rides in the same buffer
 
-    def _reduce_over_samples(self, G, idx, idx2, B, out, accumulate):
-        """sum_S keep * d loss/d masked-input (/ std) -> d loss/d adv_x for B images (autograd of attack.py:206-220)."""
-        if self._stem_split:     # G = d loss / d stem-conv output: stem input gradient + S-reduction in one launch
+    def _reduce_over_samples(self, G, idx, idx2, B, out, accumulate, where):
+        """sum_S keep * d loss/d masked-input (/ std) -> d loss/d adv_x for B images (autograd of attack.py:206-220).
+        ``where`` = (b0, b1, s0, s1): the images / local samples ``G`` covers (placement extension only)."""
+        theta, theta_inv = self._placement_ctx
+        if theta is not None:    # extension: d loss / d delta through the warp's exact adjoint (delta enters adv_x 1:1)
+            b0, b1, s0, s1 = where
+            ops.apply_affine_bwd(G, theta[b0:b1, s0:s1].contiguous(), theta_inv[b0:b1, s0:s1].contiguous(), self.table,
+                                 idx, idx2, self.dn, B=B, out=out, accumulate=accumulate)
+        elif self._stem_split:     # G = d loss / d stem-conv output: stem input gradient + S-reduction in one launch
             ops.stem_dgrad_reduce(G, self.net.stem.conv.weight, self.table, idx, idx2, self.dn, B=B, out=out,
                                   accumulate=accumulate)
         else:

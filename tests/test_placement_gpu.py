@@ -1,0 +1,141 @@
+"""EXTENSION tests — per-sample affine placement of the patch (dorpatch_amd/placement.py, dp_apply_affine_fwd/_bwd).
+
+Nothing in the reference to compare with (it places the patch at identity only), so the oracle is
+``oracle/restatement.warp_delta`` = ``F.affine_grid`` + ``F.grid_sample`` (bilinear, zeros, align_corners=False) and
+its autograd, and the anchor to the reference is: identity placement reproduces the reference path bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from dorpatch_amd import masks, ops  # noqa: E402
+from dorpatch_amd import placement as PL  # noqa: E402
+from dorpatch_amd.attack import DorPatch, HotLoop  # noqa: E402
+from oracle import restatement as R  # noqa: E402
+from oracle import toy_models  # noqa: E402
+
+DEV = "cuda:0"
+NORM = ([0.5, 0.4, 0.3], [0.5, 0.25, 0.2])
+
+
+def _setup(B, S, H, seed=0, dual=False):
+    g = torch.Generator().manual_seed(seed)
+    x, delta = torch.rand(B, 3, H, H, generator=g), (torch.rand(B, 3, H, H, generator=g) - 0.5) * 0.3
+    table_np = masks.universe_rects(H, 2)
+    rng = np.random.RandomState(seed)
+    idx_np = np.stack([rng.choice(len(table_np), S, replace=False) for _ in range(B)])
+    idx2_np = np.stack([rng.choice(len(table_np), S, replace=False) for _ in range(B)]) if dual else None
+    theta = np.stack([PL.RandomAffine(25.0, (0.7, 1.3), 6.0).draw(rng, S, H, H) for _ in range(B)])
+    return x, delta, table_np, idx_np, idx2_np, theta
+
+
+def _keep(table_np, idx_np, H):
+    keep = masks.rects_to_bool(table_np, H)                  # (n,1,H,W) bool
+    return torch.stack([keep[torch.from_numpy(r)] for r in idx_np])      # (B,S,1,H,W)
+
+
+def test_identity_placement_is_the_reference_path_bit_for_bit():
+    B, S, H = 2, 6, 56
+    x, delta, table_np, idx_np, idx2_np, _ = _setup(B, S, H, dual=True)
+    table = ops.upload_table(table_np, DEV)
+    idx, idx2 = torch.from_numpy(idx_np).int().to(DEV), torch.from_numpy(idx2_np).int().to(DEV)
+    theta = torch.from_numpy(np.stack([PL.identity(S)] * B)).to(DEV)
+    norm = ops.make_norm(*NORM, 0.5)
+    xd, dd = x.to(DEV), delta.to(DEV)
+    got = ops.apply_affine_fwd(xd, dd, theta, table, idx, idx2, norm)
+    want = ops.apply_fwd((xd + dd).contiguous(), table, idx, idx2, norm)
+    assert torch.equal(got, want)
+    G = torch.randn(B * S, 3, H, H, generator=torch.Generator().manual_seed(1)).to(DEV)
+    gb = ops.apply_affine_bwd(G, theta, theta.clone(), table, idx, idx2, norm, B=B)
+    assert torch.equal(gb, ops.apply_bwd(G, table, idx, idx2, norm, B=B))
+
+
+@pytest.mark.parametrize("B,S,H", [(2, 5, 56), (1, 3, 40)])
+def test_affine_apply_matches_grid_sample_oracle_and_its_adjoint(B, S, H):
+    x, delta, table_np, idx_np, _, theta = _setup(B, S, H, seed=3)
+    table = ops.upload_table(table_np, DEV)
+    idx = torch.from_numpy(idx_np).int().to(DEV)
+    norm = ops.make_norm(*NORM, 0.5)
+    th = torch.from_numpy(theta).to(DEV)
+    got = ops.apply_affine_fwd(x.to(DEV), delta.to(DEV), th, table, idx, None, norm).view(B, S, 3, H, H).cpu()
+    # oracle: F.affine_grid + F.grid_sample, then occlusion (fill 0.5) and normalisation as the reference does them
+    keep = _keep(table_np, idx_np, H)
+    dl = delta.clone().requires_grad_(True)
+    placed = x[:, None] + R.warp_delta(dl, torch.from_numpy(PL.to_normalized(theta, H, H)))
+    masked = placed * keep + 0.5 * ~keep
+    mean, std = torch.tensor(NORM[0]).view(1, 1, 3, 1, 1), torch.tensor(NORM[1]).view(1, 1, 3, 1, 1)
+    want = (masked - mean) / std
+    np.testing.assert_allclose(got.numpy(), want.detach().numpy(), rtol=0, atol=2e-5)
+    # backward: d/d delta of <out, G>
+    G = torch.randn(B, S, 3, H, H, generator=torch.Generator().manual_seed(5))
+    (want_g,) = torch.autograd.grad((want * G).sum(), dl)
+    got_g = ops.apply_affine_bwd(G.view(B * S, 3, H, H).to(DEV), th, torch.from_numpy(PL.invert(theta)).to(DEV), table,
+                                 idx, None, norm, B=B).cpu()
+    np.testing.assert_allclose(got_g.numpy(), want_g.numpy(), rtol=0, atol=2e-5 * float(want_g.abs().max()))
+    # exact adjoint (bilinear weights computed by the same expression in both kernels): <A d, G> == <d, A^T G>
+    d2 = torch.randn(B, 3, H, H, generator=torch.Generator().manual_seed(6))
+    zero_x = torch.zeros_like(x)
+    raw = ops.RAW_NORM
+    Ad = ops.apply_affine_fwd(zero_x.to(DEV), d2.to(DEV), th, table, idx, None, ops.make_norm(None, None, 0.0))
+    AtG = ops.apply_affine_bwd(G.view(B * S, 3, H, H).to(DEV), th, torch.from_numpy(PL.invert(theta)).to(DEV), table, idx,
+                               None, raw, B=B)
+    lhs = float((Ad.double().cpu().view(-1) * G.double().view(-1)).sum())
+    rhs = float((d2.double().view(-1) * AtG.double().cpu().view(-1)).sum())
+    assert abs(lhs - rhs) <= 1e-5 * (abs(lhs) + 1.0), (lhs, rhs)
+
+
+class FixedPlacement(object):
+    def __init__(self, theta):
+        self.theta = theta
+        self.k = 0
+
+    def draw(self, rng, S, H, W):
+        out = self.theta[self.k]
+        self.k += 1
+        return out
+
+
+class FixedDraw(object):
+    def __init__(self, rows):
+        self.rows = list(rows)
+
+    def choice(self, a, n, replace=False):
+        return np.asarray(self.rows.pop(0)).copy()
+
+
+@pytest.mark.parametrize("stage", [0, 1])
+def test_hot_loop_step_with_placement_matches_oracle(stage):
+    """One HotLoop.step with a placement: losses and the parameter gradients against the oracle step whose EOT
+    samples see x + grid_sample(delta) (autograd through the warp); B = 2 images, each with its own draws."""
+    H, S, B = 56, 6, 2
+    model = toy_models.NormModel(toy_models.make_toy(gain=2.0), toy_models.Normalize()).to(DEV)
+    g = torch.Generator().manual_seed(17)
+    x, m0, p0 = torch.rand(B, 3, H, H, generator=g), torch.rand(B, 1, H, H, generator=g), torch.rand(B, 3, H, H, generator=g)
+    if stage == 1:
+        m0 = (m0 > 0.8).float()
+    y = torch.tensor([3, 5])
+    rng = np.random.RandomState(2)
+    rows = [rng.choice(2520, S, replace=False) for _ in range(B)]
+    theta = np.stack([PL.RandomAffine(15.0, (0.85, 1.2), 4.0).draw(rng, S, H, H) for _ in range(B)])
+    got = {}
+    hook = lambda d: got.update({k: (v.detach().cpu().clone() if torch.is_tensor(v) else v) for k, v in d.items()})
+    loop = HotLoop(DorPatch(micro_batch=8, verbose=False), model, x.to(DEV), 0.12, 10, "t/cfg/sub", 0, y.to(DEV), True,
+                   1e-2, 1e-1, 0, 1, 10, 7, 'topk', 2, S, 1e-3, 1e-3, 4.0, False,
+                   dict(init_mask=m0, init_pattern=p0, rngs=[FixedDraw([rows[b]]) for b in range(B)],
+                        failure_refresh=10 ** 9, step_hook=hook, placement=FixedPlacement(list(theta))))
+    loop.stage = stage
+    loop.step(1)
+    loop.close()
+    assert np.array_equal(got["theta"], theta)
+    uni = R.mask_universe(H, 2)
+    keep = torch.stack([uni[torch.from_numpy(r)] for r in rows])                       # (B,S,1,H,W)
+    cpu = toy_models.NormModel(toy_models.make_toy(gain=2.0), toy_models.Normalize())
+    want = R.eot_step(cpu, x, m0, p0, y, keep, stage=stage, targeted=True, n_classes=10, lr=0.01,
+                      theta_norm=torch.from_numpy(PL.to_normalized(theta, H, H)))
+    np.testing.assert_allclose(got["loss_adv"], want["loss_adv"].numpy(), rtol=1e-4, atol=1e-5)
+    gw = want["grad_pattern"].numpy()
+    np.testing.assert_allclose(got["grad_pattern"].numpy(), gw, rtol=1e-3, atol=1e-3 * np.abs(gw).max())
+    if stage == 0:
+        gm, gmw = got["grad_mask"].numpy(), want["grad_mask"].numpy()
+        np.testing.assert_allclose(gm, gmw, rtol=1e-3, atol=1e-3 * np.abs(gmw).max())
