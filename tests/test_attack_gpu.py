@@ -395,20 +395,23 @@ def test_collect_failure_matches_oracle():
     atk = DorPatch(verbose=False)
     single = atk.collect_failure(adv[:1].to(DEV), y[:1].to(DEV), table, False, model)
     assert single == lists[0]
-    # the reference's calling convention (attack.py:98, 187-190): y expanded to B * sampling_size labels
-    assert atk.collect_failure(adv[:1].to(DEV), y[:1].repeat_interleave(128).to(DEV), table, False, model,
-                               batch_size=128) == single
+    # the public method's calling conventions, on the 144-mask single-window universe (dropout = 1)
+    table1, uni1 = ops.upload_table(masks.universe_rects(H, 1), DEV), R.mask_universe(H, 1)
+    single1 = atk.collect_failure(adv[:1].to(DEV), y[:1].to(DEV), table1, False, model)
+    # the reference's own convention (attack.py:98, 187-190): y expanded to B * sampling_size labels
+    assert atk.collect_failure(adv[:1].to(DEV), y[:1].repeat_interleave(128).to(DEV), table1, False, model,
+                               batch_size=128) == single1
     # B > 1: the union over the images, ascending (attack.py:403 `.unique()` per chunk)
-    both = _collect_failure(net, norm, adv.to(DEV), y.to(DEV), table, False, 128)
-    assert atk.collect_failure(adv.to(DEV), y.to(DEV), table, False, model) == sorted(set(both[0]) | set(both[1]))
+    both = _collect_failure(net, norm, adv.to(DEV), y.to(DEV), table1, False, 128)
+    assert atk.collect_failure(adv.to(DEV), y.to(DEV), table1, False, model) == sorted(set(both[0]) | set(both[1]))
     # the reference's bool (n,1,H,W) universe is rejected loudly, not mis-read
     with pytest.raises(TypeError):
-        atk.collect_failure(adv[:1].to(DEV), y[:1].to(DEV), uni.to(DEV), False, model)
+        atk.collect_failure(adv[:1].to(DEV), y[:1].to(DEV), uni1.to(DEV), False, model)
     # `transforms` (attack.py:395-396) is applied to the occluded [0,1] images right before the model
     dark = lambda t: t * 0.5
-    want_t = R.collect_failure(lambda t: cpu(dark(t)), adv[:1], y[:1], uni, False)
-    got_t = atk.collect_failure(adv[:1].to(DEV), y[:1].to(DEV), table, False, model, transforms=dark)
-    assert len(set(got_t) ^ set(want_t)) <= 2 and got_t != single
+    want_t = R.collect_failure(lambda t: cpu(dark(t)), adv[:1], y[:1], uni1, False)
+    got_t = atk.collect_failure(adv[:1].to(DEV), y[:1].to(DEV), table1, False, model, transforms=dark)
+    assert len(set(got_t) ^ set(want_t)) <= 1 and got_t != single1
 
 
 def test_patchcleanser_matches_reference_records(golden_patchcleanser):

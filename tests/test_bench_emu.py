@@ -33,7 +33,7 @@ def _run_bench(monkeypatch, capsys, argv):
 
 def test_bench_line_contract(monkeypatch, capsys):
     out = _run_bench(monkeypatch, capsys, ["--batch", "1", "--samples", "2", "--size", "32", "--steps", "1",
-                                           "--warmup", "0", "--micro-batch", "2", "--no-sweep", "--no-cpu-baseline"])
+                                           "--warmup", "0", "--micro-batch", "2", "--no-sweep", "--no-cpu-baseline", "--deterministic", "off"])
     for k, t in REQUIRED.items():
         assert isinstance(out[k], t), (k, out[k])
     assert out["metric"] == "EOT-samples/sec" and out["unit"] == "EOT-samples/s" and out["higher_is_better"] is True

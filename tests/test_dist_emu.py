@@ -178,7 +178,7 @@ def _bench_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     sys.argv = ["bench.py", "--gpus", str(world), "--backend", "gloo", "--batch", "1", "--samples", "2", "--size", "32",
-                "--steps", "1", "--warmup", "0", "--micro-batch", "2", "--no-sweep", "--no-cpu-baseline"]
+                "--steps", "1", "--warmup", "0", "--micro-batch", "2", "--no-sweep", "--no-cpu-baseline", "--deterministic", "off"]
     import contextlib
     import bench
     bench.DEVICE_OVERRIDE = "cpu"

@@ -518,6 +518,8 @@ def test_dual_conv1x1_matches_two_convolutions(stride, N, C, mid, O, H):
 def test_stem_dgrad_reduce_equals_stem_dgrad_then_apply_bwd(B, S, K, H, dual):
     """dp_stem_dgrad_reduce == dp_apply_bwd(dp_stem_dgrad(.)) bit for bit (same arithmetic, same slab partition),
     with and without the fused 1/std, single and dual masks, accumulate, sizes that do not fill the tiles."""
+    if DEV == "cpu" and K * H >= 64 * 224:          # the CPU emulation re-runs this on a smaller problem
+        K, S = 8, 3
     g = torch.Generator().manual_seed(B * 100 + S + H)
     w = (torch.randn(K, 3, 7, 7, generator=g) * 0.1).to(DEV)
     dy = torch.randn(B * S, K, H // 2, H // 2, generator=g).to(DEV)
