@@ -1897,10 +1897,14 @@ int dp_apply_fwd(const float *adv_x, const int32_t *table, int R, const int32_t 
                           norm, out, stream);
 }
 
+// S-slab partition shared by dp_apply_bwd, dp_stem_dgrad_reduce and dp_apply_affine_bwd (so that they sum in the
+// same order): enough slabs for ~4096 workgroups (the fused stem kernel runs 2-wave workgroups for a whole slab of
+// samples x 64 channels each: with fewer it is latency-bound — 1568 workgroups measured 1.8x slower than the two
+// separate kernels), at least 2 samples per slab.
 static int bwd_s_per_slab(int B, int S, int P) {
   const int tiles = cdiv(P >> 2, kBlock);
-  int nslab = cdiv(1024, tiles * B);  // >= ~1024 workgroups
-  const int max_slab = S >= 8 ? S / 4 : 1;  // keep >= 4 samples per slab
+  int nslab = cdiv(4096, tiles * B);
+  const int max_slab = S >= 4 ? S / 2 : 1;
   if (nslab > max_slab) nslab = max_slab;
   if (nslab < 1) nslab = 1;
   return cdiv(S, nslab);

@@ -386,6 +386,28 @@ int main(int argc, char **argv) {
           [&] { DP(dp_pad_maxpool_bwd(gy, code, NC, 112, 112, gs, st)); });
     float *wst = (float *)dmalloc(64 * 147 * 4);
     hipLaunchKernelGGL(k_fill, dim3(8), dim3(256), 0, st, (f4 *)wst, 64 * 147 / 4, 0.01f);
+    {  // fused stem dgrad + occlusion-masked S-reduction: 8 images x 32 samples
+      const int Bf = 8, ns = dp_apply_bwd_nslab(Bf, 32, 224 * 224);
+      float *sl = (float *)dmalloc((size_t)ns * Bf * 3 * 224 * 224 * 4);
+      const double flopf = 2.0 * 64 * 147 * 112 * 112 * Bf * 32;
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0));
+      CK(hipEventCreate(&e1));
+      auto run = [&] {
+        DP(dp_stem_dgrad_reduce(gx, wst, d_table, 2, d_idx, nullptr, 32, Bf, 32, 64, 112, 112, &norm, sl, st));
+        if (ns > 1) DP(dp_sum_slabs(sl, ns, (int64_t)Bf * 3 * 224 * 224, g_adv, 0, st));
+      };
+      for (int i = 0; i < 2; ++i) run();
+      CK(hipEventRecord(e0, st));
+      for (int i = 0; i < iters; ++i) run();
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= iters;
+      printf("%-34s %9.4f ms  %12.3e flop  %8.2f TFLOP/s  %5.1f%% of 157.3 TF fp32  (%d slabs)\n",
+             "dp_stem_dgrad_reduce 8x32 samples", ms, flopf, flopf / (ms * 1e-3) / 1e12, flopf / (ms * 1e-3) / 1e12 / 1.573, ns);
+    }
     {
       const double flop = 2.0 * 64 * 147 * 112 * 112 * Nb;  // 60.4 GFLOP
       hipEvent_t e0, e1;
