@@ -206,8 +206,9 @@ class DorPatch(object):
         ``init_pattern`` (override the ``torch.rand`` init), ``rngs`` (one legacy
         ``np.random.RandomState`` per image), ``step_hook`` (callable receiving a dict
         of per-step internals — used by the parity tests), ``switch_iteration`` (500),
-        ``failure_refresh`` (100), ``failure_sampling_start`` (1000), ``log_every`` (20), ``stem_split`` (True: with
-        dorpatch_amd's own ResNetV2 the stem's input gradient and the S-reduction run as one kernel), ``placement``
+        ``failure_refresh`` (100), ``failure_sampling_start`` (1000), ``log_every`` (20), ``stem_split`` (False; True: with
+        dorpatch_amd's own ResNetV2 the stem's input gradient and the S-reduction run as one kernel — bit-identical,
+        measured slightly slower), ``placement``
         (EXTENSION, not in the reference: e.g. ``dorpatch_amd.placement.RandomAffine()`` — every EOT sample sees the
         patch under its own random affine placement; ``None`` = the reference's identity placement).
         """
@@ -448,11 +449,14 @@ class HotLoop(object):
         self.samples_done = 0
         self.kernel_events = None
         self._conv_shared = False
-        # dorpatch_amd's own ResNetV2 with a frozen stem: the backward stops at the stem-convolution OUTPUT and
-        # dp_stem_dgrad_reduce turns that gradient into the S-reduced patch gradient in one launch (the per-sample
-        # (N,3,H,W) input gradient is never written); any other model: autograd down to the input + dp_apply_bwd
+        # Optional (extras stem_split=True), dorpatch_amd's own ResNetV2 with a frozen stem only: the backward stops at
+        # the stem-convolution OUTPUT and dp_stem_dgrad_reduce turns that gradient into the S-reduced patch gradient in
+        # one launch, so the per-sample (N,3,H,W) input gradient is never written.  Bit-identical to the default
+        # (autograd down to the masked input: dp_stem_dgrad, then dp_apply_bwd) and NOT faster: the 2.4 GB of HBM
+        # traffic it saves per step (0.4 ms) cost less than the fused kernel's lower occupancy does (measured on one
+        # box: 432.3 vs 429.8 ms/step, profiles/r02h_*), so it stays off by default.
         probe = getattr(self.net, "stem_split_supported", None)
-        self._stem_split = bool(probe is not None and extras.get("stem_split", True) and self.placement is None
+        self._stem_split = bool(probe is not None and extras.get("stem_split", False) and self.placement is None
                                 and probe(self.x))
         self.theta_np = None
 

@@ -132,10 +132,10 @@ def test_two_fresh_runs_are_bit_identical():
 
 
 def test_fused_stem_reduction_is_bit_identical_to_the_autograd_path():
-    """HotLoop's default for dorpatch_amd's own ResNetV2 — backward stops at the stem-conv output, dp_stem_dgrad_reduce
-    produces the S-reduced patch gradient — against the generic path (autograd down to the masked input +
-    dp_apply_bwd): the same arithmetic in the same order, so the same bits."""
+    """HotLoop(stem_split=True) for dorpatch_amd's own ResNetV2 — backward stops at the stem-conv output,
+    dp_stem_dgrad_reduce produces the S-reduced patch gradient — against the default path (autograd down to the masked
+    input + dp_apply_bwd): the same arithmetic in the same order, so the same bits."""
     model, x, mask, pattern, y, idx = _problem(0.0)
-    a = _product(model, x, mask, pattern, y, idx, 0)
-    b = _product(model, x, mask, pattern, y, idx, 0, stem_split=False)
+    a = _product(model, x, mask, pattern, y, idx, 0, stem_split=True)
+    b = _product(model, x, mask, pattern, y, idx, 0)
     assert torch.equal(a["g_adv"], b["g_adv"]) and np.array_equal(a["loss_adv"], b["loss_adv"])
