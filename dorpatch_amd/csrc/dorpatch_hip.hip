@@ -979,17 +979,24 @@ __global__ __launch_bounds__(T, MW) void k_gn_relu_fwd(GnArgs A, float *__restri
   if (A.res) {  // fused residual add (block output + shortcut): one extra read, one extra write
     const f4 *r4 = reinterpret_cast<const f4 *>(A.res + (size_t)ng * L);
     f4 *s4 = reinterpret_cast<f4 *>(A.sum_out + (size_t)ng * L);
-    f4 r[V];
+    constexpr int CH = V <= 7 ? V : 6;  // residual loads in flight at once (registers: V + CH float4)
 #pragma unroll
-    for (int k = 0; k < V; ++k) {
-      const int i = threadIdx.x + k * T;
-      r[k] = ld4<NT>(r4 + (i < L4 ? i : 0));
-    }
+    for (int k0 = 0; k0 < V; k0 += CH) {
+      f4 r[CH];
 #pragma unroll
-    for (int k = 0; k < V; ++k) {
-      const int i = threadIdx.x + k * T;
-      v[k] += r[k];
-      if (i < L4) st4<NT>(s4 + i, v[k]);
+      for (int c = 0; c < CH; ++c) {
+        const int i = threadIdx.x + (k0 + c) * T;
+        if (k0 + c < V) r[c] = ld4<NT>(r4 + (i < L4 ? i : 0));
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int k = k0 + c;
+        if (k < V) {
+          const int i = threadIdx.x + k * T;
+          v[k] += r[c];
+          if (i < L4) st4<NT>(s4 + i, v[k]);
+        }
+      }
     }
   }
   float s = 0.f;
@@ -1696,10 +1703,11 @@ __global__ __launch_bounds__(kBlock) void k_subsample2_add(const float *__restri
 }
 
 // (V float4 per thread, T threads) combinations that are instantiated, smallest first; the
-// group must fit: V*T >= L4.  V = 7 only with T = 1024 (launch bounds cap it at 128 VGPRs; at
+// group must fit: V*T >= L4.  V >= 7 only with T = 1024 (launch bounds cap it at 128 VGPRs; at
 // T = 256/512 the compiler spends > 160 VGPRs on V = 7).  V = 0 => streaming kernel.
 inline void gn_pick(int L4, int &V, int &T) {
-  static const int combos[6][2] = {{1, 256}, {2, 256}, {4, 256}, {4, 512}, {4, 1024}, {7, 1024}};
+  // (9, 1024) and (18, 1024) serve the forward of 384 x 384 inputs (groups of 36 864 and 73 728 floats)
+  static const int combos[8][2] = {{1, 256}, {2, 256}, {4, 256}, {4, 512}, {4, 1024}, {7, 1024}, {9, 1024}, {18, 1024}};
   for (const auto &c : combos)
     if (c[0] * c[1] >= L4) {
       V = c[0];
@@ -1733,6 +1741,7 @@ int launch_gn_fwd(int variant, const GnArgs &A, int N, float *y, float *mean, fl
   int V, T;
   gn_pick(L4, V, T);
   const dim3 grid((unsigned)(N * (A.C / A.Cg)));
+  if (V > 7 && A.Cg > kGnLdsCh) V = 0;  // the large-group kernels stage gamma / beta in LDS
   if (V == 0) {
     hipLaunchKernelGGL(k_gn_relu_fwd_stream, grid, dim3(kGnStreamT), 0, st, A, y, mean, rstd);
     return launch_status();
@@ -1743,8 +1752,10 @@ int launch_gn_fwd(int variant, const GnArgs &A, int N, float *y, float *mean, fl
   else if (T == 256) DP_GN_FWD_FLAGS(4, 256, 1);
   else if (T == 512) DP_GN_FWD_FLAGS(4, 512, 1);
   else if (V == 4) DP_GN_FWD_FLAGS(4, 1024, 1);
-  else if ((variant & kGnMW8) || (variant == kGnDefaultVariant && !A.res)) DP_GN_FWD_FLAGS(7, 1024, 8);
-  else DP_GN_FWD_FLAGS(7, 1024, 1);
+  else if (V == 7 && ((variant & kGnMW8) || (variant == kGnDefaultVariant && !A.res))) DP_GN_FWD_FLAGS(7, 1024, 8);
+  else if (V == 7) DP_GN_FWD_FLAGS(7, 1024, 1);
+  else if (V == 9) DP_GN_FWD_VT(9, 1024, true, true, 1);
+  else DP_GN_FWD_VT(18, 1024, true, true, 1);
   return launch_status();
 }
 
@@ -1764,6 +1775,9 @@ int launch_gn_bwd(int variant, const GnArgs &A, int N, const float *dy, const fl
   int V, T;
   gn_pick(L4, V, T);
   const dim3 grid((unsigned)(N * (A.C / A.Cg)));
+  if (V > 7) V = 0;  // the backward needs x and dy resident (2 x V float4): above V = 7 it re-reads (streaming kernel).
+                     // (A variant keeping only dxh in registers and re-reading x was written and dropped: hipcc spills
+                     // ~1 KB per lane for V = 18 whatever the chunking.)
   if (V == 0) {
     hipLaunchKernelGGL(k_gn_relu_bwd_stream, grid, dim3(kGnStreamT), 0, st, A, dy, mean, rstd, dx);
     return launch_status();
@@ -1774,7 +1788,8 @@ int launch_gn_bwd(int variant, const GnArgs &A, int N, const float *dy, const fl
   else if (T == 256) DP_GN_BWD_FLAGS(4, 256);
   else if (T == 512) DP_GN_BWD_FLAGS(4, 512);
   else if (V == 4) DP_GN_BWD_FLAGS(4, 1024);
-  else DP_GN_BWD_FLAGS(7, 1024);
+  else if (V == 7) DP_GN_BWD_FLAGS(7, 1024);
+  else DP_REQUIRE(false);
   return launch_status();
 }
 
@@ -1815,6 +1830,8 @@ int launch_apply_fwd(int variant, const float *adv_x, const int32_t *table, int 
   const int tiles = cdiv(P4, kBlock * G);
   // >= ~2048 workgroups (8 per CU) so the store stream covers all 8 XCDs evenly
   int nchunk = cdiv(2048, tiles * B);
+  if (variant & 32) nchunk = S;            // kbench sweep: one sample per workgroup (short-lived workgroups)
+  if (variant & 64) nchunk = cdiv(S, 4);   // kbench sweep: 4 samples per workgroup
   if (nchunk < 1) nchunk = 1;
   if (nchunk > S) nchunk = S;
   const int s_per_block = cdiv(S, nchunk);

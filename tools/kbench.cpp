@@ -262,9 +262,10 @@ int main(int argc, char **argv) {
   // ---- a-4 forward / backward
   bench("dp_apply_fwd (default variant)", out_bytes + (double)B * img, iters, st,
         [&] { DP(dp_apply_fwd(adv, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, big, st)); });
-  for (int variant : {1, 2, 4, 9, 10, 12, 16 + 4, 16 + 7, 16 + 8 + 4, 16 + 8 + 7}) {
+  for (int variant : {1, 2, 4, 9, 10, 12, 16 + 4, 16 + 7, 16 + 8 + 4, 16 + 8 + 7, 32 + 9, 32 + 10, 32 + 1, 64 + 9, 64 + 10}) {
     char name[64];
-    snprintf(name, sizeof name, "  k_apply_fwd%s<G=%d,NT=%d>", (variant & 16) ? "_ch" : "", variant & 7, (variant >> 3) & 1);
+    snprintf(name, sizeof name, "  k_apply_fwd%s<G=%d,NT=%d>%s", (variant & 16) ? "_ch" : "", variant & 7, (variant >> 3) & 1,
+             (variant & 32) ? " 1 sample/WG" : (variant & 64) ? " 4 samples/WG" : "");
     bench(name, out_bytes + (double)B * img, iters, st, [&] {
       DP(launch_apply_fwd(variant, adv, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, big, st));
     });
