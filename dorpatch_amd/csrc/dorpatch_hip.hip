@@ -180,8 +180,8 @@ inline NormDev make_norm(const dp_norm_t *n) {
 // grid: x = tiles of kBlock*G float4 groups of the image plane, y = S-chunks, z = image.
 // Each thread owns G float4 groups (4 consecutive pixels each, kBlock groups apart so that
 // every wave-instruction still covers 1 KiB of contiguous addresses) of all 3 channels,
-// reads + normalises them ONCE, then streams `s_per_block` occluded copies (3*G 16-byte
-// stores per sample).  NT selects non-temporal stores (the output is consumed by another
+// reads + normalises them once, then streams `s_per_block` occluded copies (3*G 16-byte
+// stores per sample; s_per_block = 1 in the shipped configuration, see kApplyFwdDefaultVariant).  NT selects non-temporal stores (the output is consumed by another
 // kernel much later, never re-read by this one).
 template <int G, bool NT>
 __global__ __launch_bounds__(kBlock) void k_apply_fwd(
@@ -1793,9 +1793,13 @@ int launch_gn_bwd(int variant, const GnArgs &A, int N, const float *dy, const fl
   return launch_status();
 }
 
-// Variant = G (float4 groups per thread: 1, 2 or 4) + 8 * NT (non-temporal stores).
-// dp_apply_fwd uses kApplyFwdDefaultVariant; tools/kbench.cpp sweeps the others.
-constexpr int kApplyFwdDefaultVariant = 1 + 8;
+// Variant = G (float4 groups per thread: 1, 2 or 4) + 8 * NT (non-temporal stores) + 16 (channel-split kernel)
+// + 32 (one sample per workgroup) / 64 (four).  dp_apply_fwd uses kApplyFwdDefaultVariant; tools/kbench.cpp sweeps
+// the others (profiles/r02i_kbench_apply.txt, 64 x 32 x 224^2): one sample per workgroup — 100 352 short-lived
+// workgroups of 3 stores per lane, the 38.5 MB of source images re-read from L2 — reaches 6.42 TB/s (80 % of the
+// 8 TB/s spec, above this GPU's plain-copy rate) where the round-1 form (a workgroup streams all 32 samples of its
+// tile) reaches 5.4; four samples per workgroup 5.8; the channel-split kernel 4.9-5.2.
+constexpr int kApplyFwdDefaultVariant = 1 + 8 + 32;
 
 int launch_apply_fwd(int variant, const float *adv_x, const int32_t *table, int R,
                      const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H,
