@@ -315,7 +315,7 @@ def main():
                        "images": B, "masks_per_image_per_gpu": S_local, "masks_per_image_total": S,
                        "image_size": H, "micro_batch": args.micro_batch, "miopen_find": bool(args.find),
                        "fused_gn_relu": not args.no_fused_gn, "deterministic": "%s: %s" % (args.deterministic, loop.deterministic_in_effect),
-                       "conv1x1": dict(mode=args.conv1x1, **conv1x1.report()),
+                       "conv1x1": dict(mode=args.conv1x1, gemm_solutions=conv1x1.report_tuned(), **conv1x1.report()),
                        "parallelism": "eot-sample sharding x%d, 1 all-reduce per step (patch gradient + loss slabs)" % world},
             "roofline": {"kernel": "k_apply_fwd (dp_apply_fwd)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

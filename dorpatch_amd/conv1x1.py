@@ -17,7 +17,9 @@ Neither route is always faster (``profiles/r01d_conv1x1_table_n512.jsonl``).
 ``MODE`` (environment variable ``DORPATCH_CONV1X1`` at import):
 
 ``"table"`` (default)  the committed per-(gfx950, direction, C, O, HW) table ``conv1x1_gfx950.json``,
-                       measured once on an MI355X; shapes it does not list go to MIOpen.  Deterministic:
+                       measured once on an MI355X (two columns: with the libraries' default GEMM solutions,
+                       and with the tuned solutions of ``tunableop_gfx950.csv`` — see ``tuned_gemms_active``);
+                       shapes it does not list go to MIOpen.  Deterministic:
                        every process, every rank and every run executes the same kernels in the same
                        order, so two runs give bit-identical gradients (the optimiser takes ``sign(grad)``:
                        reproducibility outranks the last per cent).
@@ -49,9 +51,46 @@ _timings = {}         # same key -> (gemm_ms, miopen_ms)
 _frozen = False       # auto mode: no further calibration (unknown shapes fall back to the table)
 _used = {}            # (direction, route) -> number of distinct shapes routed (report())
 
-with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "conv1x1_gfx950.json")) as _f:
-    TABLE = {tuple([k.split(":")[0]] + [int(v) for v in k.split(":")[1:]]): v
-             for k, v in json.load(_f)["choices"].items()}
+_HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(_HERE, "conv1x1_gfx950.json")) as _f:
+    _doc = json.load(_f)
+
+
+def _parse(choices):
+    return {tuple([k.split(":")[0]] + [int(v) for v in k.split(":")[1:]]): v for k, v in choices.items()}
+
+
+TABLE = _parse(_doc["choices"])                # routes with the BLAS libraries' default GEMM solutions
+TABLE_TUNED = _parse(_doc["choices_tuned"])    # routes when the tuned GEMM solutions below are active
+
+# Tuned GEMM solutions for the GEMM route (PyTorch TunableOp, tuning done offline on an MI355X by
+# scripts/tunableop_probe.py: 1.1-1.3x on most shapes, 2.9x on 64->64 and 1.9x on 256->64 @56x56, where hipBLASLt's
+# default pick is poor).  Loaded once, at the first GPU call, with TUNING DISABLED: the file only maps GEMM shapes to
+# library solution ids — still "MFMA left to rocBLAS/hipBLASLt", and still deterministic (no timing at run time).
+# TunableOp validates the file against the installed PyTorch / HIP / rocBLAS / hipBLASLt versions and the GPU
+# architecture and ignores it on a mismatch, in which case the plain table applies.  DORPATCH_TUNABLEOP=0 disables.
+TUNABLEOP_FILE = os.path.join(_HERE, "tunableop_gfx950.csv")
+TUNABLEOP = os.environ.get("DORPATCH_TUNABLEOP", "1") != "0"
+_tuned_state = None      # None: not tried yet; True: solutions loaded; False: not in effect
+
+
+def tuned_gemms_active(device_is_cuda=True):
+    """Load the tuned-solution file on first use (GPU only); -> whether it is in effect."""
+    global _tuned_state
+    if _tuned_state is None and device_is_cuda:
+        _tuned_state = False
+        if TUNABLEOP and os.path.exists(TUNABLEOP_FILE):
+            try:
+                import torch.cuda.tunable as tun
+                tun.enable(True)
+                tun.tuning_enable(False)
+                tun.record_untuned_enable(False)
+                _tuned_state = bool(tun.read_file(TUNABLEOP_FILE))
+                if not _tuned_state:
+                    tun.enable(False)
+            except Exception:            # noqa: BLE001 - any refusal simply leaves the default solutions in place
+                _tuned_state = False
+    return bool(_tuned_state)
 
 
 def _fwd_gemm(x, w4d, _=None):
@@ -97,8 +136,9 @@ def _time_ms(fn, t, w4d, x):
     return (time.perf_counter() - t0) * 1e3 / CAL_ITERS
 
 
-def _from_table(direction, C, O, HW):
-    return TABLE.get((direction, C, O, HW), "miopen")
+def _from_table(direction, C, O, HW, cuda=False):
+    table = TABLE_TUNED if tuned_gemms_active(cuda) else TABLE
+    return table.get((direction, C, O, HW), "miopen")
 
 
 def _pick(direction, t, w4d, x):
@@ -107,12 +147,12 @@ def _pick(direction, t, w4d, x):
     if MODE in ("gemm", "miopen"):
         algo = MODE
     elif MODE == "table":
-        algo = _from_table(direction, C, O, HW)
+        algo = _from_table(direction, C, O, HW, t.is_cuda)
     else:
         key = (direction, t.shape[0], C, O, HW)
         algo = _choice.get(key)
         if algo is None and _frozen:
-            algo = _from_table(direction, C, O, HW)
+            algo = _from_table(direction, C, O, HW, t.is_cuda)
         elif algo is None:
             with torch.no_grad():
                 ms_lib = _time_ms(_IMPL[(direction, "miopen")], t, w4d, x)
@@ -169,6 +209,10 @@ def share_choices(pg):
     _choice.clear()
     _choice.update(theirs)
     _frozen = True
+
+
+def report_tuned():
+    return "tuned GEMM solutions active (tunableop_gfx950.csv)" if _tuned_state else "library default GEMM solutions"
 
 
 def report():

@@ -80,6 +80,7 @@ def test_default_is_the_committed_table_and_it_is_deterministic():
     from scripts.conv1x1_table import downsample_shapes, shapes
     want = {(d, C, O, HW) for (C, O, HW) in list(shapes(224)) + list(downsample_shapes(224)) for d in ("fwd", "bwd")}
     assert set(conv1x1.TABLE) == want and set(conv1x1.TABLE.values()) <= {"gemm", "miopen"}
+    assert set(conv1x1.TABLE_TUNED) == want
     w = torch.randn(256, 64, 1, 1)
     x = torch.randn(2, 64, 56, 56)
     picks = [conv1x1._pick("fwd", x, w, None) for _ in range(3)]
@@ -108,3 +109,36 @@ def test_share_choices_freezes_auto_mode():
     assert conv1x1._frozen and conv1x1._pick("fwd", x, w, None) == "gemm"
     n = len(conv1x1._timings)
     assert conv1x1._pick("bwd", torch.randn(2, 16, 6, 6), w, x) == "miopen" and len(conv1x1._timings) == n
+
+
+def test_tuned_gemm_solution_file_and_its_route_table():
+    """tunableop_gfx950.csv (PyTorch TunableOp solutions for the GEMM route, tuning done offline) + the route table
+    column that goes with it: same keys as the plain table, only GEMM entries for ResNetV2-50's shapes at 512
+    samples, validators present (TunableOp ignores the file on any version / architecture mismatch).  On a box
+    without a GPU nothing is loaded and the plain table applies."""
+    assert set(conv1x1.TABLE_TUNED) == set(conv1x1.TABLE)
+    assert sum(conv1x1.TABLE_TUNED[k] != conv1x1.TABLE[k] for k in conv1x1.TABLE) >= 1
+    rows = open(conv1x1.TUNABLEOP_FILE).read().strip().splitlines()
+    validators = [r for r in rows if r.startswith("Validator,")]
+    assert {r.split(",")[1] for r in validators} >= {"PT_VERSION", "GCN_ARCH_NAME", "ROCBLAS_VERSION", "HIPBLASLT_VERSION"}
+    assert any("gfx950" in r for r in validators)
+    gemms = [r for r in rows if not r.startswith("Validator,")]
+    assert gemms and all(r.startswith("GemmStridedBatchedTunableOp_float_") and "_B_512_" in r for r in gemms)
+    if not torch.cuda.is_available():
+        assert conv1x1.tuned_gemms_active(False) is False and "default" in conv1x1.report_tuned()
+
+
+@pytest.mark.gpu
+def test_tuned_gemm_solutions_load_on_the_gpu_box_and_compute_the_same_convolution():
+    conv1x1.MODE = "table"
+    assert conv1x1.TUNABLEOP and conv1x1.tuned_gemms_active(True), "tunableop_gfx950.csv was rejected by TunableOp's validators"
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(512, 64, 56, 56, generator=g).cuda()
+    w = (torch.randn(64, 64, 1, 1, generator=g) / 8).cuda()
+    got = conv1x1._IMPL[("fwd", "gemm")](x, w, None)
+    want = F.conv2d(x, w)
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
+    got_b = conv1x1._IMPL[("bwd", "gemm")](want, w, x)
+    want_b = torch.ops.aten.convolution_backward(want, x, w, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1,
+                                                 (True, False, False))[0]
+    torch.testing.assert_close(got_b, want_b, rtol=1e-4, atol=1e-3)
