@@ -136,8 +136,12 @@ def _time_ms(fn, t, w4d, x):
     return (time.perf_counter() - t0) * 1e3 / CAL_ITERS
 
 
-def _from_table(direction, C, O, HW, cuda=False):
-    table = TABLE_TUNED if tuned_gemms_active(cuda) else TABLE
+TUNED_BATCH = 512        # the GEMM batch the solutions were tuned for (= DorPatch's default micro-batch)
+
+
+def _from_table(direction, C, O, HW, cuda=False, N=None):
+    # other batch sizes run the libraries' default solutions even with the file loaded: plain column for them
+    table = TABLE_TUNED if (tuned_gemms_active(cuda) and N == TUNED_BATCH) else TABLE
     return table.get((direction, C, O, HW), "miopen")
 
 
@@ -147,12 +151,12 @@ def _pick(direction, t, w4d, x):
     if MODE in ("gemm", "miopen"):
         algo = MODE
     elif MODE == "table":
-        algo = _from_table(direction, C, O, HW, t.is_cuda)
+        algo = _from_table(direction, C, O, HW, t.is_cuda, t.shape[0])
     else:
         key = (direction, t.shape[0], C, O, HW)
         algo = _choice.get(key)
         if algo is None and _frozen:
-            algo = _from_table(direction, C, O, HW, t.is_cuda)
+            algo = _from_table(direction, C, O, HW, t.is_cuda, t.shape[0])
         elif algo is None:
             with torch.no_grad():
                 ms_lib = _time_ms(_IMPL[(direction, "miopen")], t, w4d, x)

@@ -16,7 +16,7 @@ import torch  # noqa: E402
 from dorpatch_amd import conv1x1  # noqa: E402
 
 
-def time_ms(fn, iters=10):
+def time_ms(fn, iters=30):
     fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--n", type=int, default=512)
     ap.add_argument("--csv", default="tunableop_gfx950.csv")
     ap.add_argument("--max-ms", type=int, default=300)
+    ap.add_argument("--iters", type=int, default=20)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     shapes = sorted(conv1x1.TABLE)
@@ -49,7 +50,7 @@ def main():
     tun.enable(True)
     tun.tuning_enable(True)
     tun.set_max_tuning_duration(args.max_ms)
-    tun.set_max_tuning_iterations(20)
+    tun.set_max_tuning_iterations(args.iters)
     tun.set_filename(args.csv)
     tot_b = tot_t = 0.0
     for direction, C, O, HW, w, t in ops:
