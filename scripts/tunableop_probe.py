@@ -43,9 +43,13 @@ def main():
         w = torch.randn(O, C, 1, 1, device=dev) / C ** 0.5
         t = torch.randn(args.n, C if direction == "fwd" else O, H, H, device=dev)
         ops.append((direction, C, O, HW, w, t))
-    base = {}
+    base, lib = {}, {}
     for direction, C, O, HW, w, t in ops:
         base[(direction, C, O, HW)] = time_ms(lambda: conv1x1._IMPL[(direction, "gemm")](t, w, None))
+        H = int(round(HW ** 0.5))
+        xref = t if direction == "fwd" else torch.empty(args.n, C, H, H, device=dev)
+        lib[(direction, C, O, HW)] = time_ms(lambda: conv1x1._IMPL[(direction, "miopen")](t, w, xref))
+        del xref
     import torch.cuda.tunable as tun
     tun.enable(True)
     tun.tuning_enable(True)
@@ -60,7 +64,8 @@ def main():
         b = base[(direction, C, O, HW)]
         route = conv1x1.TABLE[(direction, C, O, HW)]
         print(json.dumps(dict(dir=direction, C=C, O=O, HW=HW, table_route=route, gemm_default_ms=round(b, 4),
-                              gemm_tuned_ms=round(tuned, 4), speedup=round(b / tuned, 3))), flush=True)
+                              gemm_tuned_ms=round(tuned, 4), speedup=round(b / tuned, 3),
+                              miopen_ms=round(lib[(direction, C, O, HW)], 4))), flush=True)
         if route == "gemm":
             tot_b += b
             tot_t += tuned
