@@ -134,6 +134,49 @@ def test_hot_loop_two_ranks_equals_one(tmp_path):
     assert torch.equal(outs[0]["pattern"], outs[1]["pattern"]) and torch.equal(outs[0]["mask"], outs[1]["mask"])
 
 
+def _placement_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        with _emu_patch().emulated_ops():
+            out = _run_placement(dist.group.WORLD, rank)
+        torch.save(out, os.path.join(out_dir, "place%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_placement(pg, rank):
+    """Two steps with the affine-placement extension: mask draws AND placements come from the per-image generators,
+    whose state every rank shares, so nothing but the one all-reduce is exchanged."""
+    from dorpatch_amd.attack import DorPatch, HotLoop
+    from dorpatch_amd.placement import RandomAffine
+    x, m, p, y, _, net = _problem()
+    np.random.seed(77 + 1000 * rank)            # ranks arrive with DIFFERENT global state: rank 0's seeds are broadcast
+    seen = []
+    hook = lambda d: seen.append(dict(idx=d["idx"].copy(), theta=d["theta"].copy(), g_adv=d["g_adv"].clone()))
+    loop = HotLoop(DorPatch(micro_batch=6, process_group=pg, verbose=False), net, x, 0.12, 10, "t/cfg/sub", 0, y,
+                   True, 1e-2, 1e-1, 0, 1, 10 ** 6, 7, 'topk', 1, S, 1e-3, 1e-3, 4.0, False,
+                   dict(init_mask=m, init_pattern=p, step_hook=hook, failure_refresh=10 ** 9,
+                        placement=RandomAffine(12.0, (0.9, 1.1), 3.0)))
+    for i in (1, 2):
+        loop.step(i)
+    out = dict(seen=seen, pattern=loop.adv_pattern.clone())
+    loop.close()
+    return out
+
+
+def test_placement_extension_two_ranks_stay_in_lock_step(tmp_path):
+    world = 2
+    mp.spawn(_placement_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), "place%d.pt" % r), weights_only=False) for r in range(world)]
+    for k in range(2):
+        assert np.array_equal(outs[0]["seen"][k]["idx"], outs[1]["seen"][k]["idx"])
+        assert np.array_equal(outs[0]["seen"][k]["theta"], outs[1]["seen"][k]["theta"])
+        assert torch.equal(outs[0]["seen"][k]["g_adv"], outs[1]["seen"][k]["g_adv"])
+    assert torch.equal(outs[0]["pattern"], outs[1]["pattern"])
+    assert not np.array_equal(outs[0]["seen"][0]["theta"], outs[0]["seen"][1]["theta"])     # a fresh draw every step
+
+
 # ---------------------------------------------------------------- evaluation driver, both shard modes
 def _driver_worker(rank, world, port, out_dir, shard):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
