@@ -1,5 +1,7 @@
 #!/bin/bash
-# Round 2, GPU call 6: same-box A/B of the round-1 tree (git 7faf45e, exported to .ab_r01/) against the current tree
+# Round 2, GPU call 6: same-box A/B of the round-1 tree (git 7faf45e, exported beforehand with
+#   mkdir .ab_r01 && git archive 7faf45e | tar -x -C .ab_r01 && (cd .ab_r01 && python -m dorpatch_amd.build)
+# and deleted afterwards) against the current tree
 # (alternating, so box-to-box clock differences cancel), MIOpen find mode, new GPU tests, micro-benchmarks.
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -31,9 +31,10 @@ def test_host_side_queries():
     assert lib.dp_abi_version() == _lib.DP_ABI_VERSION
     assert lib.dp_sumsq_nchunk(224 * 224) == 13 and lib.dp_sumsq_nchunk(384 * 384) == 36
     assert lib.dp_struct_ntile(224, 224) == 7 * 28
-    assert lib.dp_apply_bwd_nslab(64, 32, 224 * 224) == 1
+    # S-slab partition shared by dp_apply_bwd / dp_stem_dgrad_reduce / dp_apply_affine_bwd: ~4096 workgroups, >= 2 samples per slab
+    assert lib.dp_apply_bwd_nslab(64, 32, 224 * 224) == 2 and lib.dp_apply_bwd_nslab(512, 32, 224 * 224) == 1
     n = lib.dp_apply_bwd_nslab(1, 128, 224 * 224)
-    assert 1 < n <= 32
+    assert 1 < n <= 64 and lib.dp_apply_bwd_nslab(1, 2, 224 * 224) == 1
     assert lib.dp_error_string(1) is not None
 
 
