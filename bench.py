@@ -4,6 +4,9 @@
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --config {0,2,3}            # the other single-GPU BASELINE configs (parity-test cases, also timed)
+    A/B switches: --deterministic {auto,on,off}, --conv1x1 {table,auto,gemm,miopen}, DORPATCH_TUNABLEOP=0, --stem-split,
+                  --no-fused-gn, --micro-batch N, --find 1
 
 One "step" = one pass of the hot path (reference attack.py:184-342, stage 0) over one batch of
 synthetic input: blend/L2-project -> sample masks -> fused occlude+normalise (dp_apply_fwd) ->
@@ -299,8 +302,12 @@ def main():
         algo_bytes = B * S_local * 3 * P * 4          # 3*P*4 B written per EOT sample
         achieved = algo_bytes / (apply_ms * 1e-3) / 1e9
         value = B * S * args.steps / dt
-        traffic, traffic_note = (None, "skipped (--no-pmc)") if (args.no_pmc or DEVICE_OVERRIDE is not None) \
-            else pmc_traffic_live(B, S_local, H)
+        if args.no_pmc or DEVICE_OVERRIDE is not None:
+            traffic, traffic_note = None, "skipped (--no-pmc)"
+        elif world > 1:      # the per-GPU launch is the same at every N; the counter passes run in the N = 1 bench only
+            traffic, traffic_note = None, "measured at --gpus 1 only"
+        else:
+            traffic, traffic_note = pmc_traffic_live(B, S_local, H)
         note("PMC passes done: %s" % traffic_note)
         out = {
             "metric": "EOT-samples/sec", "value": round(value, 2), "unit": "EOT-samples/s",
