@@ -10,7 +10,8 @@ HIP kernels of ``csrc/dorpatch_hip.hip`` through the C ABI:
     dp_struct_loss                loss_struc                   (attack.py:33-45, 227-228)
     dp_mask_stats                 density + group lasso        (attack.py:237-245)
     dp_apply_fwd                  mask sampling apply (+Norm)  (attack.py:204-220, utils.py:77-78)
-    backbone fwd/bwd              torch / MIOpen (frozen)      (attack.py:222, 247)
+    backbone fwd/bwd              torch / MIOpen / hipBLASLt convolutions (frozen), with dorpatch_amd/resnetv2.py also
+                                  dp_gn_relu_*, dp_pad_maxpool_*, dp_stem_dgrad, dp_subsample2* (attack.py:222, 247)
     dp_cw_loss                    CW loss + dlogits            (attack.py:16-23, 224-230)
     dp_apply_bwd, dp_sum_slabs    sum_S of input grads         (autograd of attack.py:206-220)
     dp_project_update             chain rule, TV/sparsity grads, signed update (attack.py:247, 333-342)
