@@ -16,9 +16,10 @@ Neither route is always faster (``profiles/r01d_conv1x1_table_n512.jsonl``).
 
 ``MODE`` (environment variable ``DORPATCH_CONV1X1`` at import):
 
-``"table"`` (default)  the committed per-(gfx950, direction, C, O, HW) table ``conv1x1_gfx950.json``,
-                       measured once on an MI355X (two columns: with the libraries' default GEMM solutions,
-                       and with the tuned solutions of ``tunableop_gfx950.csv`` — see ``tuned_gemms_active``);
+``"table"`` (default)  the committed per-(gfx950, GEMM batch, direction, C, O, HW) table
+                       ``conv1x1_gfx950.json``, measured once on an MI355X (two columns: with the libraries' default
+                       GEMM solutions, and with the tuned solutions of ``tunableop_gfx950.csv`` — see
+                       ``tuned_gemms_active``; both files are derived by ``scripts/make_conv1x1_table.py``);
                        shapes it does not list go to MIOpen.  Deterministic:
                        every process, every rank and every run executes the same kernels in the same
                        order, so two runs give bit-identical gradients (the optimiser takes ``sign(grad)``:
@@ -60,8 +61,10 @@ def _parse(choices):
     return {tuple([k.split(":")[0]] + [int(v) for v in k.split(":")[1:]]): v for k, v in choices.items()}
 
 
-TABLE = _parse(_doc["choices"])                # routes with the BLAS libraries' default GEMM solutions
-TABLE_TUNED = _parse(_doc["choices_tuned"])    # routes when the tuned GEMM solutions below are active
+PLAIN = {int(n): _parse(c) for n, c in _doc["plain"].items()}   # routes with the BLAS libraries' default GEMM solutions
+TUNED = {int(n): _parse(c) for n, c in _doc["tuned"].items()}   # routes when the tuned GEMM solutions below are active
+TUNED_BATCH = 512        # DorPatch's default micro-batch: the GEMM batch of the headline configuration
+TABLE, TABLE_TUNED = PLAIN[TUNED_BATCH], TUNED[TUNED_BATCH]
 
 # Tuned GEMM solutions for the GEMM route (PyTorch TunableOp, tuning done offline on an MI355X by
 # scripts/tunableop_probe.py: 1.1-1.3x on most shapes, 2.9x on 64->64 and 1.9x on 256->64 @56x56, where hipBLASLt's
@@ -136,13 +139,14 @@ def _time_ms(fn, t, w4d, x):
     return (time.perf_counter() - t0) * 1e3 / CAL_ITERS
 
 
-TUNED_BATCH = 512        # the GEMM batch the solutions were tuned for (= DorPatch's default micro-batch)
-
-
 def _from_table(direction, C, O, HW, cuda=False, N=None):
-    # other batch sizes run the libraries' default solutions even with the file loaded: plain column for them
-    table = TABLE_TUNED if (tuned_gemms_active(cuda) and N == TUNED_BATCH) else TABLE
-    return table.get((direction, C, O, HW), "miopen")
+    """Route of one (GEMM batch, direction, shape).  The tuned column applies only to batch sizes the solution file was
+    tuned for (other batches run the libraries' default solutions even with the file loaded); batches without their own
+    plain column use the 512-sample one; shapes nobody measured go to MIOpen."""
+    key = (direction, C, O, HW)
+    if N in TUNED and tuned_gemms_active(cuda):
+        return TUNED[N].get(key, "miopen")
+    return PLAIN.get(N, PLAIN[TUNED_BATCH]).get(key, "miopen")
 
 
 def _pick(direction, t, w4d, x):

@@ -31,12 +31,15 @@ def time_ms(fn, iters=30):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=512)
+    ap.add_argument("--size", type=int, default=224, help="input side: 224 or 384 (the layer shapes follow from it)")
     ap.add_argument("--csv", default="tunableop_gfx950.csv")
     ap.add_argument("--max-ms", type=int, default=300)
     ap.add_argument("--iters", type=int, default=20)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    shapes = sorted(conv1x1.TABLE)
+    from scripts.conv1x1_table import downsample_shapes, shapes as stride1_shapes
+    todo = set(stride1_shapes(args.size)) | set(downsample_shapes(args.size))
+    shapes = sorted((d, C, O, HW) for (C, O, HW) in todo for d in ("fwd", "bwd"))
     ops = []
     for (direction, C, O, HW) in shapes:
         H = int(round(HW ** 0.5))
@@ -62,8 +65,8 @@ def main():
         fn()                                   # tunes this GEMM
         tuned = time_ms(fn)
         b = base[(direction, C, O, HW)]
-        route = conv1x1.TABLE[(direction, C, O, HW)]
-        print(json.dumps(dict(dir=direction, C=C, O=O, HW=HW, table_route=route, gemm_default_ms=round(b, 4),
+        route = conv1x1.TABLE.get((direction, C, O, HW), "miopen")
+        print(json.dumps(dict(dir=direction, N=args.n, size=args.size, C=C, O=O, HW=HW, table_route=route, gemm_default_ms=round(b, 4),
                               gemm_tuned_ms=round(tuned, 4), speedup=round(b / tuned, 3),
                               miopen_ms=round(lib[(direction, C, O, HW)], 4))), flush=True)
         if route == "gemm":
