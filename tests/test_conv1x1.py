@@ -123,7 +123,10 @@ def test_tuned_gemm_solution_file_and_its_route_table():
     assert {r.split(",")[1] for r in validators} >= {"PT_VERSION", "GCN_ARCH_NAME", "ROCBLAS_VERSION", "HIPBLASLT_VERSION"}
     assert any("gfx950" in r for r in validators)
     gemms = [r for r in rows if not r.startswith("Validator,")]
-    assert gemms and all(r.startswith("GemmStridedBatchedTunableOp_float_") and "_B_512_" in r for r in gemms)
+    assert gemms and all(r.startswith("GemmStridedBatchedTunableOp_float_") for r in gemms)
+    batches = {int(r.split("_B_")[1].split("_")[0]) for r in gemms}
+    assert batches == set(conv1x1.TUNED) and 512 in batches          # one route column per tuned GEMM batch
+    assert set(conv1x1.PLAIN) == set(conv1x1.TUNED)
     if not torch.cuda.is_available():
         assert conv1x1.tuned_gemms_active(False) is False and "default" in conv1x1.report_tuned()
 
