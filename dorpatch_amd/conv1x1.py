@@ -71,10 +71,56 @@ TABLE, TABLE_TUNED = PLAIN[TUNED_BATCH], TUNED[TUNED_BATCH]
 # default pick is poor).  Loaded once, at the first GPU call, with TUNING DISABLED: the file only maps GEMM shapes to
 # library solution ids — still "MFMA left to rocBLAS/hipBLASLt", and still deterministic (no timing at run time).
 # TunableOp validates the file against the installed PyTorch / HIP / rocBLAS / hipBLASLt versions and the GPU
-# architecture and ignores it on a mismatch, in which case the plain table applies.  DORPATCH_TUNABLEOP=0 disables.
+# architecture and ignores it on a mismatch, in which case the plain table applies; before the first use a child
+# process runs every tuned GEMM once (_selftest_tuned, ~10 s) and the file is only adopted if that process exits
+# cleanly.  DORPATCH_TUNABLEOP=0 disables.
 TUNABLEOP_FILE = os.path.join(_HERE, "tunableop_gfx950.csv")
 TUNABLEOP = os.environ.get("DORPATCH_TUNABLEOP", "1") != "0"
 _tuned_state = None      # None: not tried yet; True: solutions loaded; False: not in effect
+
+
+_SELFTEST = r'''
+import sys, torch
+import torch.cuda.tunable as tun
+sys.path.insert(0, sys.argv[2])
+from dorpatch_amd import conv1x1
+tun.enable(True); tun.tuning_enable(False); tun.record_untuned_enable(False)
+if not tun.read_file(sys.argv[1]):
+    sys.exit(3)
+import os
+torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+dev = torch.device("cuda", torch.cuda.current_device())
+for n, table in sorted(conv1x1.TUNED.items()):
+    for (direction, C, O, HW), route in sorted(table.items()):
+        if route != "gemm":
+            continue
+        H = int(round(HW ** 0.5))
+        w = torch.randn(O, C, 1, 1, device=dev)
+        t = torch.randn(n, C if direction == "fwd" else O, H, H, device=dev)
+        out = conv1x1._IMPL[(direction, "gemm")](t, w, None)
+        if not bool(torch.isfinite(out).all()):
+            sys.exit(4)
+torch.cuda.synchronize()
+'''
+
+
+def _selftest_tuned():
+    """Run every GEMM of the tuned route columns once, with the tuned solutions, in a CHILD process: a solution id
+    that a particular box's BLAS build rejects (or that faults) then costs a disabled feature, not the run.  The
+    verdict is passed to child processes through DORPATCH_TUNABLEOP_VERIFIED."""
+    verdict = os.environ.get("DORPATCH_TUNABLEOP_VERIFIED")
+    if verdict in ("0", "1"):
+        return verdict == "1"
+    import subprocess
+    import sys
+    env = dict(os.environ, DORPATCH_TUNABLEOP="0")          # the child loads the file explicitly
+    try:
+        rc = subprocess.run([sys.executable, "-c", _SELFTEST, TUNABLEOP_FILE, os.path.dirname(_HERE)], env=env,
+                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180).returncode
+    except (OSError, subprocess.SubprocessError):
+        rc = -1
+    os.environ["DORPATCH_TUNABLEOP_VERIFIED"] = "1" if rc == 0 else "0"
+    return rc == 0
 
 
 def tuned_gemms_active(device_is_cuda=True):
@@ -82,7 +128,7 @@ def tuned_gemms_active(device_is_cuda=True):
     global _tuned_state
     if _tuned_state is None and device_is_cuda:
         _tuned_state = False
-        if TUNABLEOP and os.path.exists(TUNABLEOP_FILE):
+        if TUNABLEOP and os.path.exists(TUNABLEOP_FILE) and _selftest_tuned():
             try:
                 import torch.cuda.tunable as tun
                 tun.enable(True)
