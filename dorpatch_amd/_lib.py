@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
-DP_ABI_VERSION = 5
+DP_ABI_VERSION = 6
 DP_MAX_RECTS = 4
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
@@ -62,6 +62,7 @@ PROTOTYPES = {
     "dp_argmax": (_I, [_P, _I, _I, _P, _P]),
     "dp_gn_relu_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P]),
     "dp_gn_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "dp_gn_relu_bwd_gather": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "dp_pad_maxpool_fwd": (_I, [_P, _L, _I, _I, _P, _P, _P]),
     "dp_pad_maxpool_bwd": (_I, [_P, _P, _L, _I, _I, _P, _P]),
     "dp_stem_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),

@@ -900,7 +900,45 @@ struct GnArgs {
   const float *dres;  // backward: optional extra gradient w.r.t. (x + res), added to the result
   int C, HW, Cg;      // channels, pixels per channel, channels per group
   float eps, inv_hw;  // inv_hw = 1 / HW
+  // backward, gather form (dp_gn_relu_bwd_gather): output sample n takes its x / mean / rstd from SOURCE sample
+  // smap[n]; the source samples live in up to kGnMaxTabs slabs of tab_rows samples each (the micro-batches of one
+  // step's forward), so a backward over the samples that still carry gradient never copies an activation.
+  const int *smap;                 // nullptr: source = n, one slab (A.x)
+  const float *xtab[8];
+  int tab_rows;                    // 0: one slab (A.x)
 };
+constexpr int kGnMaxTabs = 8;
+
+struct GnSource {
+  const float *x;   // the (sample, group)'s first element
+  size_t stat;      // index of its mean / rstd
+};
+
+// Uniform (scalar) address arithmetic: one integer division by G per workgroup and a select chain over the slabs.
+__device__ __forceinline__ GnSource gn_source(const GnArgs &A, int ng, size_t L) {
+  GnSource S;
+  if (!A.smap) {
+    S.x = A.x + (size_t)ng * L;
+    S.stat = (size_t)ng;
+    return S;
+  }
+  const int G = A.C / A.Cg;
+  const int n = ng / G, g = ng - n * G;
+  const int src = A.smap[n];
+  S.stat = (size_t)src * G + g;
+  const float *base = A.x;
+  int row = src;
+  if (A.tab_rows) {
+    const int t = src / A.tab_rows;
+    row = src - t * A.tab_rows;
+    base = A.xtab[0];
+#pragma unroll
+    for (int k = 1; k < kGnMaxTabs; ++k)
+      if (t == k) base = A.xtab[k];
+  }
+  S.x = base + ((size_t)row * G + g) * L;
+  return S;
+}
 
 // channel (within the group) of flat element e of the group; exact for e < 2^20, HW >= 1
 __device__ __forceinline__ int chan_of(int e, float inv_hw) {
@@ -1053,7 +1091,8 @@ __global__ __launch_bounds__(T, MW) void k_gn_relu_bwd(GnArgs A, const float *__
   const int G = A.C / A.Cg;
   const int cbase = (ng % G) * A.Cg;
   const int L = A.Cg * A.HW, L4 = L >> 2;
-  const f4 *x4 = reinterpret_cast<const f4 *>(A.x + (size_t)ng * L);
+  const GnSource src = gn_source(A, ng, (size_t)L);
+  const f4 *x4 = reinterpret_cast<const f4 *>(src.x);
   const f4 *g4 = reinterpret_cast<const f4 *>(dy + (size_t)ng * L);
   f4 *o4 = reinterpret_cast<f4 *>(dx + (size_t)ng * L);
   f4 xh[V], dh[V];  // raw x / dy first, transformed in place below
@@ -1073,7 +1112,7 @@ __global__ __launch_bounds__(T, MW) void k_gn_relu_bwd(GnArgs A, const float *__
   }
   const float *ga = LC ? s_gb : A.gamma + cbase;
   const float *be = LC ? s_gb + kGnLdsCh : A.beta + cbase;
-  const float mean = mean_in[ng], rstd = rstd_in[ng];
+  const float mean = mean_in[src.stat], rstd = rstd_in[src.stat];
   const bool uniform = (A.HW & 3) == 0;
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -1196,10 +1235,11 @@ __global__ __launch_bounds__(kGnStreamT) void k_gn_relu_bwd_stream(
   const int G = A.C / A.Cg;
   const int cbase = (ng % G) * A.Cg;
   const int L = A.Cg * A.HW, L4 = L >> 2;
-  const f4 *x4 = reinterpret_cast<const f4 *>(A.x + (size_t)ng * L);
+  const GnSource src = gn_source(A, ng, (size_t)L);
+  const f4 *x4 = reinterpret_cast<const f4 *>(src.x);
   const f4 *g4 = reinterpret_cast<const f4 *>(dy + (size_t)ng * L);
   f4 *o4 = reinterpret_cast<f4 *>(dx + (size_t)ng * L);
-  const float mean = mean_in[ng], rstd = rstd_in[ng];
+  const float mean = mean_in[src.stat], rstd = rstd_in[src.stat];
   const bool uniform = (A.HW & 3) == 0;
   float s1 = 0.f, s2 = 0.f;
   for (int i = threadIdx.x; i < L4; i += T) {
@@ -2097,6 +2137,8 @@ static int gn_check(const float *x, const float *gamma, const float *beta, int N
   DP_REQUIRE((long)N * G <= 0x7fffffffL);
   A.x = x; A.gamma = gamma; A.beta = beta;
   A.res = nullptr; A.sum_out = nullptr; A.dres = nullptr;
+  A.smap = nullptr; A.tab_rows = 0;
+  for (int k = 0; k < kGnMaxTabs; ++k) A.xtab[k] = nullptr;
   A.C = C; A.HW = HW; A.Cg = C / G;
   A.eps = eps; A.inv_hw = 1.f / (float)HW;
   return 0;
@@ -2125,6 +2167,27 @@ int dp_gn_relu_bwd(const float *dy, const float *dres, const float *x, const flo
   DP_REQUIRE(!dres || aligned16(dres));
   A.dres = dres;
   return launch_gn_bwd(kGnDefaultVariant, A, N, dy, mean, rstd, dx, as_stream(stream));
+}
+
+int dp_gn_relu_bwd_gather(const float *dy, const float *dres, const float *const *x_tabs, int n_tabs,
+                          int tab_rows, const int *smap, const float *gamma, const float *beta,
+                          const float *mean, const float *rstd, int M, int C, int HW, int G, float *dx,
+                          dp_stream_t stream) {
+  DP_REQUIRE(x_tabs && smap && n_tabs >= 1 && n_tabs <= kGnMaxTabs && tab_rows > 0);
+  GnArgs A;
+  const int rc = gn_check(x_tabs[0], gamma, beta, M, C, HW, G, A, 0.f);
+  if (rc) return rc;
+  DP_REQUIRE(dy && mean && rstd && dx && aligned16(dy) && aligned16(dx));
+  DP_REQUIRE(!dres || aligned16(dres));
+  DP_REQUIRE((long)n_tabs * tab_rows * G <= 0x7fffffffL);
+  for (int k = 0; k < n_tabs; ++k) {
+    DP_REQUIRE(x_tabs[k] && aligned16(x_tabs[k]));
+    A.xtab[k] = x_tabs[k];
+  }
+  A.smap = smap;
+  A.tab_rows = tab_rows;
+  A.dres = dres;
+  return launch_gn_bwd(kGnDefaultVariant, A, M, dy, mean, rstd, dx, as_stream(stream));
 }
 
 int dp_pad_maxpool_fwd(const float *x, int64_t NC, int Hin, int Win, float *y, uint8_t *code,

@@ -338,16 +338,22 @@ def gn_relu_supported(x, groups):
     return L % 4 == 0 and L < (1 << 20)
 
 
-def gn_relu_fwd(x, weight, bias, groups, eps, res=None):
+def gn_relu_fwd(x, weight, bias, groups, eps, res=None, stats_out=None):
     """s = x (+ res);  y = relu(group_norm(s)).  Returns (y, mean, rstd, s); mean / rstd are the
-    per-(sample, group) statistics the backward needs; s is x itself when res is None."""
+    per-(sample, group) statistics the backward needs; s is x itself when res is None.
+    ``stats_out`` = (mean, rstd) views of N*groups floats to write the statistics into."""
     lib = _lib.load()
     _chk(x, torch.float32, "x"), _chk(weight, torch.float32, "weight"), _chk(bias, torch.float32, "bias")
     N, C = x.shape[0], x.shape[1]
     HW = int(np.prod(x.shape[2:]))
     y = torch.empty_like(x)
-    mean = torch.empty((N * groups,), dtype=torch.float32, device=x.device)
-    rstd = torch.empty_like(mean)
+    if stats_out is None:
+        mean = torch.empty((N * groups,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+    else:
+        mean, rstd = stats_out
+        _chk(mean, torch.float32, "mean"), _chk(rstd, torch.float32, "rstd")
+        assert mean.numel() == N * groups and rstd.numel() == N * groups
     ssum = None
     if res is not None:
         _chk(res, torch.float32, "res")
@@ -370,6 +376,30 @@ def gn_relu_bwd(dy, x, weight, bias, mean, rstd, groups, dres=None):
     dx = torch.empty_like(x)
     _lib.check(lib.dp_gn_relu_bwd(_p(dy), _p(dres), _p(x), _p(weight), _p(bias), _p(mean), _p(rstd), N, C, HW,
                                   int(groups), _p(dx), _stream()), "dp_gn_relu_bwd")
+    return dx
+
+
+def gn_relu_bwd_gather(dy, x_tabs, tab_rows, smap, weight, bias, mean, rstd, groups, dres=None):
+    """``gn_relu_bwd`` over M selected samples: output sample n takes x / mean / rstd of SOURCE sample ``smap[n]``.
+    ``x_tabs``: the GroupNorm inputs saved by the micro-batches of one forward, a list of (rows, C, ...) tensors, every
+    one but the last with ``tab_rows`` rows (source sample s = row s % tab_rows of x_tabs[s // tab_rows]);
+    ``mean`` / ``rstd``: (total source samples * groups,), indexed by source sample.  dy / dres / result: (M, C, ...)."""
+    lib = _lib.load()
+    _chk(dy, torch.float32, "dy"), _chk(smap, torch.int32, "smap")
+    _chk(mean, torch.float32, "mean"), _chk(rstd, torch.float32, "rstd")
+    if dres is not None:
+        _chk(dres, torch.float32, "dres")
+    for t in x_tabs:
+        _chk(t, torch.float32, "x_tabs[k]")
+        assert t.shape[1:] == dy.shape[1:] and t.shape[0] <= tab_rows
+    assert all(t.shape[0] == tab_rows for t in x_tabs[:-1]) and smap.numel() == dy.shape[0]
+    M, C = dy.shape[0], dy.shape[1]
+    HW = int(np.prod(dy.shape[2:]))
+    ptrs = (ctypes.c_void_p * len(x_tabs))(*[t.data_ptr() for t in x_tabs])
+    dx = torch.empty_like(dy)
+    _lib.check(lib.dp_gn_relu_bwd_gather(_p(dy), _p(dres), ptrs, len(x_tabs), int(tab_rows), _p(smap), _p(weight),
+                                         _p(bias), _p(mean), _p(rstd), M, C, HW, int(groups), _p(dx), _stream()),
+               "dp_gn_relu_bwd_gather")
     return dx
 
 

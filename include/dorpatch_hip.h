@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DP_ABI_VERSION 5
+#define DP_ABI_VERSION 6
 #define DP_MAX_RECTS 4 /* occlusion windows per mask-table entry */
 
 typedef void *dp_stream_t; /* hipStream_t */
@@ -221,6 +221,17 @@ int dp_gn_relu_fwd(const float *x, const float *res, float *sum_out, const float
 int dp_gn_relu_bwd(const float *dy, const float *dres, const float *x, const float *gamma,
                    const float *beta, const float *mean, const float *rstd, int N, int C, int HW,
                    int G, float *dx, dp_stream_t stream);
+/* Gather form of the backward, for a backward pass over only the EOT samples that still carry gradient (the CW hinge
+ * of attack.py:16-23 gives an exactly zero logit gradient to every sample whose margin is met, and the frozen,
+ * per-sample-normalised backbone then yields an exactly zero input gradient for it): output sample n (of M) takes its
+ * x / mean / rstd from SOURCE sample smap[n] (device, M int32, each in [0, n_tabs*tab_rows)).  Source sample s lives
+ * in slab x_tabs[s / tab_rows] at row s % tab_rows — x_tabs is a HOST array of n_tabs (<= 8) device pointers, the
+ * GroupNorm inputs saved by the micro-batches of one step's forward; mean / rstd are indexed by s*G + g.  dy, dres,
+ * dx are dense (M,C,HW).  Same arithmetic and traffic as dp_gn_relu_bwd. */
+int dp_gn_relu_bwd_gather(const float *dy, const float *dres, const float *const *x_tabs, int n_tabs,
+                          int tab_rows, const int32_t *smap, const float *gamma, const float *beta,
+                          const float *mean, const float *rstd, int M, int C, int HW, int G, float *dx,
+                          dp_stream_t stream);
 
 /* ---- a-8  ConstantPad2d(1, 0) + MaxPool2d(3, stride 2) of the BiT stem, fused ----
  * (timm 0.6.7 create_resnetv2_stem 'fixed'; reference utils.py:51-63, attack.py:222, 247.)
