@@ -176,8 +176,9 @@ class DorPatch(object):
     (``utils.py:17``) and is not run-to-run reproducible on a GPU.
     """
 
-    def __init__(self, micro_batch=512, process_group=None, verbose=True, deterministic="auto"):
+    def __init__(self, micro_batch=512, process_group=None, verbose=True, deterministic="auto", skip_satisfied=True):
         self.micro_batch = int(micro_batch)
+        self.skip_satisfied = bool(skip_satisfied)
         if deterministic not in (True, False, "auto"):
             raise ValueError("deterministic must be True, False or 'auto'")
         self.deterministic = deterministic
@@ -209,7 +210,9 @@ class DorPatch(object):
         of per-step internals — used by the parity tests), ``switch_iteration`` (500),
         ``failure_refresh`` (100), ``failure_sampling_start`` (1000), ``log_every`` (20), ``stem_split`` (False; True: with
         dorpatch_amd's own ResNetV2 the stem's input gradient and the S-reduction run as one kernel — bit-identical,
-        measured slightly slower), ``placement``
+        measured slightly slower), ``skip_satisfied`` (default: the constructor's, True — see ``HotLoop._fb_taped``),
+        ``tape_tabs`` (micro-batches whose activations one backward may draw from, default: what fits in half of the free
+        HBM, at most 8), ``backward_ladder`` (batch sizes the selected-sample backward may use), ``placement``
         (EXTENSION, not in the reference: e.g. ``dorpatch_amd.placement.RandomAffine()`` — every EOT sample sees the
         patch under its own random affine placement; ``None`` = the reference's identity placement).
         """
@@ -283,6 +286,10 @@ class DorPatch(object):
 # ======================================================================================
 # implementation
 # ======================================================================================
+
+def tape_z_channels(net):
+    return net.stem.conv.out_channels
+
 
 def _dp_norm(norm):
     return ops.RAW_NORM if norm is None else ops.make_norm(norm[0], norm[1], 0.5)
@@ -460,6 +467,14 @@ class HotLoop(object):
         self._stem_split = bool(probe is not None and extras.get("stem_split", False) and self.placement is None
                                 and probe(self.x))
         self.theta_np = None
+        # The backward pass runs only over the EOT samples that still carry gradient (dorpatch_amd/taped.py): needs
+        # dorpatch_amd's own frozen ResNetV2; any other classifier goes through autograd, all samples.
+        from . import taped
+        self._taped = bool(extras.get("skip_satisfied", owner.skip_satisfied)) and taped.eligible(self.net)
+        self._tape_tabs = extras.get("tape_tabs")            # None: sized from free memory after the first micro-batch
+        self._ladder_user = extras.get("backward_ladder")
+        self._det_sizes = {}                                   # backward batch size -> library kernels must be forced deterministic
+        self.n_forward = self.n_active = self.n_backward = 0   # samples: forwarded / carrying gradient / back-propagated (incl. padding)
 
     # ---------------------------------------------------------------- plumbing
     def close(self):
@@ -758,25 +773,177 @@ class HotLoop(object):
             inp_all = ops.apply_fwd(self.adv_x, self.table, idx, idx2, self.dn, timer=timer)   # (B*Sl,3,H,W)
         self._placement_ctx = (theta, theta_inv)
         loss_flat = self._own_loss                 # this rank's (B, S_local) slab of the step's all-reduce buffer
+        # micro-batches: (first sample, end sample, first image, end image, first local mask, end local mask, accumulate)
+        chunks = []
         if Sl <= mb:
             ipm = max(1, mb // Sl)                 # whole images per micro-batch
             for b0 in range(0, B, ipm):
                 b1 = min(B, b0 + ipm)
-                G = self._fb_chunk(inp_all[b0 * Sl:b1 * Sl], self.y[b0:b1], crit_flags[b0:b1], Sl,
-                                   upstream, loss_flat[b0 * Sl:b1 * Sl], self.pred[b0 * Sl:b1 * Sl])
-                self._reduce_over_samples(G, idx[b0:b1], None if idx2 is None else idx2[b0:b1], b1 - b0,
-                                          self.g_adv[b0:b1], False, (b0, b1, 0, Sl))
+                chunks.append((b0 * Sl, b1 * Sl, b0, b1, 0, Sl, False))
         else:
             for b in range(B):
                 for k, s0 in enumerate(range(0, Sl, mb)):
                     s1 = min(Sl, s0 + mb)
-                    n0, n1 = b * Sl + s0, b * Sl + s1
-                    G = self._fb_chunk(inp_all[n0:n1], self.y[b:b + 1], crit_flags[b:b + 1], s1 - s0,
-                                       upstream, loss_flat[n0:n1], self.pred[n0:n1])
-                    self._reduce_over_samples(G, idx[b:b + 1, s0:s1].contiguous(),
-                                              None if idx2 is None else idx2[b:b + 1, s0:s1].contiguous(), 1,
-                                              self.g_adv[b:b + 1], k > 0, (b, b + 1, s0, s1))
+                    chunks.append((b * Sl + s0, b * Sl + s1, b, b + 1, s0, s1, k > 0))
+        self.n_forward += B * Sl
+        if self._taped:
+            from . import taped
+            try:
+                self._fb_taped(inp_all, chunks, idx, idx2, crit_flags, upstream, loss_flat)
+            except taped.Unsupported as why:        # e.g. an input size the fused kernels do not take: autograd, all samples
+                self.o._log(">> selected-sample backward not available here (%s): back-propagating every sample" % why)
+                self._taped = False
+        if not self._taped:
+            for c in chunks:
+                n0, n1, b0, b1, s0, s1, _ = c
+                G = self._fb_chunk(inp_all[n0:n1], self.y[b0:b1], crit_flags[b0:b1], s1 - s0,
+                                   upstream, loss_flat[n0:n1], self.pred[n0:n1])
+                self._reduce_chunk(G, c, idx, idx2)
+            self.n_active += B * Sl
+            self.n_backward += B * Sl
         self._own_pred.copy_(self.pred)            # int32 -> fp32 (class ids are exact), rides in the same buffer
+
+    def _reduce_chunk(self, G, c, idx, idx2):
+        n0, n1, b0, b1, s0, s1, accumulate = c
+        if s1 - s0 == self.S_local:                # whole images
+            self._reduce_over_samples(G, idx[b0:b1], None if idx2 is None else idx2[b0:b1], b1 - b0,
+                                      self.g_adv[b0:b1], accumulate, (b0, b1, s0, s1))
+        else:                                      # a slice of one image's samples
+            self._reduce_over_samples(G, idx[b0:b1, s0:s1].contiguous(),
+                                      None if idx2 is None else idx2[b0:b1, s0:s1].contiguous(), 1,
+                                      self.g_adv[b0:b1], accumulate, (b0, b1, s0, s1))
+
+    # ---------------------------------------------------------------- backward over the samples that carry gradient
+    def _fb_taped(self, inp_all, chunks, idx, idx2, crit_flags, upstream, loss_flat):
+        """Forward every micro-batch on an explicit tape, then back-propagate ONLY the EOT samples whose logit gradient
+        is non-zero.  The CW hinge (attack.py:16-23) gives a sample whose margin is met an exactly zero logit gradient,
+        and the frozen, per-sample-normalised backbone then gives it an exactly zero input gradient — the reference
+        computes those zeros (attack.py:247), here they are not computed; images that have early-stopped (their update
+        is multiplied by lr = 0) are skipped as well.  The selected samples of up to ``tape_tabs`` micro-batches are
+        compacted into backward batches of the sizes the library routes are tuned for."""
+        from . import taped
+        if self._det_pending:      # same library kernels as the autograd path at this batch size: decide there, once
+            n0, n1, b0, b1, s0, s1, _ = chunks[0]
+            self._fb_chunk(inp_all[n0:n1], self.y[b0:b1], crit_flags[b0:b1], s1 - s0, upstream,
+                           loss_flat[n0:n1], self.pred[n0:n1])
+            self._det_sizes[n1 - n0] = False       # verified (or deterministic kernels are now forced globally)
+        pos = 0
+        while pos < len(chunks):
+            rows = chunks[pos][1] - chunks[pos][0]
+            cap = self._tape_tabs if self._tape_tabs is not None else 1      # first group of the run: measure a tape
+            group = [chunks[pos]]
+            while (len(group) < min(cap, taped.MAX_TABS) and pos + len(group) < len(chunks)
+                   and group[-1][1] - group[-1][0] == rows):
+                nxt = chunks[pos + len(group)]
+                if nxt[1] - nxt[0] > rows:
+                    break
+                group.append(nxt)
+            pos += len(group)
+            self._fb_group(group, rows, inp_all, idx, idx2, crit_flags, upstream, loss_flat)
+
+    def _fb_group(self, group, tab_rows, inp_all, idx, idx2, crit_flags, upstream, loss_flat):
+        from . import taped
+        net, dev = self.net, self.dev
+        tape = taped.StepTape(tab_rows, len(group))
+        dls = []
+        for n0, n1, b0, b1, s0, s1, _ in group:
+            inp = inp_all[n0:n1]
+            z = None
+            if self._stem_split:
+                conv = net.stem.conv
+                with torch.no_grad():
+                    z = torch.nn.functional.conv2d(inp, conv.weight, None, conv.stride, conv.padding)
+            logits = taped.forward(net, inp, tape, z=z)
+            _, dlogits, pred = ops.cw_loss(logits.float().contiguous(), self.y[b0:b1].contiguous(),
+                                           crit_flags[b0:b1].contiguous(), s1 - s0, self.confidence, upstream,
+                                           loss_out=loss_flat[n0:n1])
+            self.pred[n0:n1].copy_(pred)
+            dls.append(dlogits)
+        if self._tape_tabs is None:               # size the tapes of the rest of the run
+            self._tape_tabs = self._tabs_that_fit(tape.nbytes())
+        n_group = tape.n_samples
+        dl = dls[0] if len(dls) == 1 else torch.cat(dls)
+        act = (dl != 0).any(dim=1).cpu().numpy()   # host sync: the forward of this group is complete
+        img_on = np.asarray([st.active for st in self.img])
+        if not img_on.all():                       # early-stopped images: lr = 0, their gradient is never used
+            act &= np.concatenate([np.repeat(img_on[b0:b1], s1 - s0) for _, _, b0, b1, s0, s1, _ in group])
+        nz = np.flatnonzero(act)
+        self.n_active += len(nz)
+        through_stem = not self._stem_split
+        if len(nz) == n_group:                     # everything carries gradient: one backward per micro-batch, in place
+            for j, c in enumerate(group):
+                r = c[1] - c[0]
+                sel = torch.arange(j * tab_rows, j * tab_rows + r, dtype=torch.int32, device=dev)
+                G = self._taped_backward(tape, dls[j], sel, r, through_stem)
+                self._reduce_chunk(G, c, idx, idx2)
+            self.n_backward += n_group
+            return
+        plan = taped.plan_chunks(len(nz), *self._ladder(tab_rows))
+        g_shape = (n_group, tape_z_channels(net)) + tuple(tape.z_hw) if self._stem_split else \
+            (n_group, 3, self.H, self.W)
+        G_full = torch.zeros(g_shape, dtype=torch.float32, device=dev)
+        if plan:
+            smap_np, keep_np, p = [], [], 0
+            for real, size in plan:
+                rows = nz[p:p + real]
+                smap_np.append(np.concatenate([rows, np.repeat(rows[-1:], size - real)]))
+                keep_np.append(np.concatenate([np.ones(real, np.int64), np.zeros(size - real, np.int64)]))
+                p += real
+            both = torch.as_tensor(np.stack([np.concatenate(smap_np), np.concatenate(keep_np)]), device=dev)   # one upload
+            smap_l, keep = both[0], both[1].to(torch.float32)
+            smap = smap_l.to(torch.int32)
+            dl_sel = dl.index_select(0, smap_l) * keep[:, None]         # padding rows: zero logit gradient
+            o = 0
+            for real, size in plan:
+                G = self._taped_backward(tape, dl_sel[o:o + size].contiguous(), smap[o:o + size].contiguous(), size,
+                                         through_stem)
+                G_full.index_copy_(0, smap_l[o:o + real], G[:real])
+                o += size
+                self.n_backward += size
+        for j, c in enumerate(group):
+            self._reduce_chunk(G_full[j * tab_rows:j * tab_rows + (c[1] - c[0])], c, idx, idx2)
+
+    def _taped_backward(self, tape, dl, sel, size, through_stem):
+        """taped.backward, with deterministic="auto" extended to this backward batch size: the first time a size is
+        used its gradient is computed twice; if the bits differ (atomic split-K kernels at small batches) that size runs
+        with deterministic library kernels from then on.  A rank-local decision: no collective here."""
+        from . import taped
+        forced = self._det_sizes.get(size)
+        auto = self.o.deterministic == "auto" and not torch.backends.cudnn.deterministic
+        if forced is None and auto:
+            first = taped.backward(self.net, tape, dl, sel, through_stem)
+            again = taped.backward(self.net, tape, dl, sel, through_stem)
+            forced = self._det_sizes[size] = not torch.equal(first, again)
+            if not forced:
+                return again
+            self.o._log(">> library convolutions are not run-to-run deterministic at backward batch %d: "
+                        "deterministic kernels for that size" % size)
+        if forced and not torch.backends.cudnn.deterministic:
+            torch.backends.cudnn.deterministic = True
+            try:
+                return taped.backward(self.net, tape, dl, sel, through_stem)
+            finally:
+                torch.backends.cudnn.deterministic = False
+        return taped.backward(self.net, tape, dl, sel, through_stem)
+
+    def _ladder(self, tab_rows):
+        """(batch sizes a selected-sample backward may use, cost of one pass at each size in sample-equivalents).
+        Sizes: the micro-batch itself plus the smaller batches the committed library routes were measured for
+        (conv1x1.TUNED); cost = size + 7 (micro-batches of 64 / 128 measured 10.9 % / 4.8 % slower per sample than 512:
+        profiles/r02a_ab_small_microbatch.jsonl)."""
+        from . import conv1x1
+        sizes = self._ladder_user or [L for L in sorted(conv1x1.TUNED) if L < tab_rows]
+        sizes = sorted(set(int(L) for L in sizes if 0 < int(L) <= tab_rows) | {int(tab_rows)})
+        return sizes, {L: L + 7.0 for L in sizes}
+
+    def _tabs_that_fit(self, tape_bytes):
+        """Micro-batches whose saved activations may be alive at once: half of the free HBM, at most 8."""
+        from . import taped
+        if not self.dev.type == "cuda":
+            return taped.MAX_TABS
+        free, _ = torch.cuda.mem_get_info(self.dev)
+        free += torch.cuda.memory_reserved(self.dev) - torch.cuda.memory_allocated(self.dev)
+        return int(max(1, min(taped.MAX_TABS, (free // 2 + tape_bytes) // max(1, tape_bytes))))
 
     def _reduce_over_samples(self, G, idx, idx2, B, out, accumulate, where):
         """sum_S keep * d loss/d masked-input (/ std) -> d loss/d adv_x for B images (autograd of attack.py:206-220).
