@@ -174,9 +174,15 @@ class DorPatch(object):
     the table-routed 1x1 convolutions and the fixed-order reductions of every HIP kernel, identical inputs
     then give identical bits either way.  The reference sets ``cudnn.benchmark = True``
     (``utils.py:17``) and is not run-to-run reproducible on a GPU.
+    ``skip_satisfied`` (default False = the reference's behaviour, every sample is back-propagated, ``attack.py:247``):
+    opt-in — the backward pass runs only over the EOT samples whose CW hinge is still active (a satisfied sample's
+    gradient is exactly zero), see ``HotLoop._fb_taped``.  Same gradients to ~1e-6 of their scale (the compacted
+    backward batches take other library kernels), up to 1.9x fewer ms per step once most samples meet their margin
+    (``profiles/r02t_*``); costs one extra host sync per step and, the first time a new backward batch size occurs,
+    MIOpen's one-off kernel loading for that size.
     """
 
-    def __init__(self, micro_batch=512, process_group=None, verbose=True, deterministic="auto", skip_satisfied=True):
+    def __init__(self, micro_batch=512, process_group=None, verbose=True, deterministic="auto", skip_satisfied=False):
         self.micro_batch = int(micro_batch)
         self.skip_satisfied = bool(skip_satisfied)
         if deterministic not in (True, False, "auto"):
@@ -210,7 +216,9 @@ class DorPatch(object):
         of per-step internals — used by the parity tests), ``switch_iteration`` (500),
         ``failure_refresh`` (100), ``failure_sampling_start`` (1000), ``log_every`` (20), ``stem_split`` (False; True: with
         dorpatch_amd's own ResNetV2 the stem's input gradient and the S-reduction run as one kernel — bit-identical,
-        measured slightly slower), ``skip_satisfied`` (default: the constructor's, True — see ``HotLoop._fb_taped``),
+        measured slightly slower), ``skip_satisfied`` (default: the constructor's, False — see ``HotLoop._fb_taped``), ``skip_min_fraction`` (0.2: the
+        selected-sample backward compacts a group of micro-batches only when at least this fraction of its samples is
+        skippable; below it every sample is back-propagated in place),
         ``tape_tabs`` (micro-batches whose activations one backward may draw from, default: what fits in half of the free
         HBM, at most 8), ``backward_ladder`` (batch sizes the selected-sample backward may use), ``placement``
         (EXTENSION, not in the reference: e.g. ``dorpatch_amd.placement.RandomAffine()`` — every EOT sample sees the
@@ -473,6 +481,7 @@ class HotLoop(object):
         self._taped = bool(extras.get("skip_satisfied", owner.skip_satisfied)) and taped.eligible(self.net)
         self._tape_tabs = extras.get("tape_tabs")            # None: sized from free memory after the first micro-batch
         self._ladder_user = extras.get("backward_ladder")
+        self._skip_min_fraction = float(extras.get("skip_min_fraction", 0.2))
         self._det_sizes = {}                                   # backward batch size -> library kernels must be forced deterministic
         self.n_forward = self.n_active = self.n_backward = 0   # samples: forwarded / carrying gradient / back-propagated (incl. padding)
 
@@ -870,7 +879,9 @@ class HotLoop(object):
         nz = np.flatnonzero(act)
         self.n_active += len(nz)
         through_stem = not self._stem_split
-        if len(nz) == n_group:                     # everything carries gradient: one backward per micro-batch, in place
+        if n_group - len(nz) < max(1.0, self._skip_min_fraction * n_group):
+            # (nearly) everything carries gradient: one backward per micro-batch, in place — compaction (odd batch sizes,
+            # a scatter of the result) would cost more than back-propagating the few exact zeros
             for j, c in enumerate(group):
                 r = c[1] - c[0]
                 sel = torch.arange(j * tab_rows, j * tab_rows + r, dtype=torch.int32, device=dev)

@@ -1,4 +1,4 @@
-"""``DorPatch(skip_satisfied=True)`` (the default): the backward pass runs only over the EOT samples whose CW hinge is
+"""``DorPatch(skip_satisfied=True)`` (opt-in): the backward pass runs only over the EOT samples whose CW hinge is
 active (``HotLoop._fb_taped`` + ``dorpatch_amd/taped.py``) — against the same step with every sample back-propagated
 through autograd (``skip_satisfied=False``, what the reference does at ``attack.py:247``).  Skipping must change
 nothing: a satisfied sample's logit gradient is exactly zero (``attack.py:16-23``), so its input gradient is too.
@@ -54,7 +54,7 @@ def _problem():
     return _cache["p"]
 
 
-def _step(confidence, skip, layout="split", stop_image=None, stage=0):
+def _step(confidence, skip, layout="split", stop_image=None, stage=0, **extras):
     model, x, mask, pattern, y, idx = _problem()
     cfg = LAYOUTS[layout]
     got = {}
@@ -63,7 +63,7 @@ def _step(confidence, skip, layout="split", stop_image=None, stage=0):
     loop = HotLoop(owner, model, x.to(DEV), 0.12, N_CLASSES, "t/cfg/sub", 0, y.to(DEV), True, 1e-2, confidence, 0, 1, 10, 7,
                    'topk', 2, S, 1e-3, 1e-3, 4.0, False,
                    dict(init_mask=mask, init_pattern=pattern, rngs=[FixedDraw([i]) for i in idx], failure_refresh=10 ** 9,
-                        step_hook=hook, tape_tabs=4, backward_ladder=cfg["ladder"]))
+                        step_hook=hook, tape_tabs=4, backward_ladder=cfg["ladder"], **extras))
     loop.stage = stage
     if stop_image is not None:
         loop.img[stop_image].active = False
@@ -120,3 +120,21 @@ def test_early_stopped_image_is_not_back_propagated():
     assert got["counts"][1] == S and got["counts"][2] < B * S
     assert not got["g_adv"][0].any()                               # its update is lr = 0 anyway
     assert _close(got["g_adv"][1], ref["g_adv"][1])
+
+
+def test_few_satisfied_samples_are_back_propagated_in_place():
+    """Below ``skip_min_fraction`` (default 0.2) of skippable samples a group is not compacted: every sample goes through
+    the backward in place (the zeros are computed, as in the reference); with the threshold at 0 the same step compacts."""
+    base = _step(0.1, skip=False)
+    d = np.sort(base["loss_adv"].reshape(-1) - 0.1)
+    conf = float(-0.5 * (d[5] + d[6]))                             # exactly 6 of the 32 samples meet their margin (< 20 %)
+    ref = _step(conf, skip=False)
+    assert int((ref["loss_adv"] > 0).sum()) == B * S - 6
+    got = _step(conf, skip=True)
+    assert got["counts"] == (B * S, B * S - 6, B * S)
+    tight = _step(conf, skip=True, skip_min_fraction=0.0)         # 26 active -> backward batches 8 + 8 + 8 + 2
+    assert tight["counts"][1] == B * S - 6 and tight["counts"][2] == B * S - 6
+    for run in (got, tight):
+        assert np.array_equal(run["loss_adv"], ref["loss_adv"])
+        for name in ("g_adv", "grad_pattern", "grad_mask"):
+            assert _close(run[name], ref[name]), name
