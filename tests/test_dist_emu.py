@@ -177,6 +177,67 @@ def test_placement_extension_two_ranks_stay_in_lock_step(tmp_path):
     assert not np.array_equal(outs[0]["seen"][0]["theta"], outs[0]["seen"][1]["theta"])     # a fresh draw every step
 
 
+# ---------------------------------------------------------------- opt-in selected-sample backward, sharded
+SK_H, SK_S = 112, 4            # the smallest input the fused stem pooling takes; 2 samples per rank
+
+
+def _run_skip(pg, rank, skip, confidence):
+    """One step through a shallow ResNetV2 of the real block types (the taped path needs dorpatch_amd's own network):
+    every rank decides locally which of ITS samples carry gradient; the one all-reduce is unchanged."""
+    from dorpatch_amd.attack import DorPatch, HotLoop
+    from dorpatch_amd.resnetv2 import WELL_CONDITIONED_GN_BIAS, ResNetV2, seeded_init_
+    from dorpatch_amd.utils import NormModel, get_normalize
+    net = seeded_init_(ResNetV2((1, 1, 1, 1), (256, 512, 1024, 2048), 10), seed=1234,
+                       gn_bias=WELL_CONDITIONED_GN_BIAS).fold_weight_standardization().freeze()
+    model = NormModel(net, get_normalize("imagenet", "resnetv2")).eval()
+    g = torch.Generator().manual_seed(5)
+    x, m, p = (torch.rand(1, 3, SK_H, SK_H, generator=g), torch.rand(1, 1, SK_H, SK_H, generator=g),
+               torch.rand(1, 3, SK_H, SK_H, generator=g))
+    with torch.no_grad():
+        y = model(x).topk(2)[1][:, 1].clone()
+    idx = np.random.RandomState(5).choice(630, SK_S, replace=False)
+    got = {}
+    hook = lambda d: got.update(loss_adv=d["loss_adv"].copy(), g_adv=d["g_adv"].clone())
+    loop = HotLoop(DorPatch(micro_batch=2, process_group=pg, verbose=False, skip_satisfied=skip, deterministic=False),
+                   model, x, 0.12, 10, "t/cfg/sub", 0, y, True, 1e-2, confidence, 0, 1, 10, 7, 'topk', 2, SK_S, 1e-3,
+                   1e-3, 4.0, False, dict(init_mask=m, init_pattern=p, rngs=[FixedDraw([idx])], failure_refresh=10 ** 9,
+                                          step_hook=hook, backward_ladder=[1, 2], skip_min_fraction=0.0))
+    loop.step(1)
+    got.update(counts=(loop.n_forward, loop.n_active, loop.n_backward), taped=loop._taped)
+    loop.close()
+    return got
+
+
+def _skip_worker(rank, world, port, out_dir, confidence):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        with _emu_patch().emulated_ops():
+            out = _run_skip(dist.group.WORLD, rank, True, confidence)
+        torch.save(out, os.path.join(out_dir, "skip%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_skip_satisfied_two_ranks_equals_one_rank_all_samples(tmp_path):
+    world = 2
+    with _emu_patch().emulated_ops():
+        base = _run_skip(None, 0, False, 0.1)
+        d = np.sort(base["loss_adv"].reshape(-1) - 0.1)
+        conf = float(-0.5 * (d[0] + d[1]))                   # exactly one of the 4 samples meets its margin
+        want = _run_skip(None, 0, False, conf)
+    assert int((want["loss_adv"] > 0).sum()) == SK_S - 1 and not want["taped"]
+    mp.spawn(_skip_worker, args=(world, _free_port(), str(tmp_path), conf), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), "skip%d.pt" % r), weights_only=False) for r in range(world)]
+    assert all(o["taped"] for o in outs)
+    assert sorted(o["counts"] for o in outs) == [(2, 1, 1), (2, 2, 2)]      # the satisfied sample lives on one rank
+    scale = float(want["g_adv"].abs().max())
+    for o in outs:
+        np.testing.assert_allclose(o["loss_adv"], want["loss_adv"], rtol=1e-5, atol=1e-6)
+        assert float((o["g_adv"] - want["g_adv"]).abs().max()) <= 1e-5 * scale
+    assert torch.equal(outs[0]["g_adv"], outs[1]["g_adv"])
+
+
 # ---------------------------------------------------------------- evaluation driver, both shard modes
 def _driver_worker(rank, world, port, out_dir, shard):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
