@@ -39,6 +39,7 @@ import torch
 
 from . import dist as dp_dist
 from . import masks, ops
+from ._lib import DP_MAX_RECTS
 
 SCALE_UP = 1.2                              # attack.py:88
 SCALE_DOWN = np.sqrt(SCALE_UP ** 3)         # attack.py:89
@@ -192,6 +193,7 @@ class DorPatch(object):
         self.verbose = verbose
         self.criterion = None
         self.last_run = None
+        self._bool_universe = None        # (identity of a bool mask universe, its rectangle table) for collect_failure
 
     # ------------------------------------------------------------------ distributed helpers
     def _world(self):
@@ -265,19 +267,26 @@ class DorPatch(object):
         ascending list of mask indices on which the attack fails — for B > 1 images the union over
         the images, like the reference (``failed_idx.unique()``, ``attack.py:403``).
 
-        ``mask_set_universe`` is a device rectangle table (``masks.universe_rects`` /
-        ``MaskWindow(...).rects``): the reference's (n,1,H,W) bool tensor is rejected with a
-        TypeError (masks are never materialised on this path).  ``y`` may be (B,) or the
+        ``mask_set_universe`` is a device rectangle table (``masks.universe_rects`` / ``MaskWindow(...).rects``) or the
+        reference's (n,1,H,W) bool tensor (``attack.py:83-85``), which is converted once into a table with exactly the
+        same occluded pixels (``masks.bool_to_rects``; cached per tensor) — masks are never materialised on the device
+        path; a bool mask that is not a union of two windows is refused with a ValueError.  ``y`` may be (B,) or the
         reference's expanded (B*sampling_size,) labels (``attack.py:98, 399``).  ``transforms``
         (``attack.py:395-396``), if given, is applied to the occluded images in [0,1] right before
         ``model``, exactly where the reference applies it."""
         ops.require_gpu(adv_x, "DorPatch.collect_failure (`adv_x`)")
         table = mask_set_universe
+        if isinstance(table, torch.Tensor) and table.dtype == torch.bool and table.dim() in (3, 4):
+            key = (table.data_ptr(), tuple(table.shape), str(table.device), table._version)
+            if self._bool_universe is None or self._bool_universe[0] != key:
+                self._bool_universe = (key, ops.upload_table(masks.bool_to_rects(table, DP_MAX_RECTS),
+                                                             adv_x.device))
+            table = self._bool_universe[1]
         if not (isinstance(table, torch.Tensor) and table.dtype == torch.int32 and table.dim() == 3
                 and table.shape[2] == 4):
             raise TypeError("collect_failure needs the mask universe as an (n, R, 4) int32 rectangle table "
                             "(dorpatch_amd.masks.universe_rects(H, dropout) / MaskWindow(...).rects uploaded with "
-                            "ops.upload_table), not the reference's (n,1,H,W) bool tensor")
+                            "ops.upload_table) or as the reference's (n,1,H,W) bool tensor")
         B = adv_x.shape[0]
         y_img = y.detach().to(adv_x.device).long().reshape(B, -1)[:, 0].contiguous()
         if transforms is None:

@@ -94,3 +94,46 @@ def rects_to_bool(table, H, W=None, device="cpu"):
         r0, r1, c0, c1 = (t[:, r, k].view(-1, 1, 1, 1) for k in range(4))
         occluded |= (rows >= r0) & (rows < r1) & (cols >= c0) & (cols < c1)
     return ~occluded
+
+
+def bool_to_rects(masks, max_rects=4):
+    """The reference's ``(n, 1, H, W)`` (or ``(n, H, W)``) bool masks (True = pixel kept) -> an ``(n, R, 4)`` rectangle
+    table with EXACTLY the same occluded pixels, R <= ``max_rects``.
+
+    Each mask's occluded region is cut into horizontal bands of identical rows and every band into its column runs —
+    the union of two axis-aligned windows (every PatchCleanser mask, ``PatchCleanser.py:44-59``) needs at most 4
+    rectangles this way (3 when the windows overlap in their columns).  Raises ``ValueError`` for a mask that needs more
+    than ``max_rects`` rectangles: such a mask is not a PatchCleanser mask and is refused rather than approximated."""
+    m = masks.detach().cpu().numpy() if isinstance(masks, torch.Tensor) else np.asarray(masks)
+    if m.ndim == 4:
+        if m.shape[1] != 1:
+            raise ValueError("bool masks must be (n, 1, H, W) or (n, H, W), got %s" % (m.shape,))
+        m = m[:, 0]
+    if m.ndim != 3 or m.dtype != np.bool_:
+        raise ValueError("bool masks must be a bool array of shape (n, 1, H, W) or (n, H, W)")
+    n, H, W = m.shape
+    per_mask, R = [], 1
+    for k in range(n):
+        occ = ~m[k]
+        rects = []
+        rows = np.flatnonzero(occ.any(axis=1))
+        if rows.size:
+            r_lo, r_hi = int(rows[0]), int(rows[-1]) + 1
+            body = occ[r_lo:r_hi]
+            cuts = np.flatnonzero((body[1:] != body[:-1]).any(axis=1)) + 1          # first row of every new band
+            edges = np.concatenate([[0], cuts, [r_hi - r_lo]])
+            for b0, b1 in zip(edges[:-1], edges[1:]):
+                line = np.concatenate([[0], body[b0].astype(np.int8), [0]])
+                d = np.diff(line)
+                for c0, c1 in zip(np.flatnonzero(d == 1), np.flatnonzero(d == -1)):
+                    rects.append((r_lo + int(b0), r_lo + int(b1), int(c0), int(c1)))
+        if len(rects) > max_rects:
+            raise ValueError("mask %d needs %d rectangles (> %d): not a union of two axis-aligned windows"
+                             % (k, len(rects), max_rects))
+        R = max(R, len(rects))
+        per_mask.append(rects)
+    out = np.zeros((n, R, 4), dtype=np.int32)
+    for k, rects in enumerate(per_mask):
+        for r, rect in enumerate(rects):
+            out[k, r] = rect
+    return out

@@ -404,9 +404,11 @@ def test_collect_failure_matches_oracle():
     # B > 1: the union over the images, ascending (attack.py:403 `.unique()` per chunk)
     both = _collect_failure(net, norm, adv.to(DEV), y.to(DEV), table1, False, 128)
     assert atk.collect_failure(adv.to(DEV), y.to(DEV), table1, False, model) == sorted(set(both[0]) | set(both[1]))
-    # the reference's bool (n,1,H,W) universe is rejected loudly, not mis-read
+    # the reference's bool (n,1,H,W) universe (attack.py:83-85) is accepted: converted to the same table, once
+    assert atk.collect_failure(adv[:1].to(DEV), y[:1].to(DEV), uni1.to(DEV), False, model) == single1
+    assert atk.collect_failure(adv[:1].to(DEV), y[:1].to(DEV), uni1, False, model) == single1      # a host tensor too
     with pytest.raises(TypeError):
-        atk.collect_failure(adv[:1].to(DEV), y[:1].to(DEV), uni1.to(DEV), False, model)
+        atk.collect_failure(adv[:1].to(DEV), y[:1].to(DEV), uni1.float().to(DEV), False, model)
     # `transforms` (attack.py:395-396) is applied to the occluded [0,1] images right before the model
     dark = lambda t: t * 0.5
     want_t = R.collect_failure(lambda t: cpu(dark(t)), adv[:1], y[:1], uni1, False)

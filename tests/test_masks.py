@@ -66,3 +66,32 @@ def test_pad_and_invalid():
     assert t.shape == (36, 2, 4) and (t[:, 1] == 0).all()
     with pytest.raises(ValueError):
         masks.mask_set_rects(56, 0.03, 0)
+
+
+@pytest.mark.parametrize("H,dropout", [(56, 1), (56, 2), (224, 2), (384, 2)])
+def test_bool_universe_converts_to_an_exactly_equivalent_table(H, dropout):
+    """The reference's (n,1,H,W) bool universe (attack.py:83-85) -> rectangle table with the same occluded pixels
+    (what DorPatch.collect_failure does when it is handed the reference's tensor)."""
+    table = masks.universe_rects(H, dropout)
+    if H > 56:
+        table = table[np.random.RandomState(0).choice(table.shape[0], 160, replace=False)]
+    uni = masks.rects_to_bool(table, H)
+    back = masks.bool_to_rects(uni)
+    assert back.dtype == np.int32 and back.shape[0] == table.shape[0] and back.shape[1] <= 4
+    assert torch.equal(masks.rects_to_bool(back, H), uni)
+    assert np.array_equal(masks.bool_to_rects(uni[:, 0]), back)                 # (n, H, W) form
+
+
+def test_bool_to_rects_edge_cases():
+    H = 16
+    keep_all = torch.ones(1, 1, H, H, dtype=torch.bool)
+    assert not masks.bool_to_rects(keep_all).any()                              # nothing occluded: the empty rectangle
+    none = torch.zeros(1, 1, H, H, dtype=torch.bool)
+    assert masks.bool_to_rects(none).tolist() == [[[0, H, 0, H]]]
+    stair = torch.ones(1, 1, H, H, dtype=torch.bool)
+    for i in range(6):                                                          # a staircase is not two windows
+        stair[0, 0, i, :i + 1] = False
+    with pytest.raises(ValueError):
+        masks.bool_to_rects(stair)
+    with pytest.raises(ValueError):
+        masks.bool_to_rects(torch.ones(1, 1, H, H))                             # not bool
