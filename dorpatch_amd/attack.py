@@ -487,7 +487,8 @@ class HotLoop(object):
         # The backward pass runs only over the EOT samples that still carry gradient (dorpatch_amd/taped.py): needs
         # dorpatch_amd's own frozen ResNetV2; any other classifier goes through autograd, all samples.
         from . import taped
-        self._taped = bool(extras.get("skip_satisfied", owner.skip_satisfied)) and taped.eligible(self.net)
+        self._taped = (bool(extras.get("skip_satisfied", owner.skip_satisfied)) and taped.eligible(self.net)
+                       and self.placement is None)        # the placement extension keeps the autograd path (untested there)
         self._tape_tabs = extras.get("tape_tabs")            # None: sized from free memory after the first micro-batch
         self._ladder_user = extras.get("backward_ladder")
         self._skip_min_fraction = float(extras.get("skip_min_fraction", 0.2))
