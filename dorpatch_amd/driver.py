@@ -24,7 +24,7 @@ recomputed, ``main.py:100-118, 144-153``).  What changes is the machinery:
 * extra flags (never part of the result path, so directories stay interchangeable with the
   reference's): ``--num_images`` (the reference hard-codes 10, ``main.py:85``), ``--max_iterations``,
   ``--sampling_size``, ``--img_size``, ``--miopen_find``, ``--synthetic`` (seeded-random weights + ``torch.rand`` images:
-  neither ImageNet nor the checkpoint can be fetched offline), ``--shard``, ``--micro_batch``.
+  neither ImageNet nor the checkpoint can be fetched offline), ``--shard``, ``--micro_batch``, ``--skip_satisfied``.
 """
 import argparse
 import os
@@ -84,6 +84,9 @@ def build_parser():
     extra.add_argument('--miopen_find', action='store_true',
                        help="keep the reference's cudnn.benchmark=True (utils.py:17): on ROCm that is MIOpen's exhaustive "
                             "find, minutes per new batch shape for < 2 %% (profiles/README.md); default: immediate mode")
+    extra.add_argument('--skip_satisfied', action='store_true',
+                       help='back-propagate only the EOT samples whose CW hinge is still active (DorPatch(skip_satisfied=True); '
+                            'off = the reference: every sample)')
     extra.add_argument('--quiet', action='store_true', help='no per-iteration progress lines')
     return parser
 
@@ -167,7 +170,7 @@ def run(args, model=None, dataloader=None, device=None, process_group=None, n_cl
 
     shard_samples = world > 1 and args.shard == "samples"
     attack = DorPatch(micro_batch=args.micro_batch, process_group=process_group if shard_samples else None,
-                      verbose=not args.quiet)
+                      verbose=not args.quiet, skip_satisfied=args.skip_satisfied)
     defense = [PatchCleanser(MaskWindow(args.img_size, r, 1), model) for r in DEFENSE_RATIOS]   # main.py:61
     owns_files = rank == 0 or not shard_samples       # sample-sharded ranks compute the same tensors: rank 0 writes
 
