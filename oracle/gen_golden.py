@@ -27,6 +27,11 @@ Fixtures
                    failure-biased sampling branch (attack.py:193-199) is exercised.
 ``patchcleanser_56.npz``  records of the reference PatchCleanser.robust_predict(certify=True) on a
                    location-sensitive toy net (all four decision branches) + n_patch=2 mask checksums.
+``steps_56_dual.npz``  3 + 3 recorded steps with ``dual=True`` (attack.py:208-217: a second sampled mask set per step,
+                   its indices recorded as ``idx_dual``).
+``trace_56_untargeted.npz``  control trace of an UNTARGETED run (y = None) through the untargeted -> targeted switch at
+                   iteration 500 of stage 0 (attack.py:169-182), with the reference's ``targeted`` flag, label and the
+                   masked copies' predictions per step.
 ``geometry.npz``   MaskWindow geometry for 56/224/384 and mask-universe checksums.
 ``end_metric_56.npz``  8 images x full two-stage reference runs (300 iterations per stage, S = 8, toy nets whose
                    gain sweeps the range where the attack goes from certifiably succeeding to failing): the
@@ -95,6 +100,8 @@ class Capture(torch.nn.Module):
                    failed=np.asarray(L["failed_idxs"], dtype=np.int64).copy(),
                    not_decay=int(L["not_decay"][0]), loss_best=float(L["loss_best"][0]),
                    targeted=bool(L["targeted"]), y=int(L["y"][0]))
+        if L.get("dual"):          # attack.py:208-217: the second sampled mask set of this step
+            rec["idx_dual"] = np.asarray(L["sampling_idxs_dual"]).astype(np.int64).copy()
         if self.keep(stage, i):
             rec.update(mask=L["adv_mask"].detach().clone().numpy(),
                        pattern=L["adv_pattern"].detach().clone().numpy(),
@@ -106,6 +113,7 @@ class Capture(torch.nn.Module):
             prev["loss_struc"] = float(L["loss_struc"].detach()[0])
             prev["loss_target"] = float(L["loss_target"].detach()[0])
             prev["save_best"] = bool(L["save_best"][0])
+            prev["pred"] = L["adv_logits"].detach().argmax(-1).numpy().reshape(-1).copy()
             if stage == 0:
                 prev["group_lasso"] = float(L["group_lasso"].detach()[0])
                 prev["density"] = float(L["loss_density"].detach()[0])
@@ -157,6 +165,8 @@ def _pack_steps(cap, steps):
         out[pre + "stage"], out[pre + "i"] = r["stage"], r["i"]
         for k in ("idx", "mask", "pattern", "adv_x", "loss_adv"):
             out[pre + k] = r[k]
+        if "idx_dual" in r:
+            out[pre + "idx_dual"] = r["idx_dual"]
         for k in ("lr", "structured", "coeff_group_lasso", "loss_struc", "y"):
             out[pre + k] = r[k]
         if r["stage"] == 0:
@@ -169,14 +179,17 @@ def _pack_steps(cap, steps):
     return out
 
 
-def make_steps_fixture(H, S, gain, path, n=3, eps=4.0):
+def make_steps_fixture(H, S, gain, path, n=3, eps=4.0, dual=False):
     net, x, y = toy_problem(H, gain=gain)
+    extra = dict(dual=True) if dual else {}
     cap, mask, pattern, _ = run_reference(net, x, y, sampling_size=S, max_iterations=n + 1, eps=eps,
-                                          keep=lambda s, i: True)
+                                          keep=lambda s, i: True, **extra)
     steps = [(0, i) for i in range(n)] + ([(1, i) for i in range(n)] if H <= 64 else [])
     data = _pack_steps(cap, steps)
     data.update(x=x.numpy(), y0=y.numpy(), gain=gain, H=H, S=S, eps=eps, patch_budget=0.12,
                 final_mask=mask.numpy(), final_pattern=pattern.numpy())
+    if dual:
+        data["dual"] = True
     np.savez_compressed(path, **data)
     return data
 
@@ -205,6 +218,44 @@ def make_trace_fixture(H, S, gain, path, max_iterations, eps=4.0, seed_x=5, lr=1
     fields["failed_offsets"] = np.cumsum([0] + [len(r["failed"]) for r in recs])
     fields["failed_values"] = np.concatenate([r["failed"] for r in recs]) if recs else np.zeros(0, np.int64)
     fields.update(x=x.numpy(), y0=y.numpy(), gain=gain, H=H, S=S, eps=eps, max_iterations=max_iterations, lr0=lr,
+                  final_mask=mask.numpy(), final_pattern=pattern.numpy(), log=np.array(log))
+    np.savez_compressed(path, **fields)
+    return fields
+
+
+def make_untargeted_trace_fixture(path, H=56, S=8, gain=4.0, max_iterations=560, eps=4.0, seed_x=21, lr=1e-2):
+    """An UNTARGETED run (``targeted=False, y=None``: the label is the clean prediction, attack.py:67-69) long enough
+    to pass the untargeted -> targeted switch at iteration 500 of stage 0 (attack.py:169-182: ``set_target``, new label,
+    lr / loss_best / not_decay / num_failure reset, failure list re-collected).  Scalar control trace as in
+    ``make_trace_fixture`` plus, per step, the reference's ``targeted`` flag, its current label and the predictions of
+    the step's masked copies (what ``set_target`` votes over)."""
+    net = toy_models.NormModel(toy_models.make_toy(gain=gain), toy_models.Normalize())
+    x = torch.rand(1, 3, H, H, generator=torch.Generator().manual_seed(seed_x))
+    with torch.no_grad():
+        y_clean = net(x).argmax(-1)
+    cap, mask, pattern, log = run_reference(net, x, None, sampling_size=S, max_iterations=max_iterations, eps=eps,
+                                            targeted=False, keep=lambda s, i: False, lr=lr)
+    recs = [r for r in cap.records]
+    fields = dict(
+        stage=np.array([r["stage"] for r in recs]), i=np.array([r["i"] for r in recs]),
+        idx=np.stack([r["idx"] for r in recs]),
+        n_form_failure=np.array([r["n_form_failure"] for r in recs]),
+        lr=np.array([r["lr"] for r in recs], dtype=np.float32),
+        structured=np.array([r["structured"] for r in recs], dtype=np.float64),
+        coeff_group_lasso=np.array([r["coeff_group_lasso"] for r in recs], dtype=np.float64),
+        n_failed=np.array([r["n_failed"] for r in recs]),
+        not_decay=np.array([r["not_decay"] for r in recs]),
+        loss_best=np.array([r["loss_best"] for r in recs], dtype=np.float32),
+        complete=np.array([r.get("complete", False) for r in recs]),
+        loss_adv=np.stack([r.get("loss_adv", np.full(S, np.nan, np.float32)) for r in recs]).astype(np.float32),
+        loss_target=np.array([r.get("loss_target", np.nan) for r in recs], dtype=np.float32),
+        save_best=np.array([r.get("save_best", False) for r in recs]),
+        targeted=np.array([r["targeted"] for r in recs]), y=np.array([r["y"] for r in recs], dtype=np.int64),
+        pred=np.stack([r.get("pred", np.full(S, -1, np.int64)) for r in recs]).astype(np.int64),
+    )
+    fields["failed_offsets"] = np.cumsum([0] + [len(r["failed"]) for r in recs])
+    fields["failed_values"] = np.concatenate([r["failed"] for r in recs]) if recs else np.zeros(0, np.int64)
+    fields.update(x=x.numpy(), y0=y_clean.numpy(), gain=gain, H=H, S=S, eps=eps, max_iterations=max_iterations, lr0=lr,
                   final_mask=mask.numpy(), final_pattern=pattern.numpy(), log=np.array(log))
     np.savez_compressed(path, **fields)
     return fields
@@ -315,6 +366,8 @@ def main():
     # failure-biased sampling branch (attack.py:193-199)
     make_trace_fixture(56, 8, 1.5, os.path.join(GOLDEN_DIR, "trace_56_fail.npz"), max_iterations=2500,
                        seed_x=6, lr=0.1)
+    make_steps_fixture(56, 6, 2.0, os.path.join(GOLDEN_DIR, "steps_56_dual.npz"), dual=True)
+    make_untargeted_trace_fixture(os.path.join(GOLDEN_DIR, "trace_56_untargeted.npz"))
     for f in sorted(os.listdir(GOLDEN_DIR)):
         print(f, os.path.getsize(os.path.join(GOLDEN_DIR, f)))
 

@@ -59,6 +59,16 @@ def golden_steps_224():
 
 
 @pytest.fixture(scope="session")
+def golden_steps_56_dual():
+    return load_golden("steps_56_dual.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_trace_untargeted():
+    return load_golden("trace_56_untargeted.npz")
+
+
+@pytest.fixture(scope="session")
 def golden_geometry():
     return load_golden("geometry.npz")
 

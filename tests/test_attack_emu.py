@@ -35,6 +35,7 @@ SKIP = {"test_config2_size_properties"}
 # DORPATCH_EMU_FULL=1 (test_generate_short_run_both_stages covers the same control flow in seconds)
 if os.environ.get("DORPATCH_EMU_FULL", "0") != "1":
     SKIP.add("test_generate_trajectory_tracks_reference")
+    SKIP.add("test_generate_untargeted_run_tracks_reference")
 
 
 @pytest.fixture(autouse=True)

@@ -56,9 +56,11 @@ def _replay_golden_steps(g, rtol_g):
     for n in range(int(g["n_steps"])):
         p = "s%d_" % n
         got = {}
+        dual = (p + "idx_dual") in g
         loop = _loop(model, x, torch.tensor([int(g[p + "y"])], device=DEV), S,
                      dict(init_mask=torch.from_numpy(g[p + "mask"]), init_pattern=torch.from_numpy(g[p + "pattern"]),
-                          rngs=[FixedDraw([g[p + "idx"]])], step_hook=_grab(got)), eps=float(g["eps"]))
+                          rngs=[FixedDraw([g[p + "idx"]] + ([g[p + "idx_dual"]] if dual else []))], step_hook=_grab(got)),
+                     eps=float(g["eps"]), dual=dual)
         loop.stage = int(g[p + "stage"])
         st = loop.img[0]
         st.structured, st.coeff_group_lasso = float(g[p + "structured"]), float(g[p + "coeff_group_lasso"])
@@ -92,6 +94,11 @@ def test_hot_loop_replays_reference_steps_56(golden_steps_56):
 
 def test_hot_loop_replays_reference_steps_224(golden_steps_224):
     _replay_golden_steps(golden_steps_224, 1e-3)
+
+
+def test_hot_loop_replays_reference_dual_steps(golden_steps_56_dual):
+    """`dual=True` (attack.py:208-217) against steps recorded from the unmodified reference."""
+    _replay_golden_steps(golden_steps_56_dual, 1e-3)
 
 
 def test_generate_trajectory_tracks_reference(golden_trace, tmp_path, monkeypatch):
@@ -147,6 +154,48 @@ def test_generate_trajectory_tracks_reference(golden_trace, tmp_path, monkeypatc
     assert abs(n - n_ref) <= 0.15 * 2520, (n, n_ref)
     assert not (n_ref < 0.05 * 2520) or n < 0.15 * 2520, (n, n_ref)
     assert not (n_ref > 0.85 * 2520) or n > 0.70 * 2520, (n, n_ref)
+
+
+def test_generate_untargeted_run_tracks_reference(golden_trace_untargeted, tmp_path, monkeypatch):
+    """Full untargeted DorPatch.generate (y = None), same seeds as the recorded reference run: the clean label, the
+    mask draws of every step (same RNG consumption, also across the extra collect_failure of the switch) and the
+    iteration of the untargeted -> targeted switch (attack.py:169-182) must be the reference's.  The label chosen at the
+    switch is a vote over step 499's predictions, i.e. after 500 signed updates: only its kind is asserted here —
+    tests/test_bookkeeping.py replays the reference's own vote exactly."""
+    t = golden_trace_untargeted
+    H, S = int(t["H"]), int(t["S"])
+    monkeypatch.chdir(tmp_path)
+    model = _toy(float(t["gain"]))
+    x = torch.from_numpy(t["x"]).to(DEV)
+    seen = []
+
+    def hook(d):
+        st = d["states"][0]
+        seen.append((d["stage"], d["i"], d["idx"][0].copy(), bool(st.flag_targeted), int(st.y), d["loss_adv"][0].copy()))
+
+    torch.manual_seed(1234)
+    np.random.seed(1234)
+    atk = DorPatch(verbose=False)
+    mask, _ = atk.generate(model, x, 0.12, 10, "res/cfg/sub", 0, y=None, targeted=False, lr=float(t["lr0"]),
+                           sampling_size=S, eps=float(t["eps"]), max_iterations=int(t["max_iterations"]), step_hook=hook)
+    n = min(len(seen), len(t["i"]))
+    assert n > 520
+    same_steps = 0
+    for k in range(n):
+        stage, i, idx, flag, y, la = seen[k]
+        if (stage, i) != (int(t["stage"][k]), int(t["i"][k])):
+            break                                    # an early stop on one side only: the streams are no longer aligned
+        assert np.array_equal(idx, t["idx"][k]), k   # identical RNG stream
+        assert flag == bool(t["targeted"][k]), k     # the switch happens at the same iteration
+        if not flag:
+            assert y == int(t["y0"][0])              # the clean prediction, as the reference chose it
+        same_steps += 1
+    assert same_steps > 520
+    for k in range(5):
+        np.testing.assert_allclose(seen[k][5], t["loss_adv"][k], rtol=5e-3, atol=5e-4)
+    st = atk.last_run.img[0]
+    assert st.flag_targeted and st.crit_targeted and st.y != int(t["y0"][0])
+    assert set(np.unique(mask.cpu().numpy())) <= {0.0, 1.0}
 
 
 def test_generate_short_run_both_stages(tmp_path, monkeypatch):

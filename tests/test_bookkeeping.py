@@ -56,6 +56,61 @@ def test_sampling_reproduces_reference_rng(golden_trace):
         assert np.array_equal(idx, t["idx"][k]), (int(t["stage"][k]), int(t["i"][k]))
 
 
+def test_untargeted_run_and_its_switch_replay_the_reference(golden_trace_untargeted):
+    """An UNTARGETED reference run (y = None) through the untargeted -> targeted switch at iteration 500 of stage 0
+    (attack.py:169-182): the product's per-image state machine, its ``_set_target`` vote over the recorded predictions
+    and its sampling code must reproduce every decision of the unmodified reference — label, reset of lr / loss_best /
+    not_decay / num_failure, re-collected failure list, and everything test_state_machine_replays_reference checks."""
+    from dorpatch_amd.attack import HotLoop
+
+    class Stub(object):          # HotLoop._set_target only touches self.img
+        pass
+
+    t = golden_trace_untargeted
+    S, stages = int(t["S"]), t["stage"]
+    assert not t["targeted"][0] and t["targeted"][-1] and int(t["y"][0]) == int(t["y0"][0])
+    np.random.seed(1234)
+    choices = np.arange(2520)
+    checked = switched = 0
+    st = None
+    for stage in (0, 1):
+        rows = np.nonzero(stages == stage)[0]
+        if stage == 0:
+            st = _ImageState(float(t["lr0"]), t["structured"][rows[0]], t["coeff_group_lasso"][rows[0]], False, int(t["y0"][0]))
+        else:                     # attack.py:124-132: a new stage resets the schedule, not the label / criterion
+            st.reset_stage()
+            st.structured, st.coeff_group_lasso = float(t["structured"][rows[0]]), float(t["coeff_group_lasso"][rows[0]])
+        st.failed_idxs = _failed(t, rows[0])
+        for k in rows:
+            i = int(t["i"][k])
+            if stage == 0 and i == 500 and not st.flag_targeted:       # HotLoop.step, attack.py:169-182
+                stub = Stub()
+                stub.img = [st]
+                st.flag_targeted = True
+                changed = HotLoop._set_target(stub, 0, t["pred"][k - 1])
+                st.reset_stage()
+                st.failed_idxs = _failed(t, k)                         # collect_failure at the switch
+                assert changed and st.crit_targeted
+                switched += 1
+            assert st.y == int(t["y"][k]) and st.flag_targeted == bool(t["targeted"][k]), (stage, i)
+            assert np.float32(st.lr_current) == t["lr"][k], (stage, i)
+            assert st.structured == t["structured"][k] and st.coeff_group_lasso == t["coeff_group_lasso"][k], (stage, i)
+            if i % 100 == 0:
+                st.failed_idxs = _failed(t, k)
+            assert list(st.failed_idxs) == _failed(t, k), (stage, i)
+            assert st.not_decay == t["not_decay"][k], (stage, i)
+            n_fail = st.n_from_failure(i, S, 1000)
+            assert n_fail == t["n_form_failure"][k]
+            assert np.array_equal(draw_indices(np.random, st.failed_idxs, n_fail, S, choices), t["idx"][k]), (stage, i)
+            if not t["complete"][k]:
+                continue
+            save, stop = st.step(i, stage, t["loss_adv"][k], t["loss_target"][k], t["idx"][k], n_fail)
+            assert save == bool(t["save_best"][k]), (stage, i)
+            assert not stop
+            checked += 1
+    assert switched == 1 and checked > 1000
+
+
 def test_lr_floor_and_stop_rule():
     """lr 0.01 -> 0.001 is NOT < 1e-3 in fp32; a second decay is needed."""
     st = _ImageState(1e-2, 1e-3, 1e-5, True, 0)

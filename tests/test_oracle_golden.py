@@ -22,8 +22,9 @@ def _check_steps(g, atol):
         p = "s%d_" % n
         stage = int(g[p + "stage"])
         keep = universe[torch.from_numpy(g[p + "idx"])]
+        dual = dict(keep_dual=universe[torch.from_numpy(g[p + "idx_dual"])]) if (p + "idx_dual") in g else {}
         out = R.eot_step(net, x, torch.from_numpy(g[p + "mask"]), torch.from_numpy(g[p + "pattern"]),
-                         torch.tensor([int(g[p + "y"])]), keep, stage=stage, targeted=True, n_classes=10,
+                         torch.tensor([int(g[p + "y"])]), keep, stage=stage, targeted=True, n_classes=10, **dual,
                          structured=float(g[p + "structured"]), coeff_group_lasso=float(g[p + "coeff_group_lasso"]),
                          eps=float(g["eps"]), lr=float(g[p + "lr_next"]), local_var_x=lvx)
         np.testing.assert_allclose(out["adv_x"].numpy(), g[p + "adv_x"], atol=atol, rtol=0)
@@ -48,6 +49,14 @@ def test_steps_56(golden_steps_56):
 
 def test_steps_224(golden_steps_224):
     _check_steps(golden_steps_224, atol=1e-6)
+
+
+def test_steps_56_dual(golden_steps_56_dual):
+    """attack.py:208-217 (`dual=True`), recorded from the unmodified reference: a second mask set per step."""
+    g = golden_steps_56_dual
+    assert all(("s%d_idx_dual" % n) in g for n in range(int(g["n_steps"])))
+    assert not np.array_equal(g["s0_idx"], g["s0_idx_dual"])
+    _check_steps(g, atol=1e-6)
 
 
 def test_final_mask_is_cell_aligned(golden_steps_56):
