@@ -29,6 +29,8 @@ Fixtures
                    location-sensitive toy net (all four decision branches) + n_patch=2 mask checksums.
 ``steps_56_dual.npz``  3 + 3 recorded steps with ``dual=True`` (attack.py:208-217: a second sampled mask set per step,
                    its indices recorded as ``idx_dual``).
+``steps_56_dropout1.npz``  3 + 3 recorded steps with ``dropout=1`` (attack.py:25-31, 83-85: the universe is the 4 x 36
+                   single-window masks instead of the 4 x 630 double masks).
 ``trace_56_untargeted.npz``  control trace of an UNTARGETED run (y = None) through the untargeted -> targeted switch at
                    iteration 500 of stage 0 (attack.py:169-182), with the reference's ``targeted`` flag, label and the
                    masked copies' predictions per step.
@@ -179,9 +181,11 @@ def _pack_steps(cap, steps):
     return out
 
 
-def make_steps_fixture(H, S, gain, path, n=3, eps=4.0, dual=False):
+def make_steps_fixture(H, S, gain, path, n=3, eps=4.0, dual=False, dropout=None):
     net, x, y = toy_problem(H, gain=gain)
     extra = dict(dual=True) if dual else {}
+    if dropout is not None:
+        extra["dropout"] = dropout
     cap, mask, pattern, _ = run_reference(net, x, y, sampling_size=S, max_iterations=n + 1, eps=eps,
                                           keep=lambda s, i: True, **extra)
     steps = [(0, i) for i in range(n)] + ([(1, i) for i in range(n)] if H <= 64 else [])
@@ -190,6 +194,8 @@ def make_steps_fixture(H, S, gain, path, n=3, eps=4.0, dual=False):
                 final_mask=mask.numpy(), final_pattern=pattern.numpy())
     if dual:
         data["dual"] = True
+    if dropout is not None:
+        data["dropout"] = dropout
     np.savez_compressed(path, **data)
     return data
 
@@ -368,6 +374,7 @@ def main():
                        seed_x=6, lr=0.1)
     make_steps_fixture(56, 6, 2.0, os.path.join(GOLDEN_DIR, "steps_56_dual.npz"), dual=True)
     make_untargeted_trace_fixture(os.path.join(GOLDEN_DIR, "trace_56_untargeted.npz"))
+    make_steps_fixture(56, 8, 1.5, os.path.join(GOLDEN_DIR, "steps_56_dropout1.npz"), dropout=1)
     for f in sorted(os.listdir(GOLDEN_DIR)):
         print(f, os.path.getsize(os.path.join(GOLDEN_DIR, f)))
 

@@ -64,6 +64,11 @@ def golden_steps_56_dual():
 
 
 @pytest.fixture(scope="session")
+def golden_steps_56_dropout1():
+    return load_golden("steps_56_dropout1.npz")
+
+
+@pytest.fixture(scope="session")
 def golden_trace_untargeted():
     return load_golden("trace_56_untargeted.npz")
 

@@ -37,9 +37,9 @@ def _toy(gain=1.0, dev=None):
 
 
 def _loop(model, x, y, S, extras, *, budget=0.12, targeted=True, lr=1e-2, eps=4.0, tmp="t/cfg/sub", mb=256,
-          dual=False):
+          dual=False, dropout=2):
     return HotLoop(DorPatch(micro_batch=mb, verbose=False), model, x, budget, 10, tmp, 0, y, targeted, lr, 1e-1,
-                   0, 1, 10 ** 6, 7, 'topk', 2, S, 1e-3, 1e-3, eps, dual, dict(failure_refresh=10 ** 9, **extras))
+                   0, 1, 10 ** 6, 7, 'topk', dropout, S, 1e-3, 1e-3, eps, dual, dict(failure_refresh=10 ** 9, **extras))
 
 
 def _grab(store):
@@ -60,7 +60,7 @@ def _replay_golden_steps(g, rtol_g):
         loop = _loop(model, x, torch.tensor([int(g[p + "y"])], device=DEV), S,
                      dict(init_mask=torch.from_numpy(g[p + "mask"]), init_pattern=torch.from_numpy(g[p + "pattern"]),
                           rngs=[FixedDraw([g[p + "idx"]] + ([g[p + "idx_dual"]] if dual else []))], step_hook=_grab(got)),
-                     eps=float(g["eps"]), dual=dual)
+                     eps=float(g["eps"]), dual=dual, dropout=int(g["dropout"]) if "dropout" in g else 2)
         loop.stage = int(g[p + "stage"])
         st = loop.img[0]
         st.structured, st.coeff_group_lasso = float(g[p + "structured"]), float(g[p + "coeff_group_lasso"])
@@ -154,6 +154,11 @@ def test_generate_trajectory_tracks_reference(golden_trace, tmp_path, monkeypatc
     assert abs(n - n_ref) <= 0.15 * 2520, (n, n_ref)
     assert not (n_ref < 0.05 * 2520) or n < 0.15 * 2520, (n, n_ref)
     assert not (n_ref > 0.85 * 2520) or n > 0.70 * 2520, (n, n_ref)
+
+
+def test_hot_loop_replays_reference_dropout1_steps(golden_steps_56_dropout1):
+    """`dropout=1` (the single-window universe, attack.py:25-31) against steps recorded from the unmodified reference."""
+    _replay_golden_steps(golden_steps_56_dropout1, 1e-3)
 
 
 def test_generate_untargeted_run_tracks_reference(golden_trace_untargeted, tmp_path, monkeypatch):

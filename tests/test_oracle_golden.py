@@ -16,7 +16,7 @@ def _check_steps(g, atol):
     H, S = int(g["H"]), int(g["S"])
     net = _toy(g)
     x = torch.from_numpy(g["x"])
-    universe = R.mask_universe(H, 2)
+    universe = R.mask_universe(H, int(g["dropout"]) if "dropout" in g else 2)
     lvx = R.local_variance(x)[0].mean(1)
     for n in range(int(g["n_steps"])):
         p = "s%d_" % n
@@ -56,6 +56,13 @@ def test_steps_56_dual(golden_steps_56_dual):
     g = golden_steps_56_dual
     assert all(("s%d_idx_dual" % n) in g for n in range(int(g["n_steps"])))
     assert not np.array_equal(g["s0_idx"], g["s0_idx_dual"])
+    _check_steps(g, atol=1e-6)
+
+
+def test_steps_56_dropout1(golden_steps_56_dropout1):
+    """`dropout=1` (attack.py:25-31, 83-85), recorded from the unmodified reference: the 144 single-window masks."""
+    g = golden_steps_56_dropout1
+    assert int(g["dropout"]) == 1 and max(int(g["s%d_idx" % n].max()) for n in range(int(g["n_steps"]))) < 144
     _check_steps(g, atol=1e-6)
 
 
