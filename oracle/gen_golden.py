@@ -31,6 +31,9 @@ Fixtures
                    its indices recorded as ``idx_dual``).
 ``steps_56_dropout1.npz``  3 + 3 recorded steps with ``dropout=1`` (attack.py:25-31, 83-85: the universe is the 4 x 36
                    single-window masks instead of the 4 x 630 double masks).
+``steps_56_untargeted.npz``  3 stage-0 steps of an untargeted run (the untargeted CW loss and its gradient) + the text of
+                   the TypeError the reference raises entering stage 1 (attack.py:155) when the switch at iteration
+                   500 has not happened.
 ``trace_56_untargeted.npz``  control trace of an UNTARGETED run (y = None) through the untargeted -> targeted switch at
                    iteration 500 of stage 0 (attack.py:169-182), with the reference's ``targeted`` flag, label and the
                    masked copies' predictions per step.
@@ -196,6 +199,39 @@ def make_steps_fixture(H, S, gain, path, n=3, eps=4.0, dual=False, dropout=None)
         data["dual"] = True
     if dropout is not None:
         data["dropout"] = dropout
+    np.savez_compressed(path, **data)
+    return data
+
+
+def make_untargeted_steps_fixture(path, H=56, S=8, gain=1.5, n=3, eps=4.0, seed_x=5):
+    """Stage-0 steps of an UNTARGETED run (``targeted=False, y=None``): the untargeted form of ``CW_loss``
+    (attack.py:16-23) and its gradient.  With fewer than 501 iterations the reference then CRASHES entering stage 1 —
+    ``y = set_target(preds_adv)`` (attack.py:155) lacks the ``label`` argument — so only stage 0 can be
+    recorded; the exception text is stored as evidence."""
+    ref = ref_shim.load_reference()
+    net = toy_models.NormModel(toy_models.make_toy(gain=gain), toy_models.Normalize())
+    x = torch.rand(1, 3, H, H, generator=torch.Generator().manual_seed(seed_x))
+    with torch.no_grad():
+        y_clean = net(x).argmax(-1)
+    cap = Capture(net, lambda s, i: True)
+    cwd, tmp = os.getcwd(), tempfile.mkdtemp(prefix="dorpatch_golden_")
+    os.makedirs(os.path.join(tmp, "res", "cfg", "sub"))
+    os.chdir(tmp)
+    raised = ""
+    try:
+        torch.manual_seed(1234)
+        np.random.seed(1234)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref.attack.DorPatch().generate(cap, x, 0.12, 10, "res/cfg/sub", 0, y=None, targeted=False, sampling_size=S,
+                                           max_iterations=n + 1, eps=eps)
+    except TypeError as e:
+        raised = "TypeError: %s" % e
+    finally:
+        os.chdir(cwd)
+    assert "set_target" in raised, "the reference was expected to fail at attack.py:155 (got %r)" % raised
+    data = _pack_steps(cap, [(0, i) for i in range(n)])
+    data.update(x=x.numpy(), y0=y_clean.numpy(), gain=gain, H=H, S=S, eps=eps, patch_budget=0.12, targeted=False,
+                reference_stage1_error=np.array(raised))
     np.savez_compressed(path, **data)
     return data
 
@@ -375,6 +411,7 @@ def main():
     make_steps_fixture(56, 6, 2.0, os.path.join(GOLDEN_DIR, "steps_56_dual.npz"), dual=True)
     make_untargeted_trace_fixture(os.path.join(GOLDEN_DIR, "trace_56_untargeted.npz"))
     make_steps_fixture(56, 8, 1.5, os.path.join(GOLDEN_DIR, "steps_56_dropout1.npz"), dropout=1)
+    make_untargeted_steps_fixture(os.path.join(GOLDEN_DIR, "steps_56_untargeted.npz"))
     for f in sorted(os.listdir(GOLDEN_DIR)):
         print(f, os.path.getsize(os.path.join(GOLDEN_DIR, f)))
 

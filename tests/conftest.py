@@ -69,6 +69,11 @@ def golden_steps_56_dropout1():
 
 
 @pytest.fixture(scope="session")
+def golden_steps_56_untargeted():
+    return load_golden("steps_56_untargeted.npz")
+
+
+@pytest.fixture(scope="session")
 def golden_trace_untargeted():
     return load_golden("trace_56_untargeted.npz")
 

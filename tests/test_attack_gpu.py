@@ -60,7 +60,8 @@ def _replay_golden_steps(g, rtol_g):
         loop = _loop(model, x, torch.tensor([int(g[p + "y"])], device=DEV), S,
                      dict(init_mask=torch.from_numpy(g[p + "mask"]), init_pattern=torch.from_numpy(g[p + "pattern"]),
                           rngs=[FixedDraw([g[p + "idx"]] + ([g[p + "idx_dual"]] if dual else []))], step_hook=_grab(got)),
-                     eps=float(g["eps"]), dual=dual, dropout=int(g["dropout"]) if "dropout" in g else 2)
+                     eps=float(g["eps"]), dual=dual, dropout=int(g["dropout"]) if "dropout" in g else 2,
+                     targeted=bool(g["targeted"]) if "targeted" in g else True)
         loop.stage = int(g[p + "stage"])
         st = loop.img[0]
         st.structured, st.coeff_group_lasso = float(g[p + "structured"]), float(g[p + "coeff_group_lasso"])
@@ -159,6 +160,11 @@ def test_generate_trajectory_tracks_reference(golden_trace, tmp_path, monkeypatc
 def test_hot_loop_replays_reference_dropout1_steps(golden_steps_56_dropout1):
     """`dropout=1` (the single-window universe, attack.py:25-31) against steps recorded from the unmodified reference."""
     _replay_golden_steps(golden_steps_56_dropout1, 1e-3)
+
+
+def test_hot_loop_replays_reference_untargeted_steps(golden_steps_56_untargeted):
+    """The untargeted criterion (attack.py:16-23 with targeted=False) against steps recorded from the unmodified reference."""
+    _replay_golden_steps(golden_steps_56_untargeted, 1e-3)
 
 
 def test_generate_untargeted_run_tracks_reference(golden_trace_untargeted, tmp_path, monkeypatch):

@@ -24,7 +24,8 @@ def _check_steps(g, atol):
         keep = universe[torch.from_numpy(g[p + "idx"])]
         dual = dict(keep_dual=universe[torch.from_numpy(g[p + "idx_dual"])]) if (p + "idx_dual") in g else {}
         out = R.eot_step(net, x, torch.from_numpy(g[p + "mask"]), torch.from_numpy(g[p + "pattern"]),
-                         torch.tensor([int(g[p + "y"])]), keep, stage=stage, targeted=True, n_classes=10, **dual,
+                         torch.tensor([int(g[p + "y"])]), keep, stage=stage,
+                         targeted=bool(g["targeted"]) if "targeted" in g else True, n_classes=10, **dual,
                          structured=float(g[p + "structured"]), coeff_group_lasso=float(g[p + "coeff_group_lasso"]),
                          eps=float(g["eps"]), lr=float(g[p + "lr_next"]), local_var_x=lvx)
         np.testing.assert_allclose(out["adv_x"].numpy(), g[p + "adv_x"], atol=atol, rtol=0)
@@ -63,6 +64,14 @@ def test_steps_56_dropout1(golden_steps_56_dropout1):
     """`dropout=1` (attack.py:25-31, 83-85), recorded from the unmodified reference: the 144 single-window masks."""
     g = golden_steps_56_dropout1
     assert int(g["dropout"]) == 1 and max(int(g["s%d_idx" % n].max()) for n in range(int(g["n_steps"]))) < 144
+    _check_steps(g, atol=1e-6)
+
+
+def test_steps_56_untargeted(golden_steps_56_untargeted):
+    """The untargeted form of CW_loss (attack.py:16-23) and its gradient, recorded from the unmodified reference
+    (stage 0 only: the reference raises a TypeError at attack.py:155 entering stage 1 of such a short run)."""
+    g = golden_steps_56_untargeted
+    assert not bool(g["targeted"]) and int(g["s0_y"]) == int(g["y0"][0]) and "set_target" in str(g["reference_stage1_error"])
     _check_steps(g, atol=1e-6)
 
 
