@@ -152,3 +152,33 @@ def test_utils_helpers_match(ref, tmp_path, monkeypatch):
     net = torch.nn.Conv2d(3, 4, 1)
     assert torch.equal(U.NormModel(net, a)(x), ref.utils.NormModel(net, b)(x))
     assert os.path.isdir(U.generate_saving_path(dict(args)))
+
+
+def test_patchcleanser_sweep_against_the_live_reference(ref):
+    """defenses/PatchCleanser.py:68-112: the product's PatchCleanser (dp_apply_fwd + dp_argmax, here through the host
+    emulation of the HIP kernels) against the unmodified reference's on more images than the recorded fixture holds (all
+    three outcome kinds: first round disagrees / unanimous uncertified / unanimous certified), certify on and off —
+    every record field identical."""
+    from tests_hipemu import patch as emu_patch
+    if emu_patch.build_emu.host_compiler() is None:
+        pytest.skip("no host clang++ for the HIP emulation build")
+    from dorpatch_amd.patchcleanser import MaskWindow, PatchCleanser
+    from oracle import toy_models
+    H = 56
+    net = toy_models.NormModel(toy_models.make_peaky(), toy_models.Normalize())
+    branches = set()
+    with emu_patch.emulated_ops(), torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        for r in (0.03, 0.12):
+            pc_ref = ref.PatchCleanser.PatchCleanser(ref.PatchCleanser.MaskWindow(H, r, 1), net)
+            pc = PatchCleanser(MaskWindow(H, r, 1, device="cpu"), net)
+            for seed in ((1, 4, 6, 9, 12, 19, 24, 28, 33, 36, 41, 47, 52) if r == 0.03 else (1, 8, 15, 20, 31, 44, 58)):
+                img = toy_models.blob_image(H, seed)
+                for certify in (True, False):
+                    want, got = pc_ref.robust_predict(img, certify), pc.robust_predict(img, certify)
+                    assert got.prediction == int(want.prediction) and bool(got.certification) == bool(want.certification), (r, seed)
+                    assert np.array_equal(got.preds_1, want.preds_1), (r, seed)
+                    assert (got.preds_2 is None) == (want.preds_2 is None)
+                    if want.preds_2 is not None:
+                        assert np.array_equal(got.preds_2, want.preds_2), (r, seed)
+                    branches.add((len(np.unique(want.preds_1)) > 1, bool(want.certification)))
+    assert len(branches) >= 3, branches
