@@ -37,9 +37,10 @@ def _toy(gain=1.0, dev=None):
 
 
 def _loop(model, x, y, S, extras, *, budget=0.12, targeted=True, lr=1e-2, eps=4.0, tmp="t/cfg/sub", mb=256,
-          dual=False, dropout=2):
-    return HotLoop(DorPatch(micro_batch=mb, verbose=False), model, x, budget, 10, tmp, 0, y, targeted, lr, 1e-1,
-                   0, 1, 10 ** 6, 7, 'topk', dropout, S, 1e-3, 1e-3, eps, dual, dict(failure_refresh=10 ** 9, **extras))
+          dual=False, dropout=2, confidence=1e-1, density=1e-3, structured=1e-3):
+    return HotLoop(DorPatch(micro_batch=mb, verbose=False), model, x, budget, 10, tmp, 0, y, targeted, lr, confidence,
+                   0, 1, 10 ** 6, 7, 'topk', dropout, S, density, structured, eps, dual,
+                   dict(failure_refresh=10 ** 9, **extras))
 
 
 def _grab(store):
@@ -61,7 +62,8 @@ def _replay_golden_steps(g, rtol_g):
                      dict(init_mask=torch.from_numpy(g[p + "mask"]), init_pattern=torch.from_numpy(g[p + "pattern"]),
                           rngs=[FixedDraw([g[p + "idx"]] + ([g[p + "idx_dual"]] if dual else []))], step_hook=_grab(got)),
                      eps=float(g["eps"]), dual=dual, dropout=int(g["dropout"]) if "dropout" in g else 2,
-                     targeted=bool(g["targeted"]) if "targeted" in g else True)
+                     targeted=bool(g["targeted"]) if "targeted" in g else True,
+                     **{k: float(g[k]) for k in ("confidence", "density", "budget") if k in g})
         loop.stage = int(g[p + "stage"])
         st = loop.img[0]
         st.structured, st.coeff_group_lasso = float(g[p + "structured"]), float(g[p + "coeff_group_lasso"])

@@ -182,3 +182,50 @@ def test_patchcleanser_sweep_against_the_live_reference(ref):
                         assert np.array_equal(got.preds_2, want.preds_2), (r, seed)
                     branches.add((len(np.unique(want.preds_1)) > 1, bool(want.certification)))
     assert len(branches) >= 3, branches
+
+
+@pytest.mark.parametrize("hyper", [dict(eps=1.0, confidence=0.5, density=5e-3, structured=5e-3, patch_budget=0.06),
+                                   dict(eps=8.0, confidence=0.0, density=1e-2, structured=1e-4, patch_budget=0.0204, lr=0.05)])
+def test_hot_loop_steps_under_other_hyper_parameters(ref, hyper):
+    """The reference's own `generate` run live with non-default eps / confidence / density / structured / patch_budget /
+    lr (attack.py:51-53), its first steps of both stages recorded as in oracle/gen_golden.py, and replayed through the
+    product's HotLoop.step (HIP kernels through the host emulation) and through the oracle — the recorded fixtures only
+    hold the default hyper-parameters."""
+    import importlib.util
+    from tests_hipemu import patch as emu_patch
+    if emu_patch.build_emu.host_compiler() is None:
+        pytest.skip("no host clang++ for the HIP emulation build")
+    from oracle import gen_golden as G
+    H, S, n = 56, 6, 2
+    net, x, y = G.toy_problem(H, gain=1.5, seed_x=11)
+    kw = dict(hyper)
+    eps = kw.pop("eps")
+    budget = kw.pop("patch_budget")
+    cap, _, _, _ = G.run_reference(net, x, y, sampling_size=S, max_iterations=n + 1, eps=eps, patch_budget=budget,
+                                   keep=lambda s, i: True, **kw)
+    g = G._pack_steps(cap, [(0, i) for i in range(n)] + [(1, i) for i in range(n)])
+    g.update(x=x.numpy(), gain=1.5, H=H, S=S, eps=eps, budget=budget, confidence=hyper["confidence"], density=hyper["density"])
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("_attack_gpu_for_live", os.path.join(here, "test_attack_gpu.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.DEV = "cpu"
+    saved = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None
+    try:
+        with emu_patch.emulated_ops():
+            mod._replay_golden_steps(g, 1e-3)
+    finally:
+        torch.cuda.synchronize = saved
+    # and the oracle on the same recorded steps
+    universe, lvx = R.mask_universe(H, 2), R.local_variance(x)[0].mean(1)
+    for k in range(int(g["n_steps"])):
+        p = "s%d_" % k
+        out = R.eot_step(net, x, torch.from_numpy(g[p + "mask"]), torch.from_numpy(g[p + "pattern"]), torch.tensor([int(g[p + "y"])]),
+                         universe[torch.from_numpy(g[p + "idx"])], stage=int(g[p + "stage"]), targeted=True, n_classes=10,
+                         confidence=hyper["confidence"], density=hyper["density"], structured=float(g[p + "structured"]),
+                         coeff_group_lasso=float(g[p + "coeff_group_lasso"]), eps=eps, local_var_x=lvx)
+        np.testing.assert_allclose(out["loss_adv"].numpy().reshape(-1), g[p + "loss_adv"], atol=1e-6, rtol=1e-5)
+        np.testing.assert_allclose(out["grad_pattern"].numpy(), g[p + "grad_pattern"], atol=1e-6, rtol=1e-4)
+        if int(g[p + "stage"]) == 0:
+            np.testing.assert_allclose(np.nan_to_num(out["grad_mask"].numpy()), np.nan_to_num(g[p + "grad_mask"]), atol=1e-6, rtol=1e-4)
