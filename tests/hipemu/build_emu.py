@@ -15,8 +15,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 SRC = os.path.join(ROOT, "dorpatch_amd", "csrc", "dorpatch_hip.hip")
-OUT = os.path.join(HERE, "libdorpatch_emu.so")
-GEN = os.path.join(HERE, "_dorpatch_emu_gen.cpp")
+SANITIZE = os.environ.get("DORPATCH_EMU_SANITIZE", "0") == "1"      # AddressSanitizer build (tests/test_kernels_asan.py)
+OUT = os.path.join(HERE, "libdorpatch_emu_asan.so" if SANITIZE else "libdorpatch_emu.so")
+GEN = os.path.join(HERE, "_dorpatch_emu_asan_gen.cpp" if SANITIZE else "_dorpatch_emu_gen.cpp")
 DEPS = [SRC, os.path.join(ROOT, "include", "dorpatch_hip.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
         os.path.abspath(__file__)]
 
@@ -47,12 +48,25 @@ def build(force=False):
     # same FP contract as the product build (dorpatch_amd/build.py): no fused multiply-add, no fast-math
     cmd = [cxx, "-x", "c++", "-std=c++17", "-O1", "-g0", "-ffp-contract=off", "-fPIC", "-shared", "-w",
            "-I", HERE, "-I", os.path.join(ROOT, "include"), GEN, "-o", OUT + ".tmp"]
+    if SANITIZE:     # every LDS array, local array and (through the malloc interceptor) every tensor gets red zones
+        cmd[cmd.index("-g0")] = "-g"
+        cmd[5:5] = ["-fsanitize=address", "-shared-libasan", "-fno-omit-frame-pointer"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipemu build failed:\n" + res.stdout + res.stderr)
     os.replace(OUT + ".tmp", OUT)
     os.remove(GEN)
     return OUT
+
+
+def asan_runtime():
+    """Path of clang's shared AddressSanitizer runtime (to LD_PRELOAD into the python process), or None."""
+    cxx = host_compiler()
+    if cxx is None:
+        return None
+    res = subprocess.run([cxx, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    path = res.stdout.strip()
+    return path if os.path.isabs(path) and os.path.exists(path) else None
 
 
 if __name__ == "__main__":

@@ -1,0 +1,78 @@
+"""Memory checking of the HIP kernels (the role compute-sanitizer / rocgdb memcheck play on a device; SURVEY §4's
+"race detection, failure detection" aux row): the product's HIP translation unit, compiled unchanged as host C++ for the
+emulation (tests/hipemu), is built with AddressSanitizer and the whole kernel parity suite re-runs under it in a child
+process.  Every `__shared__` array, every local array and — through ASan's malloc interceptor — every tensor carries red
+zones, so an out-of-bounds LDS tile access, a halo that runs past the image or a store past the end of an output
+buffer aborts the run.  A canary proves the set-up catches such a store by one of the product's kernels.
+
+TEST INFRASTRUCTURE ONLY: nothing here is loaded by the product."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests_hipemu import build_emu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+RUNTIME = build_emu.asan_runtime()
+
+if build_emu.host_compiler() is None or RUNTIME is None:
+    pytest.skip("no host clang++ / shared AddressSanitizer runtime", allow_module_level=True)
+
+
+def _env():
+    env = dict(os.environ, DORPATCH_EMU_SANITIZE="1", LD_PRELOAD=RUNTIME, PYTHONPATH=ROOT,
+               ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:verify_asan_link_order=0:halt_on_error=1:"
+                            "abort_on_error=0:exitcode=86")
+    return env
+
+
+CANARY = r'''
+import ctypes, sys, torch
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(tests)r)
+import importlib.util, os
+spec = importlib.util.spec_from_file_location("tests_hipemu", os.path.join(%(tests)r, "hipemu", "__init__.py"),
+                                              submodule_search_locations=[os.path.join(%(tests)r, "hipemu")])
+mod = importlib.util.module_from_spec(spec); sys.modules["tests_hipemu"] = mod; spec.loader.exec_module(mod)
+from tests_hipemu import patch
+lib = patch.emu_lib()
+x = torch.rand(4, 8, 8)
+y = torch.empty(4 * 4 * 4 - %(short)d)            # dp_subsample2 writes 4 x 4 x 4 floats
+rc = lib.dp_subsample2(x.data_ptr(), 4, 8, 8, y.data_ptr(), None)
+print("returned", rc)
+'''
+
+
+def _run_canary(short):
+    code = CANARY % dict(root=ROOT, tests=HERE, short=short)
+    return subprocess.run([sys.executable, "-c", code], env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=600)
+
+
+def test_asan_catches_a_kernel_store_past_its_output_buffer():
+    ok = _run_canary(0)
+    assert ok.returncode == 0 and "returned 0" in ok.stdout, ok.stderr[-2000:]
+    bad = _run_canary(8)                                   # the last 8 floats of the output do not exist
+    assert bad.returncode != 0 and "AddressSanitizer" in bad.stderr and "heap-buffer-overflow" in bad.stderr, \
+        (bad.returncode, bad.stderr[-2000:])
+    assert "k_subsample2" in bad.stderr                    # the report names the kernel
+
+
+def test_kernel_suite_is_clean_under_address_sanitizer():
+    """Default: the kernel suite minus its slowest cases (the whole-network test and the two largest residual-GroupNorm
+    shapes; the smaller shapes of the same kernels stay in).  DORPATCH_ASAN_FULL=1: everything, plus the selected-sample backward (dp_gn_relu_bwd_gather)
+    and the affine-placement kernels — run clean in the round-2 build container."""
+    full = os.environ.get("DORPATCH_ASAN_FULL", "0") == "1"
+    files = [os.path.join(HERE, "test_kernels_emu.py")]
+    select = []
+    if full:
+        files += [os.path.join(HERE, "test_taped_emu.py"), os.path.join(HERE, "test_placement_emu.py")]
+    else:
+        select = ["-k", "not resnetv2_fused and not (add_gn_relu_fusion and (shape0 or shape1))"]
+    res = subprocess.run([sys.executable, "-m", "pytest"] + files + ["-q", "-x", "-p", "no:cacheprovider"] + select,
+                         env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=2400)
+    tail = (res.stdout + res.stderr)[-3000:]
+    assert res.returncode == 0 and "AddressSanitizer" not in res.stdout + res.stderr, tail
+    assert " passed" in res.stdout and "failed" not in res.stdout, tail
