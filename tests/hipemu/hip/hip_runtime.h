@@ -89,6 +89,31 @@ inline void trampoline() {
   swapcontext(&s.cur->ctx, &s.main);
 }
 
+// Schedule fuzzing (tests/test_kernels_schedule.py): HIPEMU_ORDER=1 runs the runnable fibers of a block in DESCENDING
+// thread order and the blocks of a grid in reverse order; 2 = a fixed pseudo-random permutation of both.  A kernel whose
+// result depends on the order in which threads between two barriers (or blocks of a launch) execute — a missing
+// __syncthreads() around an LDS tile, an inter-block dependency — then gives different results and fails its parity test.
+inline int order_mode() {
+  static const int mode = [] {
+    const char *e = getenv("HIPEMU_ORDER");
+    return e ? atoi(e) : 0;
+  }();
+  return mode;
+}
+
+inline unsigned permute(unsigned i, unsigned n) {  // position i of the schedule -> index (a bijection on [0, n))
+  const int m = order_mode();
+  if (m == 1) return n - 1 - i;
+  if (m == 2) {  // multiplicative shuffle: stride coprime to n
+    unsigned stride = 7919u % n;
+    if (stride == 0) stride = 1;
+    auto gcd = [](unsigned a, unsigned b) { while (b) { unsigned t = a % b; a = b; b = t; } return a; };
+    while (gcd(stride, n) != 1) ++stride;
+    return (unsigned)(((unsigned long long)i * stride + 3) % n);
+  }
+  return i;
+}
+
 inline void yield(State st) {
   Sched &s = S();
   s.cur->state = st;
@@ -120,8 +145,8 @@ inline void run_block(const dim3 &bidx, const dim3 &bdim, const dim3 &gdim) {
   int alive = T;
   while (alive > 0) {
     bool ran = false;
-    for (int t = 0; t < T; ++t) {
-      Fiber &f = s.fibers[t];
+    for (int i = 0; i < T; ++i) {
+      Fiber &f = s.fibers[permute((unsigned)i, (unsigned)T)];
       if (f.state != RUNNABLE) continue;
       s.cur = &f;
       swapcontext(&s.main, &f.ctx);
@@ -172,7 +197,8 @@ inline void launch(dim3 grid, dim3 block, size_t lds, const std::function<void()
   s.dyn_lds.assign(lds + 16, 0);
   for (unsigned z = 0; z < grid.z; ++z)
     for (unsigned y = 0; y < grid.y; ++y)
-      for (unsigned x = 0; x < grid.x; ++x) run_block(dim3(x, y, z), block, grid);
+      for (unsigned x = 0; x < grid.x; ++x)
+        run_block(dim3(permute(x, grid.x), permute(y, grid.y), permute(z, grid.z)), block, grid);
   s.body = nullptr;
 }
 

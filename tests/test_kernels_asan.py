@@ -1,7 +1,9 @@
 """Memory checking of the HIP kernels (the role compute-sanitizer / rocgdb memcheck play on a device; SURVEY §4's
 "race detection, failure detection" aux row): the product's HIP translation unit, compiled unchanged as host C++ for the
-emulation (tests/hipemu), is built with AddressSanitizer and the whole kernel parity suite re-runs under it in a child
-process.  Every `__shared__` array, every local array and — through ASan's malloc interceptor — every tensor carries red
+emulation (tests/hipemu), is built with AddressSanitizer and the kernel parity suite re-runs under it in a child
+process — with the emulator's thread and block schedule REVERSED (schedule fuzzing: a kernel whose result depends on the
+order in which the threads between two barriers, or the blocks of a launch, execute — a missing `__syncthreads()` around
+an LDS tile, an inter-block dependency — then fails its parity test; a second canary shows that).  Every `__shared__` array, every local array and — through ASan's malloc interceptor — every tensor carries red
 zones, so an out-of-bounds LDS tile access, a halo that runs past the image or a store past the end of an output
 buffer aborts the run.  A canary proves the set-up catches such a store by one of the product's kernels.
 
@@ -23,7 +25,9 @@ if build_emu.host_compiler() is None or RUNTIME is None:
 
 
 def _env():
-    env = dict(os.environ, DORPATCH_EMU_SANITIZE="1", LD_PRELOAD=RUNTIME, PYTHONPATH=ROOT,
+    # HIPEMU_ORDER=1: the same child run also executes the threads of every block in DESCENDING order and the blocks of
+    # every launch in reverse (schedule fuzzing, see below) — the plain emulation suites run ascending
+    env = dict(os.environ, DORPATCH_EMU_SANITIZE="1", LD_PRELOAD=RUNTIME, PYTHONPATH=ROOT, HIPEMU_ORDER="1",
                ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:verify_asan_link_order=0:halt_on_error=1:"
                             "abort_on_error=0:exitcode=86")
     return env
@@ -76,3 +80,44 @@ def test_kernel_suite_is_clean_under_address_sanitizer():
     tail = (res.stdout + res.stderr)[-3000:]
     assert res.returncode == 0 and "AddressSanitizer" not in res.stdout + res.stderr, tail
     assert " passed" in res.stdout and "failed" not in res.stdout, tail
+
+
+RACY = r"""
+#include <hip/hip_runtime.h>
+#include <cstdio>
+template <bool SYNC>
+__global__ void k_rotate(const int *in, int *out) {
+  __shared__ int tile[128];
+  tile[threadIdx.x] = in[threadIdx.x];
+  if (SYNC) __syncthreads();                       // without it the read below races with the neighbour's write
+  out[threadIdx.x] = tile[(threadIdx.x + 1) & 127];
+}
+int main(int argc, char **argv) {
+  int in[128], out[128];
+  for (int i = 0; i < 128; ++i) { in[i] = i + 1; out[i] = -1; }
+  const int *pin = in;
+  int *pout = out;
+  if (argv[1][0] == 'r') hipLaunchKernelGGL(k_rotate<false>, dim3(1), dim3(128), 0, nullptr, pin, pout);
+  else hipLaunchKernelGGL(k_rotate<true>, dim3(1), dim3(128), 0, nullptr, pin, pout);
+  long sum = 0;
+  for (int i = 0; i < 128; ++i) sum = sum * 31 + out[i];
+  printf("%ld\n", sum);
+  return 0;
+}
+"""
+
+
+def test_schedule_fuzzing_exposes_a_missing_barrier(tmp_path):
+    """A kernel with a missing __syncthreads() gives different results under the ascending and the reversed schedule;
+    the same kernel with the barrier does not."""
+    src = tmp_path / "racy.cpp"
+    src.write_text(RACY)
+    exe = str(tmp_path / "racy")
+    subprocess.run([build_emu.host_compiler(), "-x", "c++", "-std=c++17", "-O1", "-w",
+                    "-I", os.path.join(HERE, "hipemu"), str(src), "-o", exe], check=True, capture_output=True)
+
+    def run(which, order):
+        return subprocess.run([exe, which], env=dict(os.environ, HIPEMU_ORDER=str(order)), capture_output=True, text=True,
+                              check=True).stdout.strip()
+    assert run("s", 0) == run("s", 1) == run("s", 2)
+    assert len({run("r", 0), run("r", 1), run("r", 2)}) > 1
