@@ -66,8 +66,40 @@ def _stem_supported(x, weight, stride, padding):
             and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
 
 
+def _poisoned(fn):
+    """torch.empty / torch.empty_like that hand out NaN (float) or a sentinel (integer) instead of whatever the
+    allocator had: an output element a kernel forgets to write then reaches the comparison as NaN / garbage."""
+    def make(*a, **k):
+        t = fn(*a, **k)
+        if t.numel():
+            if t.is_floating_point():
+                t.fill_(float("nan"))
+            elif t.dtype == torch.bool:
+                t.fill_(True)
+            elif t.dtype in (torch.uint8, torch.int8):
+                t.fill_(0x5B)
+            else:
+                t.fill_(-123456789 if t.dtype != torch.int16 else -12345)
+        return t
+    return make
+
+
 @contextlib.contextmanager
 def emulated_ops():
+    import os
+    poison = os.environ.get("HIPEMU_POISON", "0") == "1"     # tests/test_kernels_asan.py sets it for its child run
+    saved_empty = (torch.empty, torch.empty_like)
+    if poison:
+        torch.empty, torch.empty_like = _poisoned(torch.empty), _poisoned(torch.empty_like)
+    try:
+        with _emulated_ops() as lib:
+            yield lib
+    finally:
+        torch.empty, torch.empty_like = saved_empty
+
+
+@contextlib.contextmanager
+def _emulated_ops():
     lib = emu_lib()
     assert lib is not None, "no host clang++: cannot build the emulation library"
     saved = dict(lib=_lib._lib, req=ops.require_gpu, chk=ops._chk, stream=ops._stream, gn=ops.gn_relu_supported,

@@ -26,8 +26,9 @@ if build_emu.host_compiler() is None or RUNTIME is None:
 
 def _env():
     # HIPEMU_ORDER=1: the same child run also executes the threads of every block in DESCENDING order and the blocks of
-    # every launch in reverse (schedule fuzzing, see below) — the plain emulation suites run ascending
-    env = dict(os.environ, DORPATCH_EMU_SANITIZE="1", LD_PRELOAD=RUNTIME, PYTHONPATH=ROOT, HIPEMU_ORDER="1",
+    # every launch in reverse (schedule fuzzing, see below) — the plain emulation suites run ascending.  HIPEMU_POISON=1:
+    # torch.empty / empty_like hand out NaN / sentinels, so an output element a kernel never writes fails the comparison
+    env = dict(os.environ, DORPATCH_EMU_SANITIZE="1", LD_PRELOAD=RUNTIME, PYTHONPATH=ROOT, HIPEMU_ORDER="1", HIPEMU_POISON="1",
                ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:verify_asan_link_order=0:halt_on_error=1:"
                             "abort_on_error=0:exitcode=86")
     return env
