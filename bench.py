@@ -5,6 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
     python bench.py --config {0,2,3}            # the other single-GPU BASELINE configs (parity-test cases, also timed)
+    DORPATCH_TRACE=1: roctx ranges around the step's phases (for `rocprofv3 --marker-trace --kernel-trace`).
     A/B switches: --deterministic {auto,on,off}, --conv1x1 {table,auto,gemm,miopen}, DORPATCH_TUNABLEOP=0, --stem-split, --skip-satisfied {on,off},
                   --satisfied F (what-if),
                   --no-fused-gn, --micro-batch N, --find 1
@@ -346,7 +347,7 @@ def main():
                                                           args.patch_budget),
                        "images": B, "masks_per_image_per_gpu": S_local, "masks_per_image_total": S,
                        "image_size": H, "micro_batch": args.micro_batch, "miopen_find": bool(args.find),
-                       "fused_gn_relu": not args.no_fused_gn, "deterministic": "%s: %s" % (args.deterministic, loop.deterministic_in_effect),
+                       "fused_gn_relu": not args.no_fused_gn, "trace": loop.phases.mode, "deterministic": "%s: %s" % (args.deterministic, loop.deterministic_in_effect),
                        "backward": {"skip_satisfied": args.skip_satisfied == "on", "explicit_tape": bool(loop._taped),
                                     "samples_forward": loop.n_forward, "samples_with_gradient": loop.n_active,
                                     "samples_back_propagated": loop.n_backward, "tape_micro_batches": loop._tape_tabs,

@@ -157,6 +157,43 @@ class _ImageState(object):
         return loss_decay, stop
 
 
+class _Phases(object):
+    """Opt-in tracing of the step's phases (the reference has none).  ``DORPATCH_TRACE=1``: each phase is a
+    roctx range (``torch.cuda.nvtx`` is roctx on ROCm) — `rocprofv3 --marker-trace --kernel-trace` then groups the
+    kernels of a step under `dp:blend`, `dp:collect_failure`, `dp:sample`, `dp:regularisers`, `dp:eot_fwd_bwd`,
+    `dp:allreduce`, `dp:sync+bookkeeping`, `dp:project_update`.  ``DORPATCH_TRACE=log``: the names are appended to
+    ``.log`` instead (what the CPU tests read).  Off (default): every call is one attribute test."""
+
+    def __init__(self, mode, cuda):
+        self.log = []
+        self.mode = None
+        self._open = False
+        if mode == "log":
+            self.mode = "log"
+        elif mode and mode != "0" and cuda:
+            try:                                  # a torch build without roctx: tracing off, never an error
+                torch.cuda.nvtx.range_push("dp:probe")
+                torch.cuda.nvtx.range_pop()
+                self.mode = "roctx"
+            except Exception:                     # noqa: BLE001
+                self.mode = None
+
+    def mark(self, name):
+        """End the current phase (if any) and, unless ``name`` is None, begin phase ``name``."""
+        if self.mode is None:
+            return
+        if self.mode == "log":
+            if name is not None:
+                self.log.append(name)
+            return
+        if self._open:
+            torch.cuda.nvtx.range_pop()
+            self._open = False
+        if name is not None:
+            torch.cuda.nvtx.range_push(name)
+            self._open = True
+
+
 class DorPatch(object):
     """Drop-in for the reference ``attack.DorPatch`` (``attack.py:47-406``).
 
@@ -221,6 +258,8 @@ class DorPatch(object):
         measured slightly slower), ``skip_satisfied`` (default: the constructor's, False — see ``HotLoop._fb_taped``), ``skip_min_fraction`` (0.2: the
         selected-sample backward compacts a group of micro-batches only when at least this fraction of its samples is
         skippable; below it every sample is back-propagated in place),
+        ``trace`` (default: the environment's ``DORPATCH_TRACE``; ``1`` = roctx ranges
+        around the step's phases, ``"log"`` = phase names collected in ``last_run.phases.log`` — see ``_Phases``),
         ``tape_tabs`` (micro-batches whose activations one backward may draw from, default: what fits in half of the free
         HBM, at most 8), ``backward_ladder`` (batch sizes the selected-sample backward may use), ``placement``
         (EXTENSION, not in the reference: e.g. ``dorpatch_amd.placement.RandomAffine()`` — every EOT sample sees the
@@ -494,6 +533,7 @@ class HotLoop(object):
         self._skip_min_fraction = float(extras.get("skip_min_fraction", 0.2))
         self._det_sizes = {}                                   # backward batch size -> library kernels must be forced deterministic
         self.n_forward = self.n_active = self.n_backward = 0   # samples: forwarded / carrying gradient / back-propagated (incl. padding)
+        self.phases = _Phases(extras.get("trace", os.environ.get("DORPATCH_TRACE", "0")), self.dev.type == "cuda")
 
     # ---------------------------------------------------------------- plumbing
     def close(self):
@@ -657,9 +697,13 @@ class HotLoop(object):
             self._refresh_failures()        # on the previous step's adv_x, like the reference
 
         # --- a-2: utils.clip + adv_x (attack.py:184-185)
+        ph = self.phases
+        ph.mark("dp:blend")
         _, scale, l2 = ops.blend(self.adv_mask, self.adv_pattern, self.x, self.eps, out=self.adv_x)
         if i % self.failure_refresh == 0:                              # attack.py:187-190
+            ph.mark("dp:collect_failure")
             self._refresh_failures()
+        ph.mark("dp:sample")
 
         # --- a-3: mask sampling on the host (same RNG calls as the reference)
         # (every rank draws the full (B, S) index set from identical generator state and keeps its own S-slice)
@@ -672,6 +716,7 @@ class HotLoop(object):
         crit_flags = self._dev_i32(self._flags("crit_targeted"))
 
         # --- a-5 / a-6 forward terms (identical on every rank: same inputs, fixed-order reductions)
+        ph.mark("dp:regularisers")
         if self.world > 1:
             self._tail.zero_()          # the other ranks' slabs must be 0 going into the SUM
             self._own_chk.fill_(self._draw_checksum())
@@ -682,15 +727,19 @@ class HotLoop(object):
                                               gl_out=self._reg[B:2 * B], dens_out=self._reg[2 * B:3 * B])
 
         # --- a-4, a-8, a-7: occlude -> frozen backbone fwd/bwd -> CW loss, in micro-batches
+        ph.mark("dp:eot_fwd_bwd")
         self._eot_forward_backward(idx, idx2, crit_flags)
         if self.world > 1 and not self._conv_shared:    # conv1x1 "auto" only: every replica adopts rank 0's routes
             from . import conv1x1
             conv1x1.share_choices(o.pg)
             self._conv_shared = True
         # THE collective of the step: patch gradient (602 112 B per image @224) + the loss / prediction slabs
+        if self.world > 1:
+            ph.mark("dp:allreduce")
         dp_dist.allreduce_sum_(self._comm[:self._n_g + self._n_tail], o.pg)
 
         # --- the one device->host sync of the step
+        ph.mark("dp:sync+bookkeeping")
         loss_adv_np, loss_struc_np, gl_np, dens_np = self._gather_stats()
 
         # --- a-9: per-image bookkeeping (attack.py:249-316)
@@ -738,6 +787,7 @@ class HotLoop(object):
                                 save_best=save_best.copy(), states=self.img))
 
         # --- a-2 backward + a-5/a-6 gradients + signed update (attack.py:247, 333-342)
+        ph.mark("dp:project_update")
         ops.project_update(
             self.x, self.adv_x, self.lv_x, self.g_adv, scale, self._dev_f32(structured_pre),
             self.adv_pattern, self.adv_mask, stage=stage, lr=self._dev_f32(lr_now),
@@ -745,6 +795,7 @@ class HotLoop(object):
             win=self.win, density=self.density, clip_min=self.clip_min, clip_max=self.clip_max,
             save_best=self._dev_i32(save_best), best_pattern=self.best_pattern,
             best_mask=self.best_mask, do_update=True)
+        ph.mark(None)
         self.samples_done += B * S
         return any(st.active for st in self.img)
 

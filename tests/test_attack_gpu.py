@@ -211,6 +211,24 @@ def test_generate_untargeted_run_tracks_reference(golden_trace_untargeted, tmp_p
     assert set(np.unique(mask.cpu().numpy())) <= {0.0, 1.0}
 
 
+def test_phase_trace_log():
+    """DORPATCH_TRACE / extras trace="log": the step announces its phases in order (on a GPU with trace=1 the same marks
+    are roctx ranges for `rocprofv3 --marker-trace`); off by default."""
+    H, S = 56, 4
+    model = _toy(2.0)
+    x = torch.rand(1, 3, H, H, generator=torch.Generator().manual_seed(2)).to(DEV)
+    loop = _loop(model, x, torch.tensor([3], device=DEV), S, dict(trace="log"))
+    loop.step(0)
+    loop.step(1)
+    loop.close()
+    step1 = ["dp:blend", "dp:sample", "dp:regularisers", "dp:eot_fwd_bwd", "dp:sync+bookkeeping", "dp:project_update"]
+    assert loop.phases.log == step1[:1] + ["dp:collect_failure"] + step1[1:] + step1
+    quiet = _loop(model, x, torch.tensor([3], device=DEV), S, {})
+    quiet.step(1)
+    quiet.close()
+    assert quiet.phases.mode is None and quiet.phases.log == []
+
+
 def test_generate_short_run_both_stages(tmp_path, monkeypatch):
     """A 12-iterations-per-stage DorPatch.generate (seconds, also under the CPU emulation): stage 0 consumes
     the global RNG streams exactly like the recorded reference run (identical mask draws and first-step
