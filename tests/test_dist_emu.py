@@ -104,8 +104,10 @@ def _loop_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_hot_loop_two_ranks_equals_one(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_hot_loop_two_ranks_equals_one(world, tmp_path):
+    """world = 4 as well: the slab layout of the all-reduce buffer, the mask-universe slices of the sharded failure sweep
+    and the draw checksums beyond two ranks (the driver's 8-GPU scaling run is the first time RCCL sees this code)."""
     mp.spawn(_loop_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     with _emu_patch().emulated_ops():
         want = _run_loop(None, 0)
@@ -128,10 +130,11 @@ def test_hot_loop_two_ranks_equals_one(tmp_path):
         assert ((o["pattern"] - want["pattern"]).abs() > 1e-6).float().mean() < 5e-3
         assert ((o["mask"] - want["mask"]).abs() > 1e-6).float().mean() < 5e-3
     # ranks stay in lock-step: bit-identical reduced gradients, losses and parameters
-    for k in range(N_STEPS):
-        assert torch.equal(outs[0]["seen"][k]["g_adv"], outs[1]["seen"][k]["g_adv"])
-        assert np.array_equal(outs[0]["seen"][k]["loss_adv"], outs[1]["seen"][k]["loss_adv"])
-    assert torch.equal(outs[0]["pattern"], outs[1]["pattern"]) and torch.equal(outs[0]["mask"], outs[1]["mask"])
+    for other in outs[1:]:
+        for k in range(N_STEPS):
+            assert torch.equal(outs[0]["seen"][k]["g_adv"], other["seen"][k]["g_adv"])
+            assert np.array_equal(outs[0]["seen"][k]["loss_adv"], other["seen"][k]["loss_adv"])
+        assert torch.equal(outs[0]["pattern"], other["pattern"]) and torch.equal(outs[0]["mask"], other["mask"])
 
 
 def _placement_worker(rank, world, port, out_dir):
@@ -291,17 +294,17 @@ def _bench_worker(rank, world, port, out_dir):
             bench.main()
 
 
-def test_bench_two_ranks_prints_one_whole_job_line(tmp_path):
-    """`python -m torch.distributed.run ... bench.py --gpus 2` as the driver launches it (here: gloo, CPU
-    tensors, emulated kernels): rank 0 alone prints the line, for the WHOLE job (weak scaling: 2 masks per
-    image per rank -> 4 per image in total)."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_two_ranks_prints_one_whole_job_line(world, tmp_path):
+    """`python -m torch.distributed.run ... bench.py --gpus N` as the driver launches it for N = 2 and 8 (here: gloo,
+    CPU tensors, emulated kernels): rank 0 alone prints the line, for the WHOLE job (weak scaling: 2 masks per
+    image per rank -> 2 N per image in total)."""
     import json
-    world = 2
     mp.spawn(_bench_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     out0 = open(os.path.join(str(tmp_path), "stdout0.txt")).read().strip().splitlines()
-    out1 = open(os.path.join(str(tmp_path), "stdout1.txt")).read().strip()
-    assert len(out0) == 1 and out1 == ""
+    others = [open(os.path.join(str(tmp_path), "stdout%d.txt" % r)).read().strip() for r in range(1, world)]
+    assert len(out0) == 1 and all(o == "" for o in others)
     line = json.loads(out0[0])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "cpu_baseline" not in line
-    assert line["config"]["masks_per_image_per_gpu"] == 2 and line["config"]["masks_per_image_total"] == 4
-    assert abs(line["value"] - 1 * 4 / (line["ms_per_step"] / 1e3)) <= 0.006 + 1e-3 * line["value"]
+    assert line["n_gpus"] == world and line["scaling"] == "weak" and "cpu_baseline" not in line
+    assert line["config"]["masks_per_image_per_gpu"] == 2 and line["config"]["masks_per_image_total"] == 2 * world
+    assert abs(line["value"] - 1 * 2 * world / (line["ms_per_step"] / 1e3)) <= 0.006 + 1e-3 * line["value"]
