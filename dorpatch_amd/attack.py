@@ -205,13 +205,15 @@ class DorPatch(object):
     takes ``sign(grad)``: two runs from identical seeds otherwise drift apart).  At small batches MIOpen's
     immediate mode picks split-K implicit-GEMM kernels that accumulate with float atomics (5 of ResNetV2-50's
     23 convolution shapes at 8 samples; none at 512 — ``profiles/r02c_determinism_probe.jsonl``).
-    ``True``: ``torch.backends.cudnn.deterministic = True`` while ``generate`` runs (costs 5 % at the benchmark
-    configuration, where it changes nothing: MIOpen then avoids kernels that were deterministic anyway);
-    ``False``: leave MIOpen alone; ``"auto"`` (default): MEASURE — the first micro-batch's forward/backward runs
-    twice, and only if the two input gradients differ in any bit is the flag switched on for this run.  With
-    the table-routed 1x1 convolutions and the fixed-order reductions of every HIP kernel, identical inputs
-    then give identical bits either way.  The reference sets ``cudnn.benchmark = True``
-    (``utils.py:17``) and is not run-to-run reproducible on a GPU.
+    ``True``: ``torch.backends.cudnn.deterministic = True`` while ``generate`` runs (bans MIOpen's whole NHWC
+    implicit-GEMM family: 5 % at the benchmark configuration, where it changes nothing, 7.8 % at 1 image x 128 masks);
+    ``False``: leave MIOpen alone; ``"auto"`` (default): decide PER CONVOLUTION PROBLEM — the first time a
+    (direction, batch, shape) is seen it runs three times on its real operands, and only a problem whose results
+    differ in any bit is run with deterministic kernels from then on (``dorpatch_amd/libconv.py``; with
+    dorpatch_amd's own ResNetV2; another classifier's convolutions are outside its reach — use ``True`` there).
+    With the table-routed 1x1 convolutions and the fixed-order reductions of every HIP kernel, identical inputs
+    then give identical bits.  The reference sets ``cudnn.benchmark = True`` (``utils.py:17``) and is not run-to-run
+    reproducible on a GPU.
     ``skip_satisfied`` (default False = the reference's behaviour, every sample is back-propagated, ``attack.py:247``):
     opt-in — the backward pass runs only over the EOT samples whose CW hinge is still active (a satisfied sample's
     gradient is exactly zero), see ``HotLoop._fb_taped``.  Same gradients to ~1e-6 of their scale (the compacted
@@ -223,8 +225,8 @@ class DorPatch(object):
     def __init__(self, micro_batch=512, process_group=None, verbose=True, deterministic="auto", skip_satisfied=False):
         self.micro_batch = int(micro_batch)
         self.skip_satisfied = bool(skip_satisfied)
-        if deterministic not in (True, False, "auto"):
-            raise ValueError("deterministic must be True, False or 'auto'")
+        if not (deterministic is True or deterministic is False or deterministic == "auto"):
+            raise ValueError("deterministic must be True, False or 'auto' (got %r)" % (deterministic,))
         self.deterministic = deterministic
         self.pg = process_group
         self.verbose = verbose
@@ -431,12 +433,23 @@ class HotLoop(object):
         self._frozen = [(p, p.requires_grad) for p in self.net.parameters()]
         for p, _ in self._frozen:
             p.requires_grad_(False)
+        # Tuned GEMM solutions for the table-routed 1x1 convolutions of dorpatch_amd's own ResNetV2: one verdict per
+        # process (rank 0's numeric self-test, agreed by all ranks), in effect only between here and close().
+        from . import conv1x1, resnetv2
+        self._tuned_scope = False
+        if any(isinstance(m, resnetv2.StdConv2d) for m in self.net.modules()):
+            self._tuned_scope = conv1x1.activate(owner.pg, self.dev.type == "cuda")
+        self.gemm_solutions = conv1x1.report_tuned()
+        # Run-to-run bit reproducibility of the library convolutions (class docstring): True = the global flag for the
+        # whole run; "auto" = per (direction, batch, shape) problem, probed at first use (dorpatch_amd/libconv.py).
+        from . import libconv
         self._cudnn_det = torch.backends.cudnn.deterministic
+        self._libconv_mode = libconv.MODE
         if owner.deterministic is True:
             torch.backends.cudnn.deterministic = True
-        self._det_pending = owner.deterministic == "auto" and not torch.backends.cudnn.deterministic
-        self.deterministic_in_effect = "on" if torch.backends.cudnn.deterministic else \
-            ("pending" if self._det_pending else "off")
+        elif owner.deterministic == "auto" and not torch.backends.cudnn.deterministic:
+            libconv.MODE = "auto"
+        self._det_rows_merged = set()        # micro-batch row counts whose per-problem decisions the ranks have agreed on
 
         owner.criterion = CW_loss(n_classes, targeted, confidence)     # attack.py:57
         # attack.py:59-60 — CPU generator, mask first then pattern
@@ -531,15 +544,32 @@ class HotLoop(object):
         self._tape_tabs = extras.get("tape_tabs")            # None: sized from free memory after the first micro-batch
         self._ladder_user = extras.get("backward_ladder")
         self._skip_min_fraction = float(extras.get("skip_min_fraction", 0.2))
-        self._det_sizes = {}                                   # backward batch size -> library kernels must be forced deterministic
         self.n_forward = self.n_active = self.n_backward = 0   # samples: forwarded / carrying gradient / back-propagated (incl. padding)
         self.phases = _Phases(extras.get("trace", os.environ.get("DORPATCH_TRACE", "0")), self.dev.type == "cuda")
 
     # ---------------------------------------------------------------- plumbing
+    @property
+    def deterministic_in_effect(self):
+        """What run-to-run reproducibility of the library convolutions rests on in this run (bench.py records it)."""
+        from . import libconv
+        if torch.backends.cudnn.deterministic:
+            return "on (torch.backends.cudnn.deterministic for the whole run)"
+        if libconv.MODE == "auto":
+            d = libconv.summary()
+            return "per problem: %d of %d probed (direction, batch, shape) problems forced to deterministic kernels" % (
+                d["forced"], d["problems"])
+        return "off"
+
     def close(self):
         for p, flag in self._frozen:
             p.requires_grad_(flag)
         torch.backends.cudnn.deterministic = self._cudnn_det
+        from . import libconv
+        libconv.MODE = self._libconv_mode
+        if self._tuned_scope:                    # TunableOp back to what the caller's process had
+            from . import conv1x1
+            conv1x1.deactivate()
+            self._tuned_scope = False
 
     def _forward_plain(self, imgs):
         """model(imgs) for un-occluded images in [0,1] (NormModel applied if it was peeled)."""
@@ -800,9 +830,16 @@ class HotLoop(object):
         return any(st.active for st in self.img)
 
     def _draw_checksum(self):
-        """A float-exact fingerprint of this step's draw; all ranks must agree (verified in _gather_stats)."""
+        """A float-exact fingerprint of this step's draws — the mask indices, the second (``dual``) index set and the
+        bit patterns of the placement extension's affine maps; all ranks must agree (verified in _gather_stats)."""
         w = np.arange(1, self.S + 1, dtype=np.int64)
-        return float(int((self.idx_np * w).sum()) % 8388593)      # < 2^23: exact in fp32
+        h = int((self.idx_np * w).sum())
+        if self.idx2_np is not None:
+            h = h * 31 + int((self.idx2_np * w).sum())
+        if self.theta_np is not None:
+            bits = np.ascontiguousarray(self.theta_np, dtype=np.float32).view(np.uint32).astype(np.int64).reshape(-1)
+            h = h * 31 + int((bits * (np.arange(bits.size, dtype=np.int64) % 8191 + 1)).sum() % 2147483629)
+        return float(h % 8388593)                                   # < 2^23: exact in fp32
 
     def _gather_stats(self):
         """Host copies of loss_adv (B,S) over all ranks' samples, loss_struc, group lasso, density (B,);
@@ -892,11 +929,6 @@ class HotLoop(object):
         is multiplied by lr = 0) are skipped as well.  The selected samples of up to ``tape_tabs`` micro-batches are
         compacted into backward batches of the sizes the library routes are tuned for."""
         from . import taped
-        if self._det_pending:      # same library kernels as the autograd path at this batch size: decide there, once
-            n0, n1, b0, b1, s0, s1, _ = chunks[0]
-            self._fb_chunk(inp_all[n0:n1], self.y[b0:b1], crit_flags[b0:b1], s1 - s0, upstream,
-                           loss_flat[n0:n1], self.pred[n0:n1])
-            self._det_sizes[n1 - n0] = False       # verified (or deterministic kernels are now forced globally)
         pos = 0
         while pos < len(chunks):
             rows = chunks[pos][1] - chunks[pos][0]
@@ -921,8 +953,9 @@ class HotLoop(object):
             z = None
             if self._stem_split:
                 conv = net.stem.conv
+                from . import libconv
                 with torch.no_grad():
-                    z = torch.nn.functional.conv2d(inp, conv.weight, None, conv.stride, conv.padding)
+                    z = libconv.conv_fwd(inp, conv.weight, conv.stride, conv.padding)
             logits = taped.forward(net, inp, tape, z=z)
             _, dlogits, pred = ops.cw_loss(logits.float().contiguous(), self.y[b0:b1].contiguous(),
                                            crit_flags[b0:b1].contiguous(), s1 - s0, self.confidence, upstream,
@@ -976,26 +1009,9 @@ class HotLoop(object):
             self._reduce_chunk(G_full[j * tab_rows:j * tab_rows + (c[1] - c[0])], c, idx, idx2)
 
     def _taped_backward(self, tape, dl, sel, size, through_stem):
-        """taped.backward, with deterministic="auto" extended to this backward batch size: the first time a size is
-        used its gradient is computed twice; if the bits differ (atomic split-K kernels at small batches) that size runs
-        with deterministic library kernels from then on.  A rank-local decision: no collective here."""
+        """taped.backward; under deterministic="auto" every library call inside decides per (batch, shape) problem
+        whether it needs deterministic kernels (libconv) — rank-local decisions, no collective here."""
         from . import taped
-        forced = self._det_sizes.get(size)
-        auto = self.o.deterministic == "auto" and not torch.backends.cudnn.deterministic
-        if forced is None and auto:
-            first = taped.backward(self.net, tape, dl, sel, through_stem)
-            again = taped.backward(self.net, tape, dl, sel, through_stem)
-            forced = self._det_sizes[size] = not torch.equal(first, again)
-            if not forced:
-                return again
-            self.o._log(">> library convolutions are not run-to-run deterministic at backward batch %d: "
-                        "deterministic kernels for that size" % size)
-        if forced and not torch.backends.cudnn.deterministic:
-            torch.backends.cudnn.deterministic = True
-            try:
-                return taped.backward(self.net, tape, dl, sel, through_stem)
-            finally:
-                torch.backends.cudnn.deterministic = False
         return taped.backward(self.net, tape, dl, sel, through_stem)
 
     def _ladder(self, tab_rows):
@@ -1032,26 +1048,22 @@ class HotLoop(object):
             ops.apply_bwd(G, self.table, idx, idx2, self.dn, B=B, out=out, accumulate=accumulate)
 
     def _fb_chunk(self, inp, y, flags, S_chunk, upstream, loss_out, pred_out):
-        if self._det_pending:        # deterministic="auto": are the library kernels picked for this shape reproducible?
-            self._det_pending = False
-            first = self._fb_chunk_once(inp, y, flags, S_chunk, upstream, loss_out, pred_out)
-            again = self._fb_chunk_once(inp, y, flags, S_chunk, upstream, loss_out, pred_out)
-            differ = torch.tensor([0 if torch.equal(first, again) else 1], dtype=torch.int32, device=self.dev)
-            dp_dist.allreduce_max_(differ, self.o.pg)        # every replica takes the same decision
-            if int(differ.item()) == 0:
-                self.deterministic_in_effect = "off (verified: two runs of the first micro-batch bit-identical)"
-                return again
-            torch.backends.cudnn.deterministic = True      # restored by close()
-            self.deterministic_in_effect = "on (two runs of the first micro-batch differed)"
-            self.o._log(">> library convolutions are not run-to-run deterministic at this batch size: "
-                        "switching to deterministic kernels")
-        return self._fb_chunk_once(inp, y, flags, S_chunk, upstream, loss_out, pred_out)
+        G = self._fb_chunk_once(inp, y, flags, S_chunk, upstream, loss_out, pred_out)
+        from . import libconv
+        rows = inp.shape[0]
+        if libconv.MODE == "auto" and self.world > 1 and rows not in self._det_rows_merged:
+            # the first micro-batch of a new row count probed new convolution problems: every replica adopts the union
+            # of the ranks' findings (rank-symmetric: the chunking is the same on every rank)
+            libconv.merge_across(self.o.pg)
+            self._det_rows_merged.add(rows)
+        return G
 
     def _fb_chunk_once(self, inp, y, flags, S_chunk, upstream, loss_out, pred_out):
         if self._stem_split:
             conv = self.net.stem.conv
+            from . import libconv
             with torch.no_grad():
-                inp = torch.nn.functional.conv2d(inp, conv.weight, None, conv.stride, conv.padding)
+                inp = libconv.conv_fwd(inp, conv.weight, conv.stride, conv.padding)
         inp = inp.detach().requires_grad_(True)
         with torch.enable_grad():
             logits = self.net.forward_after_stem_conv(inp) if self._stem_split else self.net(inp)

@@ -68,78 +68,150 @@ TABLE, TABLE_TUNED = PLAIN[TUNED_BATCH], TUNED[TUNED_BATCH]
 
 # Tuned GEMM solutions for the GEMM route (PyTorch TunableOp, tuning done offline on an MI355X by
 # scripts/tunableop_probe.py: 1.1-1.3x on most shapes, 2.9x on 64->64 and 1.9x on 256->64 @56x56, where hipBLASLt's
-# default pick is poor).  Loaded once, at the first GPU call, with TUNING DISABLED: the file only maps GEMM shapes to
-# library solution ids — still "MFMA left to rocBLAS/hipBLASLt", and still deterministic (no timing at run time).
-# TunableOp validates the file against the installed PyTorch / HIP / rocBLAS / hipBLASLt versions and the GPU
-# architecture and ignores it on a mismatch, in which case the plain table applies; before the first use a child
-# process runs every tuned GEMM once (_selftest_tuned, ~10 s) and the file is only adopted if that process exits
-# cleanly.  DORPATCH_TUNABLEOP=0 disables.
+# default pick is poor).  The file only maps GEMM shapes to library solution ids — still "MFMA left to
+# rocBLAS/hipBLASLt", and still deterministic (TUNING DISABLED: no timing at run time).
+#
+# Life cycle (one verdict per process tree, one scope per generate()):
+#   activate(pg)   called by HotLoop.__init__: the first call decides the VERDICT — rank 0 runs every tuned GEMM once in a
+#                  child process, with the tuned solution and with the library default, and compares the two results
+#                  numerically (_selftest_tuned: max |tuned - default| <= 1e-4 of the result's scale per shape; a
+#                  solution id that faults costs the child, not the run); the verdict is broadcast, then every rank loads
+#                  the file (TunableOp validates it against the installed PyTorch / HIP / rocBLAS / hipBLASLt versions and
+#                  the GPU architecture) and the ranks agree on the AND of their results — so all replicas run the same
+#                  kernels.  It then switches TunableOp on (tuning off) and remembers the state it found.
+#   deactivate()   called by HotLoop.close(): TunableOp back to the state the caller had — GEMMs of the user's process
+#                  outside generate() (PatchCleanser, their own model) never see the file.
+# Between the two, batch sizes that have a tuned route column use it; outside, the plain columns and the libraries' default
+# solutions apply.  DORPATCH_TUNABLEOP=0 disables the whole mechanism.
 TUNABLEOP_FILE = os.path.join(_HERE, "tunableop_gfx950.csv")
 TUNABLEOP = os.environ.get("DORPATCH_TUNABLEOP", "1") != "0"
-_tuned_state = None      # None: not tried yet; True: solutions loaded; False: not in effect
+SELFTEST_RTOL = 1e-4     # per tuned GEMM: max |tuned - default| / max |default|
+_tuned_verdict = None    # None: undecided; True: file verified + loaded in this process; False: not usable here
+_tuned_scope = 0         # > 0: inside activate() ... deactivate()
+_tuned_prev = None       # TunableOp's (enabled, tuning) before the outermost activate()
+_selftest_report = None  # what the self-test measured (bench.py / last_run record it)
 
 
-_SELFTEST = r'''
-import sys, torch
+_SELFTEST = r"""
+import json, os, sys, torch
 import torch.cuda.tunable as tun
 sys.path.insert(0, sys.argv[2])
 from dorpatch_amd import conv1x1
+rtol = float(sys.argv[3])
 tun.enable(True); tun.tuning_enable(False); tun.record_untuned_enable(False)
 if not tun.read_file(sys.argv[1]):
-    sys.exit(3)
-import os
+    print(json.dumps({"ok": False, "why": "TunableOp rejected the file (validators)"})); sys.exit(3)
 torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
 dev = torch.device("cuda", torch.cuda.current_device())
-for n, table in sorted(conv1x1.TUNED.items()):
+gen = torch.Generator(device="cpu").manual_seed(0)
+worst, n, bad = 0.0, 0, []
+for batch, table in sorted(conv1x1.TUNED.items()):
     for (direction, C, O, HW), route in sorted(table.items()):
         if route != "gemm":
             continue
         H = int(round(HW ** 0.5))
-        w = torch.randn(O, C, 1, 1, device=dev)
-        t = torch.randn(n, C if direction == "fwd" else O, H, H, device=dev)
-        out = conv1x1._IMPL[(direction, "gemm")](t, w, None)
-        if not bool(torch.isfinite(out).all()):
-            sys.exit(4)
+        w = (torch.randn(O, C, 1, 1, generator=gen) / C ** 0.5).to(dev)
+        t = torch.randn(batch, C if direction == "fwd" else O, H, H, generator=gen).to(dev)
+        tun.enable(True)
+        got = conv1x1._IMPL[(direction, "gemm")](t, w, None)
+        tun.enable(False)
+        want = conv1x1._IMPL[(direction, "gemm")](t, w, None)
+        err = float((got - want).abs().max() / want.abs().max())
+        n += 1
+        if not (err <= rtol):          # NaN fails too
+            bad.append([batch, direction, C, O, HW, err])
+        worst = max(worst, err) if err == err else float("inf")
 torch.cuda.synchronize()
-'''
+print(json.dumps({"ok": not bad, "gemms": n, "max_rel_err": worst, "rtol": rtol, "bad": bad}))
+sys.exit(0 if not bad else 4)
+"""
 
 
 def _selftest_tuned():
-    """Run every GEMM of the tuned route columns once, with the tuned solutions, in a CHILD process: a solution id
-    that a particular box's BLAS build rejects (or that faults) then costs a disabled feature, not the run.  The
-    verdict is passed to child processes through DORPATCH_TUNABLEOP_VERIFIED."""
+    """Every GEMM of the tuned route columns, tuned solution vs library default, in a CHILD process (see above).
+    The verdict reaches child processes of this one through DORPATCH_TUNABLEOP_VERIFIED."""
+    global _selftest_report
     verdict = os.environ.get("DORPATCH_TUNABLEOP_VERIFIED")
     if verdict in ("0", "1"):
+        _selftest_report = _selftest_report or {"ok": verdict == "1", "inherited": True}
         return verdict == "1"
     import subprocess
     import sys
     env = dict(os.environ, DORPATCH_TUNABLEOP="0")          # the child loads the file explicitly
+    report = {"ok": False}
     try:
-        rc = subprocess.run([sys.executable, "-c", _SELFTEST, TUNABLEOP_FILE, os.path.dirname(_HERE)], env=env,
-                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180).returncode
-    except (OSError, subprocess.SubprocessError):
-        rc = -1
-    os.environ["DORPATCH_TUNABLEOP_VERIFIED"] = "1" if rc == 0 else "0"
-    return rc == 0
+        res = subprocess.run([sys.executable, "-c", _SELFTEST, TUNABLEOP_FILE, os.path.dirname(_HERE), repr(SELFTEST_RTOL)],
+                             env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, text=True)
+        lines = [l for l in res.stdout.strip().splitlines() if l.startswith("{")]
+        if lines:
+            report = json.loads(lines[-1])
+        report["returncode"] = res.returncode
+        ok = res.returncode == 0 and bool(report.get("ok"))
+    except (OSError, subprocess.SubprocessError, ValueError) as e:
+        ok = False
+        report = {"ok": False, "why": repr(e)}
+    _selftest_report = report
+    os.environ["DORPATCH_TUNABLEOP_VERIFIED"] = "1" if ok else "0"
+    return ok
+
+
+def _decide(pg):
+    """The once-per-process verdict; collective when ``pg`` is a process group (every rank must call it)."""
+    from . import dist as dp_dist
+    _, rank = dp_dist.world_rank(pg)
+    ok = False
+    if TUNABLEOP and os.path.exists(TUNABLEOP_FILE):
+        ok = _selftest_tuned() if rank == 0 else True
+    ok = bool(dp_dist.broadcast_object(ok, pg))             # rank 0's verdict
+    if ok:
+        try:
+            import torch.cuda.tunable as tun
+            was = (tun.is_enabled(), tun.tuning_is_enabled())
+            tun.enable(True)
+            tun.tuning_enable(False)
+            tun.record_untuned_enable(False)
+            ok = bool(tun.read_file(TUNABLEOP_FILE))
+            tun.enable(was[0])
+            tun.tuning_enable(was[1])
+        except Exception:            # noqa: BLE001 - any refusal simply leaves the default solutions in place
+            ok = False
+    return dp_dist.all_true(ok, pg)                          # one rank's refusal is every rank's
+
+
+def activate(pg=None, device_is_cuda=True):
+    """Enter a tuned-solution scope (see the life-cycle note above); -> whether the tuned solutions are in effect."""
+    global _tuned_verdict, _tuned_scope, _tuned_prev
+    if not device_is_cuda:
+        return False
+    if _tuned_verdict is None:
+        _tuned_verdict = _decide(pg)
+    if not _tuned_verdict:
+        return False
+    import torch.cuda.tunable as tun
+    if _tuned_scope == 0:
+        _tuned_prev = (tun.is_enabled(), tun.tuning_is_enabled())
+        tun.enable(True)
+        tun.tuning_enable(False)
+    _tuned_scope += 1
+    return True
+
+
+def deactivate():
+    """Leave the scope opened by the matching ``activate`` that returned True."""
+    global _tuned_scope, _tuned_prev
+    if _tuned_scope == 0:
+        return
+    _tuned_scope -= 1
+    if _tuned_scope == 0 and _tuned_prev is not None:
+        import torch.cuda.tunable as tun
+        tun.enable(_tuned_prev[0])
+        tun.tuning_enable(_tuned_prev[1])
+        _tuned_prev = None
 
 
 def tuned_gemms_active(device_is_cuda=True):
-    """Load the tuned-solution file on first use (GPU only); -> whether it is in effect."""
-    global _tuned_state
-    if _tuned_state is None and device_is_cuda:
-        _tuned_state = False
-        if TUNABLEOP and os.path.exists(TUNABLEOP_FILE) and _selftest_tuned():
-            try:
-                import torch.cuda.tunable as tun
-                tun.enable(True)
-                tun.tuning_enable(False)
-                tun.record_untuned_enable(False)
-                _tuned_state = bool(tun.read_file(TUNABLEOP_FILE))
-                if not _tuned_state:
-                    tun.enable(False)
-            except Exception:            # noqa: BLE001 - any refusal simply leaves the default solutions in place
-                _tuned_state = False
-    return bool(_tuned_state)
+    """Are the tuned solutions (and therefore the tuned route columns) in effect right now?  Pure query."""
+    return bool(device_is_cuda and _tuned_scope > 0 and _tuned_verdict)
 
 
 def _fwd_gemm(x, w4d, _=None):
@@ -149,7 +221,8 @@ def _fwd_gemm(x, w4d, _=None):
 
 
 def _fwd_miopen(x, w4d, _=None):
-    return F.conv2d(x, w4d)
+    from . import libconv
+    return libconv.conv_fwd(x, w4d)
 
 
 def _bwd_gemm(dy, w4d, x=None):
@@ -161,8 +234,8 @@ def _bwd_gemm(dy, w4d, x=None):
 def _bwd_miopen(dy, w4d, x):
     # exactly the call autograd makes for F.conv2d (input gradient only); `x` is passed for its shape —
     # MIOpen's backward-data never reads it, but ATen wants a dense tensor there
-    return torch.ops.aten.convolution_backward(dy, x, w4d, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1,
-                                               (True, False, False))[0]
+    from . import libconv
+    return libconv.conv_bwd_data(dy, x, w4d)
 
 
 _IMPL = {("fwd", "gemm"): _fwd_gemm, ("fwd", "miopen"): _fwd_miopen,
@@ -225,7 +298,19 @@ def _pick(direction, t, w4d, x):
 
 
 def _run(direction, t, w4d, x=None):
-    return _IMPL[(direction, _pick(direction, t, w4d, x))](t, w4d, x)
+    algo = _pick(direction, t, w4d, x)
+    if algo == "gemm":
+        from . import libconv
+        if libconv.MODE == "auto":
+            # a BLAS solution that accumulates with atomics (split-K / stream-K) would not be reproducible either:
+            # probed like the MIOpen problems; the forced alternative is MIOpen's deterministic kernel
+            key = ("gemm-" + direction, int(t.shape[0]), int(w4d.shape[1]), int(w4d.shape[0]), 1, 1, int(t.shape[2]),
+                   int(t.shape[3]))
+            if direction == "bwd" and x is None:
+                x = torch.empty((t.shape[0], w4d.shape[1]) + tuple(t.shape[2:]), dtype=t.dtype, device=t.device)
+            return libconv.guard(key, lambda: _IMPL[(direction, "gemm")](t, w4d, x),
+                                 lambda: _IMPL[(direction, "miopen")](t, w4d, x))
+    return _IMPL[(direction, algo)](t, w4d, x)
 
 
 class Conv1x1Function(torch.autograd.Function):
@@ -266,7 +351,12 @@ def share_choices(pg):
 
 
 def report_tuned():
-    return "tuned GEMM solutions active (tunableop_gfx950.csv)" if _tuned_state else "library default GEMM solutions"
+    """What generate() runs with in this process (the verdict of ``activate``), for bench.py / last_run."""
+    return "tuned GEMM solutions active (tunableop_gfx950.csv)" if _tuned_verdict else "library default GEMM solutions"
+
+
+def selftest_report():
+    return _selftest_report
 
 
 def report():

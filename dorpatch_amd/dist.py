@@ -59,6 +59,16 @@ def broadcast_object(obj, pg):
     return box[0]
 
 
+def all_true(flag, pg):
+    """AND of a bool over the ranks (setup only: feature agreement, never on the data path)."""
+    if pg is None:
+        return bool(flag)
+    import torch.distributed as dist
+    votes = [None] * dist.get_world_size(pg)
+    dist.all_gather_object(votes, bool(flag), group=pg)
+    return all(votes)
+
+
 def allreduce_sum_(t, pg):
     """In-place sum over ranks of the patch gradient (+ loss slabs) — THE data-path collective."""
     if pg is not None:

@@ -1,0 +1,113 @@
+"""Library (MIOpen) convolution calls of the frozen backbone, with PER-LAYER run-to-run determinism.
+
+Why.  The optimiser takes ``sign(grad)`` (``attack.py:336-340``): two runs from identical seeds stay together only if
+every kernel of the step is bit-reproducible.  The HIP kernels of this repo are (fixed-order reductions, no float
+atomics); MIOpen's immediate mode, however, picks split-K implicit-GEMM kernels that accumulate with float atomics for
+SOME (shape, batch) combinations — at 8 samples 5 of ResNetV2-50's 23 convolution shapes, forward and/or backward-data,
+at 512 samples none (``profiles/r02c_determinism_probe.jsonl``).  ``torch.backends.cudnn.deterministic = True`` for the
+whole run fixes that but bans MIOpen's whole NHWC implicit-GEMM family, also where it was deterministic anyway: 7.8 % at
+the reference's own problem size (1 image x 128 masks: 29.98 vs 27.82 ms/step, ``profiles/r02w_final_tree_runs.json``).
+
+So the decision is taken per (direction, batch, shape): the first time a convolution problem is seen under
+``MODE == "auto"`` it is executed three times on its real operands; if any bit differs, that problem — and only that
+problem — runs with deterministic library kernels from then on (the global flag is flipped around that one call).
+The reference sets ``cudnn.benchmark = True`` (``utils.py:17``) and is not reproducible on a GPU at all.
+
+``POLICY`` is process-global (a MIOpen property of the box, not of a run); ``merge_across(pg)`` ORs it over the ranks of
+a process group so every replica forces the same problems.
+"""
+import contextlib
+
+import torch
+import torch.nn.functional as F
+
+MODE = "off"        # "off": call the library as is;  "auto": probe each new problem once, force the non-reproducible ones
+POLICY = {}         # (direction, N, C, O, k, stride, H, W) -> True (force deterministic kernels) | False (reproducible as is)
+PROBE_RUNS = 3
+
+
+@contextlib.contextmanager
+def _forced():
+    was = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        yield
+    finally:
+        torch.backends.cudnn.deterministic = was
+
+
+def guard(key, fn, forced_fn=None):
+    """Run ``fn()`` under the policy of problem ``key``.  ``forced_fn`` (default: ``fn`` itself under the deterministic
+    flag) is what runs when the problem turned out not to be reproducible."""
+    if MODE != "auto" or torch.backends.cudnn.deterministic:
+        return fn()
+    force = POLICY.get(key)
+    if force is None:
+        outs = [fn() for _ in range(PROBE_RUNS)]
+        force = POLICY[key] = not all(torch.equal(outs[0], o) for o in outs[1:])      # host sync: once per problem
+        if not force:
+            return outs[-1]
+    if not force:
+        return fn()
+    with _forced():
+        return (forced_fn or fn)()
+
+
+def _key(direction, n, w, stride, hw_in):
+    return (direction, int(n), int(w.shape[1]), int(w.shape[0]), int(w.shape[2]), int(stride[0]), int(hw_in[0]),
+            int(hw_in[1]))
+
+
+def conv_fwd(x, w, stride=(1, 1), padding=(0, 0)):
+    """``F.conv2d(x, w, None, stride, padding)`` for a frozen filter."""
+    if MODE != "auto":
+        return F.conv2d(x, w, None, stride, padding)
+    return guard(_key("fwd", x.shape[0], w, stride, x.shape[2:]), lambda: F.conv2d(x, w, None, stride, padding))
+
+
+def conv_bwd_data(dy, x_ref, w, stride=(1, 1), padding=(0, 0)):
+    """Input gradient of the same convolution — exactly the call autograd makes (``x_ref`` is passed for its shape:
+    MIOpen's backward-data never reads it, but ATen wants a dense tensor there)."""
+    def call():
+        return torch.ops.aten.convolution_backward(dy, x_ref, w, None, tuple(stride), tuple(padding), (1, 1), False,
+                                                   (0, 0), 1, (True, False, False))[0]
+    if MODE != "auto":
+        return call()
+    return guard(_key("bwd", dy.shape[0], w, stride, x_ref.shape[2:]), call)
+
+
+class FrozenConvFunction(torch.autograd.Function):
+    """``conv2d`` with a frozen filter as an autograd node whose two library calls go through the policy above
+    (plain autograd would make the same two calls, but outside this module's reach)."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, padding):
+        x = x.contiguous()
+        ctx.save_for_backward(x, w)          # x: a shape reference for backward-data, never re-read
+        ctx.geometry = (tuple(stride), tuple(padding))
+        return conv_fwd(x, w, stride, padding)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, padding = ctx.geometry
+        return conv_bwd_data(dy.contiguous(), x, w, stride, padding), None, None, None
+
+
+def summary():
+    """{"problems": n probed, "forced": m, "forced_list": [...]}: what ``deterministic="auto"`` decided so far."""
+    forced = sorted(k for k, v in POLICY.items() if v)
+    return {"problems": len(POLICY), "forced": len(forced), "forced_list": [list(k) for k in forced]}
+
+
+def merge_across(pg):
+    """OR the per-problem decisions over the ranks of ``pg`` (collective; call where every rank has seen the same
+    problems — the all-samples autograd path — never from the rank-local selected-sample backward)."""
+    if pg is None:
+        return
+    import torch.distributed as dist
+    boxes = [None] * dist.get_world_size(pg)
+    dist.all_gather_object(boxes, {k: v for k, v in POLICY.items()}, group=pg)
+    for other in boxes:
+        for k, v in other.items():
+            POLICY[k] = bool(POLICY.get(k, False) or v)

@@ -50,6 +50,9 @@ class StdConv2d(nn.Conv2d):
             from . import conv1x1
             if conv1x1.applicable(self, x):      # frozen 1x1/1 on the GPU: MIOpen or a batched GEMM, whichever measured faster
                 return conv1x1.Conv1x1Function.apply(x, self.weight)
+            if not self.weight.requires_grad:    # frozen: the library call goes through the per-layer determinism policy
+                from . import libconv
+                return libconv.FrozenConvFunction.apply(x, self.weight, self.stride, self.padding)
         w = self.weight if self.folded else self.standardized_weight()
         return F.conv2d(x, w, None, self.stride, self.padding)
 

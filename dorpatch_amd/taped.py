@@ -18,9 +18,8 @@ losses; ``attack.HotLoop`` decides which samples carry gradient.
 """
 import numpy as np
 import torch
-import torch.nn.functional as F
 
-from . import conv1x1, ops
+from . import conv1x1, libconv, ops
 from .resnetv2 import GroupNormAct, ResNetV2, StdConv2d
 
 MAX_TABS = 8          # kGnMaxTabs of dp_gn_relu_bwd_gather
@@ -108,7 +107,7 @@ def _conv_fwd(tape, conv, x):
     tape.conv_route[id(conv)] = routed
     if routed:
         return conv1x1._run("fwd", x, conv.weight)
-    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+    return libconv.conv_fwd(x, conv.weight, conv.stride, conv.padding)
 
 
 @torch.no_grad()
@@ -120,7 +119,7 @@ def forward(net, x, tape, z=None):
     _need(k == 0 or tape.rows[-1] == tape.tab_rows, "only the last tab of a tape may be short")
     stem = net.stem.conv
     if z is None:
-        z = F.conv2d(x, stem.weight, None, stem.stride, stem.padding)
+        z = libconv.conv_fwd(x, stem.weight, stem.stride, stem.padding)
     n = z.shape[0]
     _need(n <= tape.tab_rows, "micro-batch larger than the tape's tab")
     _need(ops.pad_maxpool_supported(z), "stem pooling shape %s" % (tuple(z.shape),))
@@ -178,8 +177,7 @@ def _conv_bwd(tape, conv, dy, refs):
     ref = refs.get((dy.shape[0],) + tape.conv_in[id(conv)])
     if tape.conv_route[id(conv)]:
         return conv1x1._run("bwd", dy, conv.weight, ref)
-    return torch.ops.aten.convolution_backward(dy, ref, conv.weight, None, conv.stride, conv.padding, (1, 1), False,
-                                               (0, 0), 1, (True, False, False))[0]
+    return libconv.conv_bwd_data(dy, ref, conv.weight, conv.stride, conv.padding)
 
 
 @torch.no_grad()

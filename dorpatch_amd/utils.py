@@ -100,24 +100,12 @@ def get_model(dataset_name, model_name, model_dir='pretrained_models'):
 
 
 def get_dataset(dataset_name, data_dir='/home/data', train=False, batch_size=128, shuffle=True):
-    """reference utils.py:81-102 (Resize 256 -> CenterCrop 224 -> ToTensor).  Needs torchvision."""
-    try:
-        import torchvision.transforms as transforms
-        from torchvision import datasets
-    except ImportError as e:  # pragma: no cover - torchvision is absent offline
-        raise ImportError("get_dataset needs torchvision (not installed in this image); "
-                          "feed DorPatch.generate your own (B,3,H,W) tensors instead") from e
-    ctors = {'cifar10': datasets.CIFAR10, 'cifar100': datasets.CIFAR100, 'imagenet': datasets.ImageNet}
-    extra = {'cifar10': {'train': train, 'download': True}, 'cifar100': {'train': train, 'download': True},
-             'imagenet': {'split': 'train' if train else 'val'}}
-    size = 224
-    tf = transforms.Compose([transforms.Resize(int(size / 0.875)), transforms.CenterCrop((size, size)),
-                             transforms.ToTensor()])
-    dataset = ctors[dataset_name](root=os.path.join(data_dir, dataset_name), transform=tf,
-                                  **extra[dataset_name])
-    print('Dataset has {} instances'.format(len(dataset)))
-    return torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=shuffle,
-                                       num_workers=1, pin_memory=True)
+    """Name kept because the reference's ``main.py:1`` star-imports it (``utils.py:81-102``).  Dataset acquisition is
+    outside the accelerated path (OUT OF SCOPE) and is not restated here: build the loader with the
+    reference's own ``utils.get_dataset`` (torchvision) and hand ``DorPatch.generate`` its (B,3,H,W) batches, or run the
+    driver with ``--synthetic``."""
+    raise NotImplementedError("dorpatch_amd does not restate dataset loading (reference utils.py:81-102, out of scope): "
+                              "use the reference's get_dataset / your own DataLoader, or `main.py --synthetic`")
 
 
 def clip(mask, pattern, x, eps):

@@ -7,8 +7,9 @@ used exactly the way the reference uses it, what ``/root/reference`` computes on
 the hot path; every function cites the reference lines it follows.  It is pinned
 against the committed ``tests/golden/*.npz`` fixtures, which ``oracle/gen_golden.py``
 records by executing the *unmodified* reference through ``oracle/ref_shim.py`` in the build
-container (``tests/test_oracle_golden.py``, ``tests/test_patchcleanser_oracle.py``,
-``tests/test_end_metric_golden.py``).
+container (``tests/test_oracle_golden.py``, ``tests/test_patchcleanser_oracle.py``; the end-metric fixtures are
+consumed by ``tests/test_end_metric_gpu.py`` / ``tests/test_end_metric_emu.py``), and, in the build container, checked
+bit for bit against the unmodified reference executed in place (``tests/test_vs_live_reference.py``).
 
 Parity status: pinned for everything below; the timm backbone is opaque to this
 path (any ``nn.Module``) and is unpinned (see oracle/__init__.py).

@@ -128,16 +128,60 @@ def test_tuned_gemm_solution_file_and_its_route_table():
     assert batches == set(conv1x1.TUNED) and 512 in batches          # one route column per tuned GEMM batch
     assert set(conv1x1.PLAIN) == set(conv1x1.TUNED)
     if not torch.cuda.is_available():
+        assert conv1x1.activate(None, device_is_cuda=False) is False       # nothing is loaded without a GPU
         assert conv1x1.tuned_gemms_active(False) is False and "default" in conv1x1.report_tuned()
 
 
+def test_tuned_scope_is_a_query_outside_activate(monkeypatch):
+    """the tuned solutions are in effect only between activate() and deactivate(); the verdict is taken once
+    per process, rank 0's self-test is what every rank adopts, and a refusal on any rank is every rank's."""
+    import dorpatch_amd.dist as dp_dist
+
+    class FakeTun(object):
+        def __init__(self):
+            self.enabled, self.tuning, self.calls = False, True, []
+        def is_enabled(self): return self.enabled
+        def tuning_is_enabled(self): return self.tuning
+        def enable(self, v): self.enabled = bool(v); self.calls.append(("enable", bool(v)))
+        def tuning_enable(self, v): self.tuning = bool(v)
+        def record_untuned_enable(self, v): pass
+        def read_file(self, path): self.calls.append(("read", path)); return True
+    fake = FakeTun()
+    monkeypatch.setattr(torch.cuda, "tunable", fake, raising=False)
+    import sys
+    monkeypatch.setitem(sys.modules, "torch.cuda.tunable", fake)
+    monkeypatch.setattr(conv1x1, "_tuned_verdict", None)
+    monkeypatch.setattr(conv1x1, "_tuned_scope", 0)
+    monkeypatch.setattr(conv1x1, "_tuned_prev", None)
+    ran = []
+    monkeypatch.setattr(conv1x1, "_selftest_tuned", lambda: ran.append(1) or True)
+    monkeypatch.setattr(dp_dist, "all_true", lambda flag, pg: bool(flag))
+    assert not conv1x1.tuned_gemms_active(True)
+    assert conv1x1.activate(None, True) is True and ran == [1]
+    assert conv1x1.tuned_gemms_active(True) and fake.enabled and not fake.tuning
+    assert conv1x1.activate(None, True) is True and ran == [1]            # nested scope, no second self-test
+    conv1x1.deactivate()
+    assert conv1x1.tuned_gemms_active(True) and fake.enabled
+    conv1x1.deactivate()
+    assert not conv1x1.tuned_gemms_active(True) and not fake.enabled and fake.tuning     # the caller's state is back
+    assert "tuned" in conv1x1.report_tuned()
+    # one rank's refusal is every rank's
+    monkeypatch.setattr(conv1x1, "_tuned_verdict", None)
+    monkeypatch.setattr(dp_dist, "all_true", lambda flag, pg: False)
+    assert conv1x1.activate(None, True) is False and not conv1x1.tuned_gemms_active(True) and not fake.enabled
+
+
 @pytest.mark.gpu
-def test_tuned_gemm_solutions_load_on_the_gpu_box_and_compute_the_same_convolution():
+def test_tuned_gemm_solutions_load_on_the_gpu_box_and_compute_the_same_convolution(request):
     conv1x1.MODE = "table"
-    if not (conv1x1.TUNABLEOP and conv1x1.tuned_gemms_active(True)):
+    if not (conv1x1.TUNABLEOP and conv1x1.activate(None, True)):
         # a different PyTorch / rocBLAS / hipBLASLt build or GPU stepping: TunableOp ignores the file and the library
         # defaults + the plain route column apply — slower (433 vs 409 ms/step), not wrong
-        pytest.skip("tunableop_gfx950.csv was rejected by TunableOp's validators on this box")
+        pytest.skip("tunableop_gfx950.csv was rejected by TunableOp's validators on this box: %r" % (conv1x1.selftest_report(),))
+    rep = conv1x1.selftest_report()
+    if rep and not rep.get("inherited"):          # the numeric self-test ran in this process tree: every tuned GEMM vs default
+        assert rep["ok"] and rep["gemms"] >= 20 and rep["max_rel_err"] <= conv1x1.SELFTEST_RTOL, rep
+    request.addfinalizer(conv1x1.deactivate)
     g = torch.Generator().manual_seed(0)
     x = torch.randn(512, 64, 56, 56, generator=g).cuda()
     w = (torch.randn(64, 64, 1, 1, generator=g) / 8).cuda()

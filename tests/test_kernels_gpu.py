@@ -360,10 +360,13 @@ def test_gn_relu_autograd_function_in_module():
 
 
 def test_resnetv2_fused_equals_unfused():
-    """Whole frozen ResNetV2-50x1-BiT: logits and input gradient with the fused GN+ReLU kernels
-    vs the eager composition (same MIOpen convolutions either way)."""
-    from dorpatch_amd.resnetv2 import GroupNormAct, resnetv2_50x1_bit, seeded_init_
-    net = seeded_init_(resnetv2_50x1_bit(1000)).fold_weight_standardization().freeze().to(DEV)
+    """Whole frozen ResNetV2-50x1-BiT: logits and input gradient with the fused GN+ReLU / pooling / stem kernels vs the
+    eager composition (same library convolutions either way), on the WELL-CONDITIONED seeded weights
+    (resnetv2.seeded_init_: ReLU gate flips under re-ordered fp32 sums are rare), so the bound is tight — 1e-4 of the
+    scale with at most 0.1 % of the elements beyond it (one flipped gate).  The fp64-oracle statement of the same
+    network is tests/test_backbone_parity_gpu.py; this one isolates the hand-written backbone kernels."""
+    from dorpatch_amd.resnetv2 import WELL_CONDITIONED_GN_BIAS, GroupNormAct, resnetv2_50x1_bit, seeded_init_
+    net = seeded_init_(resnetv2_50x1_bit(1000), gn_bias=WELL_CONDITIONED_GN_BIAS).fold_weight_standardization().freeze().to(DEV)
     n, side = (4, 224) if DEV != "cpu" else (2, 96)     # the CPU emulation re-runs this test on a smaller problem
     x = torch.rand(n, 3, side, side, generator=torch.Generator().manual_seed(2)).to(DEV) * 2 - 1
     dl = torch.randn(n, 1000, generator=torch.Generator().manual_seed(3)).to(DEV)
@@ -374,14 +377,13 @@ def test_resnetv2_fused_equals_unfused():
             xi = x.clone().requires_grad_(True)
             lg = net(xi)
             (gx,) = torch.autograd.grad(lg, xi, dl)
-            outs.append((lg.detach().cpu().numpy(), gx.cpu().numpy()))
+            outs.append((lg.detach().cpu().numpy().astype(np.float64), gx.cpu().numpy().astype(np.float64)))
         finally:
             GroupNormAct.fused = True
-    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-3, atol=1e-4)
-    a, b = outs[0][1].astype(np.float64), outs[1][1].astype(np.float64)
-    # fp32 noise floor of this random-weight net is ~1e-2 rel-L2: ReLU gates flip
-    assert np.linalg.norm(a - b) / np.linalg.norm(b) < 5e-2
-    assert (a * b).sum() / np.linalg.norm(a) / np.linalg.norm(b) > 0.998
+    for got, want in zip(outs[0], outs[1]):
+        err = np.abs(got - want) / np.abs(want).max()
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 5e-4 and (err > 1e-4).mean() <= 1e-3, \
+            (np.linalg.norm(got - want) / np.linalg.norm(want), err.max(), (err > 1e-4).mean())
 
 
 @pytest.mark.parametrize("shape", [(2, 256, 56, 56), (3, 512, 28, 28), (2, 2048, 7, 7), (1, 256, 96, 96)])
