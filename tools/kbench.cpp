@@ -298,6 +298,44 @@ int main(int argc, char **argv) {
       if (ns > 1) DP(dp_sum_slabs(sl, ns, (int64_t)Bm * 3 * P, g_adv, 0, st));
     });
   }
+  // ---- EXTENSION: per-sample affine placement fused with the occlusion apply (dorpatch_amd/placement.py RandomAffine
+  // defaults: rotation +-10 deg, scale 0.9..1.1, translation +-8 px about the image centre; theta = output -> source)
+  if (!g_filter || strstr(g_filter, "affine")) {
+    std::vector<float> th((size_t)N * 6), thi((size_t)N * 6);
+    std::uniform_real_distribution<double> Ur(-10.0, 10.0), Us(0.9, 1.1), Ut(-8.0, 8.0);
+    const double cx = (W - 1) / 2.0, cy = (H - 1) / 2.0;
+    for (int n = 0; n < N; ++n) {
+      const double rot = Ur(rng) * M_PI / 180.0, sc = Us(rng), tx = Ut(rng), ty = Ut(rng);
+      const double c = std::cos(rot) / sc, s_ = std::sin(rot) / sc;
+      const double a00 = c, a01 = s_, a10 = -s_, a11 = c;
+      const double t0 = cx - (a00 * (cx + tx) + a01 * (cy + ty)), t1 = cy - (a10 * (cx + tx) + a11 * (cy + ty));
+      const double det = a00 * a11 - a01 * a10;
+      const double i00 = a11 / det, i01 = -a01 / det, i10 = -a10 / det, i11 = a00 / det;
+      float *t = &th[(size_t)n * 6], *ti = &thi[(size_t)n * 6];
+      t[0] = (float)a00; t[1] = (float)a01; t[2] = (float)t0; t[3] = (float)a10; t[4] = (float)a11; t[5] = (float)t1;
+      ti[0] = (float)i00; ti[1] = (float)i01; ti[2] = (float)-(i00 * t0 + i01 * t1);
+      ti[3] = (float)i10; ti[4] = (float)i11; ti[5] = (float)-(i10 * t0 + i11 * t1);
+    }
+    float *d_th = (float *)dmalloc(th.size() * 4), *d_thi = (float *)dmalloc(thi.size() * 4);
+    CK(hipMemcpy(d_th, th.data(), th.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_thi, thi.data(), thi.size() * 4, hipMemcpyHostToDevice));
+    // algorithmic bytes: the same 3*P*4 B per EOT sample as the identity-placement kernels (+ x and delta / + the result once)
+    bench("dp_apply_affine_fwd", out_bytes + 2.0 * B * img, iters, st, [&] {
+      DP(dp_apply_affine_fwd(x, g_adv, d_th, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, big, st));
+    });
+    bench("dp_apply_affine_bwd (+dp_sum_slabs)", out_bytes + (double)B * img, iters, st, [&] {
+      DP(dp_apply_affine_bwd(big2, d_th, d_thi, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, nslab == 1 ? g_adv : slabs, st));
+      if (nslab > 1) DP(dp_sum_slabs(slabs, nslab, (int64_t)B * 3 * P, g_adv, 0, st));
+    });
+    {  // the shape HotLoop uses per micro-batch: 8 images x 32 masks
+      const int Bm = std::min(B, 8), ns = dp_apply_bwd_nslab(Bm, S, P);
+      float *sl = (float *)dmalloc((size_t)ns * Bm * img);
+      bench("dp_apply_affine_bwd micro-batch 8x32", (double)Bm * S * img + (double)Bm * img, iters, st, [&] {
+        DP(dp_apply_affine_bwd(big2, d_th, d_thi, d_table, 2, d_idx, nullptr, S, Bm, S, H, W, &norm, ns == 1 ? g_adv : sl, st));
+        if (ns > 1) DP(dp_sum_slabs(sl, ns, (int64_t)Bm * 3 * P, g_adv, 0, st));
+      });
+    }
+  }
   // ---- a-7
   bench("dp_cw_loss (+grad, pred)", (double)N * C * 8, iters, st,
         [&] { DP(dp_cw_loss(logits, y, tflag, N, C, S, 0.1f, 1.f / S, loss, dlogits, pred, st)); });
@@ -321,7 +359,7 @@ int main(int argc, char **argv) {
           });
   }
   // ---- a-8: backbone element-wise kernels at the training micro-batch (256 samples)
-  if (H == 224 && (!g_filter || strstr(g_filter, "gn_relu") || strstr(g_filter, "maxpool") || strstr(g_filter, "stem"))) {
+  if (H == 224 && (!g_filter || strstr(g_filter, "gn_relu") || strstr(g_filter, "maxpool") || strstr(g_filter, "stem") || strstr(g_filter, "pool"))) {
     const int Nb = 256;
     struct Shape { int C, HW; const char *what; };
     const Shape shapes[] = {{64, 3136, "64ch@56x56"}, {256, 3136, "256ch@56x56"}, {512, 784, "512ch@28x28"},
@@ -385,6 +423,30 @@ int main(int argc, char **argv) {
           [&] { DP(dp_pad_maxpool_fwd(gx, NC, 112, 112, gy, code, st)); });
     bench("dp_pad_maxpool_bwd 256x64x112x112", pe * 5.25, iters, st,
           [&] { DP(dp_pad_maxpool_bwd(gy, code, NC, 112, 112, gs, st)); });
+    {  // in-situ conditions (3.6 TB/s in every step trace vs 5.8 here): the 512-sample micro-batch of the
+       // headline configuration (dy + codes = 514 MB: past the 256 MiB Infinity Cache), random dy, codes from random x
+      const int Nc = 512;
+      const int64_t NC5 = (int64_t)Nc * 64;
+      const size_t e_in = (size_t)NC5 * 112 * 112, e_out = (size_t)NC5 * 56 * 56;
+      float *px = (float *)dmalloc(e_in * 4), *pdx = (float *)dmalloc(e_in * 4);
+      float *py = (float *)dmalloc(e_out * 4), *pdy = (float *)dmalloc(e_out * 4);
+      uint8_t *pcode = (uint8_t *)dmalloc(e_out);
+      {
+        std::vector<float> h(1 << 22);
+        std::normal_distribution<float> Nrm(0.f, 1.f);
+        for (auto &v : h) v = Nrm(rng);
+        for (size_t off = 0; off < e_in; off += h.size())
+          CK(hipMemcpy(px + off, h.data(), std::min(h.size(), e_in - off) * 4, hipMemcpyHostToDevice));
+        for (size_t off = 0; off < e_out; off += h.size() - 4099)      // a different phase per block
+          CK(hipMemcpy(pdy + off, h.data() + (off / 977) % 4099, std::min(h.size() - 4099, e_out - off) * 4, hipMemcpyHostToDevice));
+      }
+      const double pe5 = (double)e_in;
+      bench("dp_pad_maxpool_fwd 512x64x112x112 rnd", pe5 * 5.25, iters, st,
+            [&] { DP(dp_pad_maxpool_fwd(px, NC5, 112, 112, py, pcode, st)); });
+      bench("dp_pad_maxpool_bwd 512x64x112x112 rnd", pe5 * 5.25, iters, st,
+            [&] { DP(dp_pad_maxpool_bwd(pdy, pcode, NC5, 112, 112, pdx, st)); });
+      CK(hipFree(px)); CK(hipFree(pdx)); CK(hipFree(py)); CK(hipFree(pdy)); CK(hipFree(pcode));
+    }
     float *wst = (float *)dmalloc(64 * 147 * 4);
     hipLaunchKernelGGL(k_fill, dim3(8), dim3(256), 0, st, (f4 *)wst, 64 * 147 / 4, 0.01f);
     {  // fused stem dgrad + occlusion-masked S-reduction: 8 images x 32 samples
