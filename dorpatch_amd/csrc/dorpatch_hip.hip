@@ -29,6 +29,14 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBlock = 256;  // threads per workgroup: 4 waves of 64
 
+// Register-allocation hint: the compiler must forget what it knows about a lane-private value (so that it re-derives
+// addresses / predicates from it instead of keeping dozens of them alive).  No semantics; empty in the host emulation.
+#ifdef HIPEMU_HOST
+#define DP_LAUNDER(v) ((void)0)
+#else
+#define DP_LAUNDER(v) asm volatile("" : "+v"(v))
+#endif
+
 #define DP_REQUIRE(cond)                                \
   do {                                                  \
     if (!(cond)) return (int)hipErrorInvalidValue;      \
@@ -1169,6 +1177,127 @@ __global__ __launch_bounds__(T, MW) void k_gn_relu_bwd(GnArgs A, const float *__
   }
 }
 
+// Backward for the large groups of 384 x 384 inputs: V = 9 (36 864 floats: 512 ch @ 48 x 48, 128 ch @ 96 x 96) and
+// V = 18 float4 per thread x 1024 threads (73 728 floats: 256 ch @ 96 x 96).  At V = 18, x and dy together are 590 KB —
+// more than a workgroup's registers (1024 threads x 128 VGPRs = 512 KB) — so the CU's two on-chip memories are used
+// together.  Per thread, of the V float4 of each operand:
+//   * dh = dy * gate * a (what both phases need) always stays in REGISTERS (V float4);
+//   * xh of the first XR float4 stays in registers, of the next XL float4 goes to LDS (XL * 16 KB of the CU's 160 KB;
+//     one float4 per lane per slot: conflict-free, own slots only: no barrier);
+//   * the remaining V - XR - XL float4 of x are re-read after the reductions (this workgroup's own lines: L2 / MALL).
+// V = 9: XR = 9 (everything on chip, 12 B/elem of HBM traffic).  V = 18: XR = 0, XL = 9: 12 B/elem + the re-read half of
+// x, vs 20 B/elem for the streaming kernel (x and dy twice).  Loads are issued in batches of BT float4 per operand, all
+// of a batch before the first use of any of it; addresses are (uniform base + 32-bit lane offset) so that an in-flight
+// load costs one address VGPR, not two — with 1024 threads the budget is 128 VGPRs and dh alone takes 72 at V = 18.
+// Two things keep hipcc from spilling (1000 B per lane without them): the per-float4 channel test is compile-time
+// (HW % 4 == 0 is required; the launcher sends other shapes to the streaming kernel) — a run-time branch per unrolled
+// element splits the kernel into ~70 basic blocks and the allocator gives up —, and every batch re-derives its lane index
+// from a laundered copy, so the 36 clamped offsets / predicates are not all kept alive from the first load to the last store.
+constexpr int kGnBigT = 1024;
+
+template <bool NT>
+__device__ __forceinline__ f4 ld4_at(const float *base, uint32_t elem4) {
+  const f4 *p = reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(base) + (size_t)(elem4 * 16u));
+  return ld4<NT>(p);
+}
+
+template <int V, int XR, int XL, int BT>
+__global__ __launch_bounds__(kGnBigT, 1) void k_gn_relu_bwd_big(GnArgs A, const float *__restrict__ dy,
+                                                                const float *__restrict__ mean_in,
+                                                                const float *__restrict__ rstd_in,
+                                                                float *__restrict__ dx) {
+  constexpr int T = kGnBigT;
+  static_assert(V % BT == 0 && XR % BT == 0 && XL % BT == 0 && XR + XL <= V, "batches must not straddle the placements");
+  __shared__ float sm1[T / 64], sm2[T / 64];
+  __shared__ float s_gb[2 * kGnLdsCh];
+  __shared__ f4 s_xh[XL > 0 ? XL * T : 1];
+  const int ng = blockIdx.x;
+  const int G = A.C / A.Cg;
+  const int cbase = (ng % G) * A.Cg;
+  const int L = A.Cg * A.HW, L4 = L >> 2;
+  const GnSource src = gn_source(A, ng, (size_t)L);
+  const float *xb = src.x;
+  const float *gb = dy + (size_t)ng * L;
+  f4 *o4 = reinterpret_cast<f4 *>(dx + (size_t)ng * L);
+  if ((int)threadIdx.x < A.Cg) {
+    s_gb[threadIdx.x] = A.gamma[cbase + threadIdx.x];
+    s_gb[kGnLdsCh + threadIdx.x] = A.beta[cbase + threadIdx.x];
+  }
+  __syncthreads();
+  const float *ga = s_gb, *be = s_gb + kGnLdsCh;
+  const float mean = mean_in[src.stat], rstd = rstd_in[src.stat];
+  constexpr bool uniform = true;   // the launcher sends HW % 4 != 0 to the streaming kernel
+  f4 dh[V];
+  f4 xk[XR > 0 ? XR : 1];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k0 = 0; k0 < V; k0 += BT) {
+    f4 xr[BT];
+    int tid = threadIdx.x;
+    DP_LAUNDER(tid);
+#pragma unroll
+    for (int c = 0; c < BT; ++c) {
+      const int i = tid + (k0 + c) * T;
+      const uint32_t ic = i < L4 ? (uint32_t)i : 0u;
+      xr[c] = ld4_at<true>(xb, ic);
+      dh[k0 + c] = ld4_at<true>(gb, ic);
+    }
+#pragma unroll
+    for (int c = 0; c < BT; ++c) {
+      const int k = k0 + c;
+      const int i = tid + k * T;
+      const bool ok = i < L4;
+      float a[4], b[4];
+      gn_coeffs(ga, be, A.inv_hw, (ok ? i : 0) << 2, uniform, mean, rstd, a, b);
+      const float xs[4] = {xr[c].x, xr[c].y, xr[c].z, xr[c].w};
+      const float gs[4] = {dh[k].x, dh[k].y, dh[k].z, dh[k].w};
+      float xo[4], go[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float z = xs[j] * a[j] + b[j];
+        xo[j] = (xs[j] - mean) * rstd;
+        go[j] = (ok && z > 0.f) ? gs[j] * a[j] : 0.f;
+        s1 += go[j];
+        s2 += go[j] * xo[j];
+      }
+      dh[k] = f4{go[0], go[1], go[2], go[3]};
+      if (k < XR) xk[k] = f4{xo[0], xo[1], xo[2], xo[3]};
+      else if (k < XR + XL) s_xh[(k - XR) * T + tid] = f4{xo[0], xo[1], xo[2], xo[3]};
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the batches apart: hoisting the next batch's loads is what spills
+  }
+  const float m1 = block_allsum<T>(s1, sm1) / (float)L;
+  const float m2 = block_allsum<T>(s2, sm2) / (float)L;
+  const float *db = A.dres ? A.dres + (size_t)ng * L : nullptr;
+#pragma unroll
+  for (int k0 = 0; k0 < V; k0 += BT) {
+    f4 xr[BT], dr[BT];
+    int tid = threadIdx.x;
+    DP_LAUNDER(tid);
+#pragma unroll
+    for (int c = 0; c < BT; ++c) {
+      const int i = tid + (k0 + c) * T;
+      const uint32_t ic = i < L4 ? (uint32_t)i : 0u;
+      if (k0 + c >= XR + XL) xr[c] = ld4_at<false>(xb, ic);   // re-read: this workgroup touched it microseconds ago
+      if (db) dr[c] = ld4_at<true>(db, ic);
+    }
+#pragma unroll
+    for (int c = 0; c < BT; ++c) {
+      const int k = k0 + c;
+      const int i = tid + k * T;
+      f4 xh;
+      if (k < XR) xh = xk[k];
+      else if (k < XR + XL) xh = s_xh[(k - XR) * T + tid];
+      else xh = (xr[c] - mean) * rstd;                        // the first phase's own expression
+      f4 o = (dh[k] - m1) - xh * m2;
+      if (db) o = o + dr[c];
+      if (i < L4) st4<true>(o4 + i, o);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+
 // Streaming variants for groups too large for registers (e.g. 384x384 inputs): the group is
 // re-read from L2/HBM instead (forward 3 reads + 1 write, backward 4 reads + 1 write).
 constexpr int kGnStreamT = 1024;
@@ -1763,7 +1892,8 @@ inline void gn_pick(int L4, int &V, int &T) {
 // Measured on MI355X (profiles/r02b_kbench_gn_variants.txt, 256 samples): NT + LC is fastest on 17 of the 20
 // (shape, direction, residual) cases, by 8-21 % over neither; MW8 wins only for the forward without residual
 // (256ch@56x56: 0.270 vs 0.284 ms) and loses with it, so it is applied to that case alone.
-constexpr int kGnNT = 1, kGnLC = 2, kGnMW8 = 4;
+//   8 = (kbench A/B only) groups larger than V = 7 through the streaming backward, as in round 2.
+constexpr int kGnNT = 1, kGnLC = 2, kGnMW8 = 4, kGnStreamLarge = 8;
 constexpr int kGnDefaultVariant = kGnNT | kGnLC;
 
 #define DP_GN_FWD_VT(V_, T_, NT_, LC_, MW_) \
@@ -1815,9 +1945,18 @@ int launch_gn_bwd(int variant, const GnArgs &A, int N, const float *dy, const fl
   int V, T;
   gn_pick(L4, V, T);
   const dim3 grid((unsigned)(N * (A.C / A.Cg)));
-  if (V > 7) V = 0;  // the backward needs x and dy resident (2 x V float4): above V = 7 it re-reads (streaming kernel).
-                     // (A variant keeping only dxh in registers and re-reading x was written and dropped: hipcc spills
-                     // ~1 KB per lane for V = 18 whatever the chunking.)
+  // The backward needs x and dy on chip (2 x V float4 per thread): registers up to V = 9 (72 VGPRs of the 128 a
+  // 1024-thread workgroup may use); V = 18 splits them between registers and LDS (k_gn_relu_bwd_big).  Both stage
+  // gamma / beta in LDS, so groups of more than kGnLdsCh channels (and anything larger) take the streaming kernel.
+  if (V > 7 && (A.Cg > kGnLdsCh || (A.HW & 3) != 0 || (variant & kGnStreamLarge))) V = 0;
+  if (V == 9) {
+    hipLaunchKernelGGL((k_gn_relu_bwd_big<9, 9, 0, 3>), grid, dim3(kGnBigT), 0, st, A, dy, mean, rstd, dx);
+    return launch_status();
+  }
+  if (V == 18) {
+    hipLaunchKernelGGL((k_gn_relu_bwd_big<18, 0, 9, 3>), grid, dim3(kGnBigT), 0, st, A, dy, mean, rstd, dx);
+    return launch_status();
+  }
   if (V == 0) {
     hipLaunchKernelGGL(k_gn_relu_bwd_stream, grid, dim3(kGnStreamT), 0, st, A, dy, mean, rstd, dx);
     return launch_status();

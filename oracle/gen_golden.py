@@ -61,9 +61,15 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file
 class Capture(torch.nn.Module):
     """Wraps the classifier handed to the reference and records the generate() frame."""
 
-    def __init__(self, model, keep_tensors_for=lambda stage, i: True):
+    def __init__(self, model, keep_tensors_for=lambda stage, i: True, grad_noise=None):
         super().__init__()
         self.inner = model
+        # NULL-DISTRIBUTION runs (make_end_metric_null_fixture): (seed, rel) adds, to every gradient the reference's
+        # backward hands to adv_pattern / adv_mask, Gaussian noise of standard deviation rel x RMS(nonzero entries) on
+        # the entries that are not exactly zero (exact zeros — masked-out pixels — stay zero, as they do under any
+        # re-ordering of the fp32 sums).  The reference's code is untouched: the noise enters through a tensor hook.
+        self.noise_rel = None if grad_noise is None else float(grad_noise[1])
+        self.noise_gen = None if grad_noise is None else torch.Generator().manual_seed(int(grad_noise[0]))
         self.records = []          # one dict per hot-loop model call
         self.grads = {}            # (stage, i) -> dict(pattern=..., mask=...)
         self._hooked = set()
@@ -128,13 +134,19 @@ class Capture(torch.nn.Module):
     def _on_grad(self, key, g):
         if self._stage_i is not None and self.keep(*self._stage_i):
             self.grads.setdefault(self._stage_i, {})[key] = g.detach().clone().numpy()
+        if self.noise_rel is not None:
+            nz = g != 0
+            if bool(nz.any()):
+                rms = g[nz].pow(2).mean().sqrt()
+                return g + nz * (self.noise_rel * rms) * torch.randn(g.shape, generator=self.noise_gen, dtype=g.dtype)
+        return None
 
 
 def run_reference(model, x, y, *, sampling_size, max_iterations, eps=4.0, patch_budget=0.12,
-                  targeted=True, n_classes=10, seed=1234, keep=lambda s, i: True, **kw):
+                  targeted=True, n_classes=10, seed=1234, keep=lambda s, i: True, grad_noise=None, **kw):
     """Run the reference's DorPatch.generate under capture.  Returns (Capture, mask, pattern, stdout)."""
     ref = ref_shim.load_reference()
-    cap = Capture(model, keep)
+    cap = Capture(model, keep, grad_noise=grad_noise)
     cwd = os.getcwd()
     tmp = tempfile.mkdtemp(prefix="dorpatch_golden_")
     os.makedirs(os.path.join(tmp, "res", "cfg", "sub"))
@@ -392,13 +404,140 @@ def make_end_metric_fixture(path, H=56, S=8, max_iterations=300, eps=4.0):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# End metric WITH A NULL DISTRIBUTION: how much do the reference's own end metrics move when its
+# gradients are perturbed at the fp32 rounding level?  The update is p -= lr * sign(g): any two correct fp32
+# implementations (another summation order over the S samples, another convolution algorithm) decorrelate pixel-wise
+# within a few hundred steps, so "the product's certified ASR differs from the reference's by x points" means nothing
+# without the spread of reference-vs-reference.  Every image is attacked NULL_RUNS + 1 times by the UNMODIFIED reference:
+# run 0 as is, runs 1.. with Gaussian noise of NULL_NOISE_REL x RMS added to the non-zero entries of the gradients
+# (Capture.grad_noise) — 2 ulp of the typical gradient entry, the level at which two fp32 evaluations of an 8-term sum
+# of convolution outputs differ.  Same seeds in every run: identical init and identical mask draws, only the rounding
+# differs.
+NULL_RUNS = 7
+NULL_NOISE_REL = 2.0 ** -22
+NULL_GAINS = (1.0, 1.08, 1.12, 1.2)          # 8 images each: from certifiably broken to unbroken (cf. END_METRIC_GAINS)
+
+
+def _toy_job(job):
+    k, run, H, S, n_it, eps = job
+    torch.set_num_threads(2)
+    from . import restatement as R
+    ref = ref_shim.load_reference()
+    gain = NULL_GAINS[k % len(NULL_GAINS)]
+    net, x, y = toy_problem(H, seed_x=200 + k, gain=float(gain))
+    noise = None if run == 0 else (10_000 * run + k, NULL_NOISE_REL)
+    cap, mask, pattern, _ = run_reference(net, x, y, sampling_size=S, max_iterations=n_it, eps=eps,
+                                          keep=lambda s, i: False, seed=1234 + k, grad_noise=noise)
+    return k, run, _score(ref, R, net, x, y, mask, pattern, H, eps, 10) + (x.numpy()[0], float(gain))
+
+
+def _score(ref, R, net, x, y, mask, pattern, H, eps, n_classes):
+    """What main.py:140-184 derives from a finished attack: PatchCleanser records at the 4 ratios, predictions on the
+    clean / adversarial image, and the failure count over the 2520-mask universe."""
+    adv = x + R.clip(mask, pattern, x, eps)
+    preds, certs = [], []
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        for r in END_METRIC_RATIOS:
+            pc = ref.PatchCleanser.PatchCleanser(ref.PatchCleanser.MaskWindow(H, r, 1), net)
+            rec = pc.robust_predict(adv[0], True)                          # main.py:150-151
+            preds.append(int(rec.prediction))
+            certs.append(bool(rec.certification))
+        clean, adv_pred = int(net(x).argmax(-1)), int(net(adv).argmax(-1))
+    n_fail = len(R.collect_failure(net, adv, y, R.mask_universe(H, 2), True))
+    return (np.array(preds), np.array(certs), n_fail, clean, adv_pred, int(y))
+
+
+def _pool_map(fn, jobs, procs):
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(procs) as pool:
+        for i, res in enumerate(pool.imap_unordered(fn, jobs)):
+            print("  job %d/%d done" % (i + 1, len(jobs)), flush=True)
+            yield res
+
+
+def _pack_null(path, results, n_images, meta):
+    R1 = NULL_RUNS_OF[meta["name"]] + 1
+    pc_pred = np.zeros((R1, n_images, 4), np.int64)
+    pc_cert = np.zeros((R1, n_images, 4), bool)
+    n_fail = np.zeros((R1, n_images), np.int64)
+    adv_pred = np.zeros((R1, n_images), np.int64)
+    xs, clean, target, gains = [None] * n_images, np.zeros(n_images, np.int64), np.zeros(n_images, np.int64), np.zeros(n_images)
+    for k, run, (preds, certs, nf, cl, ap, y, x, gain) in results:
+        pc_pred[run, k], pc_cert[run, k], n_fail[run, k], adv_pred[run, k] = preds, certs, nf, ap
+        xs[k], clean[k], target[k], gains[k] = x, cl, y, gain
+    out = dict(meta)
+    out.pop("name")
+    out.update(x=np.stack(xs), clean=clean, target=target, gains=gains, pc_pred=pc_pred, pc_cert=pc_cert, n_fail=n_fail,
+               adv_pred=adv_pred, ratios=np.array(END_METRIC_RATIOS), noise_rel=NULL_NOISE_REL)
+    np.savez_compressed(path, **out)
+    return out
+
+
+NULL_RUNS_OF = {"toy": NULL_RUNS, "bit": 3}
+
+
+def make_end_metric_null_fixture(path, n_images=32, H=56, S=8, max_iterations=300, eps=4.0, procs=4):
+    """``end_metric_null_56.npz``: 32 toy problems x (1 + NULL_RUNS) full two-stage runs of the unmodified reference.
+    Arrays indexed [run, image(, ratio)]; run 0 is the unperturbed reference."""
+    jobs = [(k, run, H, S, max_iterations, eps) for k in range(n_images) for run in range(NULL_RUNS + 1)]
+    results = list(_pool_map(_toy_job, jobs, procs))
+    return _pack_null(path, results, n_images, dict(name="toy", H=H, S=S, max_iterations=max_iterations, eps=eps,
+                                                    patch_budget=0.12, n_classes=10))
+
+
+# --- the same through the REAL backbone at reduced resolution (VERDICT r2 item 2b): ResNetV2-50x1-BiT, well-conditioned
+# seeded weights, 56x56 inputs (the reference needs a multiple of 7: attack.py:72-80; 64 is not), S = 8, 300 iterations
+# per stage, 8 images x (1 + 3) runs.
+def bit_problem(k, H=56):
+    from dorpatch_amd.resnetv2 import WELL_CONDITIONED_GN_BIAS, resnetv2_50x1_bit, seeded_init_
+    from dorpatch_amd.utils import NormModel, get_normalize
+    net = seeded_init_(resnetv2_50x1_bit(1000), seed=1234, gn_bias=WELL_CONDITIONED_GN_BIAS).fold_weight_standardization().freeze()
+    model = NormModel(net, get_normalize("imagenet", "resnetv2")).eval()
+    x = torch.rand(1, 3, H, H, generator=torch.Generator().manual_seed(300 + k))
+    with torch.no_grad():
+        y = model(x).topk(2)[1][:, 1].clone()
+    return model, x, y
+
+
+def _bit_job(job):
+    k, run, H, S, n_it, eps = job
+    torch.set_num_threads(2)
+    from . import restatement as R
+    ref = ref_shim.load_reference()
+    model, x, y = bit_problem(k, H)
+    noise = None if run == 0 else (10_000 * run + k, NULL_NOISE_REL)
+    cap, mask, pattern, _ = run_reference(model, x, y, sampling_size=S, max_iterations=n_it, eps=eps, n_classes=1000,
+                                          keep=lambda s, i: False, seed=1234 + k, grad_noise=noise)
+    return k, run, _score(ref, R, model, x, y, mask, pattern, H, eps, 1000) + (x.numpy()[0], 0.0)
+
+
+def make_end_metric_bit_fixture(path, n_images=8, H=56, S=8, max_iterations=300, eps=4.0, procs=4):
+    """``end_metric_bit_56.npz``: the end metric through ResNetV2-50x1-BiT (dorpatch_amd/resnetv2.py on the CPU — an opaque
+    nn.Module for the reference), 8 images x (1 + 3) runs of the unmodified reference."""
+    jobs = [(k, run, H, S, max_iterations, eps) for k in range(n_images) for run in range(NULL_RUNS_OF["bit"] + 1)]
+    results = list(_pool_map(_bit_job, jobs, procs))
+    return _pack_null(path, results, n_images, dict(name="bit", H=H, S=S, max_iterations=max_iterations, eps=eps,
+                                                    patch_budget=0.12, n_classes=1000))
+
+
 def main():
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    if "--only-end-metric-null" in sys.argv:
+        o = make_end_metric_null_fixture(os.path.join(GOLDEN_DIR, "end_metric_null_56.npz"))
+        print({k: o[k].tolist() for k in ("n_fail",)})
+        return
+    if "--only-end-metric-bit" in sys.argv:
+        o = make_end_metric_bit_fixture(os.path.join(GOLDEN_DIR, "end_metric_bit_56.npz"))
+        print({k: o[k].tolist() for k in ("n_fail", "pc_pred", "pc_cert", "adv_pred", "target", "clean")})
+        return
     if "--only-end-metric" in sys.argv:
         o = make_end_metric_fixture(os.path.join(GOLDEN_DIR, "end_metric_56.npz"))
         print({k: o[k].tolist() for k in ("target", "clean", "adv_pred", "n_fail", "pc_pred", "pc_cert", "steps")})
         return
     make_end_metric_fixture(os.path.join(GOLDEN_DIR, "end_metric_56.npz"))
+    make_end_metric_null_fixture(os.path.join(GOLDEN_DIR, "end_metric_null_56.npz"))
+    make_end_metric_bit_fixture(os.path.join(GOLDEN_DIR, "end_metric_bit_56.npz"))
     make_patchcleanser_fixture(os.path.join(GOLDEN_DIR, "patchcleanser_56.npz"))
     make_geometry_fixture(os.path.join(GOLDEN_DIR, "geometry.npz"))
     make_steps_fixture(56, 8, 1.0, os.path.join(GOLDEN_DIR, "steps_56.npz"))

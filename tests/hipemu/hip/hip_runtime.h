@@ -32,6 +32,7 @@
 #define __launch_bounds__(...)
 #define __shared__ static
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)   /* scheduling hint: no meaning on the host */
+#define HIPEMU_HOST 1   /* lets the product TU drop gfx950 inline-asm register hints (DP_LAUNDER) */
 
 using std::max;
 using std::min;

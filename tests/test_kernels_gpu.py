@@ -286,7 +286,13 @@ GN_SHAPES = [  # (N, C, H, W): every (V, T) register variant, the HW = 49 per-la
     (2, 256, 14, 14),     # L4 = 392   -> <2,256>
     (5, 512, 7, 7),       # L4 = 196   -> <1,256>, HW % 4 != 0
     (2, 2048, 7, 7),      # L4 = 784, HW % 4 != 0
-    (1, 256, 96, 96),     # L4 = 18432 -> streaming kernel (384x384 inputs)
+    (1, 256, 96, 96),     # L4 = 18432 -> fwd <18,1024>, bwd k_gn_relu_bwd_big<18,0,9,3>: dh in registers, half of xh in LDS (384x384 inputs)
+    (1, 128, 96, 96),     # L4 = 9216  -> fwd <9,1024>, bwd k_gn_relu_bwd_big<9,9,0,3>: all in registers
+    (2, 512, 48, 48),     # L4 = 9216  -> the same, 16 channels per group
+    (1, 256, 88, 88),     # L4 = 15488 -> the V = 18 kernels with a ragged tail (lanes past the group)
+    (1, 512, 44, 44),     # L4 = 7744  -> the V = 9 kernels with a ragged tail
+    (1, 256, 94, 94),     # L4 = 17672, HW % 4 == 0; (1, 256, 93, 93) below: HW % 4 != 0 -> streaming kernels
+    (1, 256, 93, 93),
     (2, 32, 4, 4),        # one channel per group, tiny
 ]
 
@@ -386,7 +392,8 @@ def test_resnetv2_fused_equals_unfused():
             (np.linalg.norm(got - want) / np.linalg.norm(want), err.max(), (err > 1e-4).mean())
 
 
-@pytest.mark.parametrize("shape", [(2, 256, 56, 56), (3, 512, 28, 28), (2, 2048, 7, 7), (1, 256, 96, 96)])
+@pytest.mark.parametrize("shape", [(2, 256, 56, 56), (3, 512, 28, 28), (2, 2048, 7, 7), (1, 256, 96, 96), (1, 512, 48, 48),
+                                   (1, 256, 88, 88)])
 def test_add_gn_relu_fusion(shape):
     """Residual add fused into GroupNorm+ReLU: (x, res) -> (x + res, relu(gn(x + res))) and the backward
     with the shortcut gradient folded in, against the unfused kernels (bit-exact: same arithmetic)
