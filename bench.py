@@ -93,6 +93,11 @@ def parse():
     ap.add_argument("--stem-split", action="store_true",
                     help="dp_stem_dgrad_reduce (stem input gradient + S-reduction in one launch) instead of autograd down "
                          "to the masked input + dp_apply_bwd (A/B; bit-identical, measured 0.6 %% slower)")
+    ap.add_argument("--placement", action="store_true",
+                    help="EXTENSION workload (not the headline): every EOT sample sees the patch under its own random affine "
+                         "placement (dorpatch_amd.placement.RandomAffine defaults: +-10 deg, scale 0.9-1.1, +-8 px); the "
+                         "roofline object then describes dp_apply_affine_fwd, the fused apply-patch-with-transform-and-"
+                         "occlusion kernel north_star names (same algorithmic bytes: 3*P*4 B written per EOT sample)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for functional "
                                                        "multi-rank tests on a single GPU)")
     ap.add_argument("--force-pg", action="store_true",
@@ -288,8 +293,13 @@ def main():
     owner = DorPatch(micro_batch=args.micro_batch, process_group=pg, verbose=False,
                      deterministic={"auto": "auto", "on": True, "off": False}[args.deterministic])
     # failure_refresh: the every-100-steps collect_failure sweep is timed apart below, never inside the timed steps
+    extras = dict(failure_refresh=10 ** 12, stem_split=args.stem_split, skip_satisfied=args.skip_satisfied == "on")
+    if args.placement:
+        from dorpatch_amd.placement import RandomAffine
+        extras["placement"] = RandomAffine()
+        args.config_label = "custom (EXTENSION: random affine placement per EOT sample; otherwise %s)" % args.config_label
     loop = HotLoop(owner, model, x, args.patch_budget, 1000, "bench_out/cfg/sub", 0, y, True, 1e-2, 1e-1,
-                   0, 1, 10 ** 9, 7, 'topk', 2, S, 1e-3, 1e-3, 4.0, False, dict(failure_refresh=10 ** 12, stem_split=args.stem_split, skip_satisfied=args.skip_satisfied == "on"))
+                   0, 1, 10 ** 9, 7, 'topk', 2, S, 1e-3, 1e-3, 4.0, False, extras)
     loop.stage = args.stage
 
     def barrier():
@@ -361,6 +371,8 @@ def main():
         value = B * S * args.steps / dt
         if args.no_pmc or DEVICE_OVERRIDE is not None:
             traffic, traffic_note = None, "skipped (--no-pmc)"
+        elif args.placement:
+            traffic, traffic_note = None, "not collected for the placement extension"
         elif world > 1:      # the per-GPU launch is the same at every N; the counter passes run in the N = 1 bench only
             traffic, traffic_note = None, "measured at --gpus 1 only"
         else:
@@ -389,7 +401,8 @@ def main():
                                       % (world, "" if pg is None else "; process group backend %s%s" % (
                                           args.backend, " (world-size-1 group forced: collectives executed, not skipped)"
                                           if world == 1 else ""))},
-            "roofline": {"kernel": "k_apply_fwd (dp_apply_fwd)", "bound": "hbm",
+            "roofline": {"kernel": "k_apply_affine_fwd (dp_apply_affine_fwd)" if args.placement else "k_apply_fwd (dp_apply_fwd)",
+                         "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_source": traffic_note,

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
-DP_ABI_VERSION = 6
+DP_ABI_VERSION = 7
 DP_MAX_RECTS = 4
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
@@ -73,6 +73,8 @@ PROTOTYPES = {
     "dp_event_destroy": (_I, [_P]),
     "dp_event_elapsed_ms": (_I, [_P, _P, ctypes.POINTER(ctypes.c_float)]),
     "dp_apply_fwd_timed": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, ctypes.POINTER(DpNorm), _P, _P, _P, _P]),
+    "dp_apply_affine_fwd_timed": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, ctypes.POINTER(DpNorm), _P, _P, _P,
+                                       _P]),
 }
 
 _lib = None

@@ -875,7 +875,7 @@ class HotLoop(object):
             theta = torch.as_tensor(th, device=self.dev)
             theta_inv = torch.as_tensor(dp_placement.invert(th), device=self.dev)
             delta = ops.blend(self.adv_mask, self.adv_pattern, self.x, self.eps, add_x=False)[0]
-            inp_all = ops.apply_affine_fwd(self.x, delta, theta, self.table, idx, idx2, self.dn)
+            inp_all = ops.apply_affine_fwd(self.x, delta, theta, self.table, idx, idx2, self.dn, timer=timer)
         else:
             inp_all = ops.apply_fwd(self.adv_x, self.table, idx, idx2, self.dn, timer=timer)   # (B*Sl,3,H,W)
         self._placement_ctx = (theta, theta_inv)

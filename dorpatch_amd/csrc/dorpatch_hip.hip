@@ -364,23 +364,110 @@ __device__ __forceinline__ void affine_src(const Affine &A, int ox, int oy, floa
   sy = (A.a10 * (float)ox + A.a11 * (float)oy) + A.t1;
 }
 
+// Tiling (round 3).  Round 2's kernels issued 48 scalar global gathers per lane (forward: 1.24 ms per 64 x 32 x 224^2
+// launch = 13 % of the HBM roofline) and walked a 6 x 6 box of candidate outputs per source pixel, re-deriving every tap
+// and re-testing every occlusion window (backward: 4.19 ms = 3.8 %) — profiles/r03a_kbench_affine.txt.  Now a workgroup
+// owns a 32 x 32 tile and stages what it gathers from in LDS:
+//   forward   the tile's source footprint in delta — the bounding box of the 4 mapped tile corners + 1 tap + 1 margin
+//             pixel, zero outside the image, 3 channels — is loaded once with coalesced row segments; every lane then
+//             takes its 4 x 4 x 3 taps from LDS and writes its 3 float4 with non-temporal stores;
+//   backward  (exact adjoint, GATHER form, fixed order: no float atomics) per sample of the slab the workgroup stages the
+//             OUTPUT region that can touch its 32 x 32 source tile: the incoming gradient with the occlusion already
+//             applied (3 floats), and per output pixel its tap record — floor(src) relative to the tile and the two
+//             fractional weights, computed ONCE per output by the forward's own expression instead of once per
+//             (source pixel, candidate).  A source pixel then tests its 2kx x 2ky candidate outputs (kx = ceil of the
+//             inverse map's row sum: 4 x 4 for the default placement range) with one LDS read each and accumulates the
+//             hits in row-major order of the outputs, samples ascending: deterministic.
+// A footprint that does not fit the LDS budget (extreme scale / rotation) takes the round-2 per-pixel code (slow path,
+// same arithmetic).  Identity placement stays bit-identical to dp_apply_fwd / dp_apply_bwd.
+constexpr int kAffT = 32;            // tile side
+constexpr int kAffCapF = 48 * 48;    // forward: source-footprint pixels per channel in LDS (27 KiB for 3 channels)
+constexpr int kAffCapB = 48 * 48;    // backward: staged output pixels (6 dwords each: 54 KiB)
+
+__device__ __forceinline__ bool occluded1(const int32_t *__restrict__ t, int R, int h, int w) {
+  bool occ = false;
+  for (int r = 0; r < R; ++r)
+    occ |= (h >= t[4 * r] && h < t[4 * r + 1] && w >= t[4 * r + 2] && w < t[4 * r + 3]);
+  return occ;
+}
+
+// Bilinear taps of one output pixel straight from global memory (the slow path; round 2's arithmetic, tap order
+// (y0,x0), (y0,x1), (y1,x0), (y1,x1), out-of-image taps skipped).
+__device__ __forceinline__ void affine_taps_global(const Affine &A, const float *__restrict__ db, int P, int H, int W,
+                                                   int ox, int oy, float acc[3]) {
+  float sx, sy;
+  affine_src(A, ox, oy, sx, sy);
+  const float fx0 = floorf(sx), fy0 = floorf(sy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+  const bool inx0 = x0 >= 0 && x0 < W, inx1 = x0 + 1 >= 0 && x0 + 1 < W;
+  const bool iny0 = y0 >= 0 && y0 < H, iny1 = y0 + 1 >= 0 && y0 + 1 < H;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float *dc = db + (size_t)c * P;
+    float a = 0.f;
+    if (iny0 && inx0) a += (wy0 * wx0) * dc[y0 * W + x0];
+    if (iny0 && inx1) a += (wy0 * wx1) * dc[y0 * W + x0 + 1];
+    if (iny1 && inx0) a += (wy1 * wx0) * dc[(y0 + 1) * W + x0];
+    if (iny1 && inx1) a += (wy1 * wx1) * dc[(y0 + 1) * W + x0 + 1];
+    acc[c] = a;
+  }
+}
+
+// grid: x = 32 x 32 output tiles (row-major), y = sample, z = image.  Thread (ly = tid / 8, lx = 4 * (tid % 8)) owns
+// output pixels (ty0 + ly, tx0 + lx .. + 3) of all 3 channels.
 __global__ __launch_bounds__(kBlock) void k_apply_affine_fwd(
     const float *__restrict__ x, const float *__restrict__ delta, const float *__restrict__ theta,
     const int32_t *__restrict__ table, int R, const int32_t *__restrict__ idx,
-    const int32_t *__restrict__ idx2, int idx_bstride, int S, int H, int W, NormDev nd,
+    const int32_t *__restrict__ idx2, int idx_bstride, int S, int H, int W, int tiles_x, NormDev nd,
     float *__restrict__ out) {
+  __shared__ float sd[3 * kAffCapF];
   const int P = H * W, P4 = P >> 2;
-  const int g = blockIdx.x * kBlock + threadIdx.x;
-  if (g >= P4) return;
   const int s = blockIdx.y, b = blockIdx.z;
-  const int pix = g << 2;
-  const int h = pix / W, w = pix - h * W;
+  const int tx0 = (blockIdx.x % tiles_x) * kAffT, ty0 = (blockIdx.x / tiles_x) * kAffT;
   const Affine A = load_affine(theta, (size_t)b * S + s);
-  const int m1 = idx[(size_t)b * idx_bstride + s];
-  unsigned occ = occluded4(table, R, m1, h, w);
-  if (idx2) occ |= occluded4(table, R, idx2[(size_t)b * idx_bstride + s], h, w);
   const float *xb = x + (size_t)b * 3 * P, *db = delta + (size_t)b * 3 * P;
   float *ob = out + ((size_t)b * S + s) * 3 * P;
+
+  // source footprint of the tile: the map is affine, so its extremes are at the tile's corners
+  const int cx1 = min(tx0 + kAffT - 1, W - 1), cy1 = min(ty0 + kAffT - 1, H - 1);
+  float sx00, sy00, sx01, sy01, sx10, sy10, sx11, sy11;
+  affine_src(A, tx0, ty0, sx00, sy00);
+  affine_src(A, cx1, ty0, sx01, sy01);
+  affine_src(A, tx0, cy1, sx10, sy10);
+  affine_src(A, cx1, cy1, sx11, sy11);
+  const float fx_lo = fminf(fminf(sx00, sx01), fminf(sx10, sx11)), fx_hi = fmaxf(fmaxf(sx00, sx01), fmaxf(sx10, sx11));
+  const float fy_lo = fminf(fminf(sy00, sy01), fminf(sy10, sy11)), fy_hi = fmaxf(fmaxf(sy00, sy01), fmaxf(sy10, sy11));
+  // [floor(lo) - 1, floor(hi) + 2]: the +1 tap and one pixel of margin either side (rounding of interior points)
+  const bool finite = fabsf(fx_lo) < 1e6f && fabsf(fx_hi) < 1e6f && fabsf(fy_lo) < 1e6f && fabsf(fy_hi) < 1e6f;
+  const int rx0 = finite ? (int)floorf(fx_lo) - 1 : 0, ry0 = finite ? (int)floorf(fy_lo) - 1 : 0;
+  const int RW = finite ? (int)floorf(fx_hi) + 2 - rx0 + 1 : 1 << 20, RH = finite ? (int)floorf(fy_hi) + 2 - ry0 + 1 : 1;
+  const bool staged = RW <= 64 && RW * RH <= kAffCapF;   // wave-uniform
+
+  if (staged) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gx = rx0 + lane;
+    const bool colok = lane < RW && gx >= 0 && gx < W;
+    for (int ry = wv; ry < RH; ry += kBlock / 64) {
+      const int gy = ry0 + ry;
+      const bool ok = colok && gy >= 0 && gy < H;
+      const size_t o = (size_t)(ok ? gy : 0) * W + (ok ? gx : 0);
+      const float v0 = db[o], v1 = db[P + o], v2 = db[2 * (size_t)P + o];   // all three issued before the first use
+      if (lane < RW) {
+        sd[ry * RW + lane] = ok ? v0 : 0.f;
+        sd[kAffCapF + ry * RW + lane] = ok ? v1 : 0.f;
+        sd[2 * kAffCapF + ry * RW + lane] = ok ? v2 : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+
+  const int oy = ty0 + (threadIdx.x >> 3), ox = tx0 + ((threadIdx.x & 7) << 2);
+  if (oy >= H || ox >= W) return;
+  const int g = (oy * W + ox) >> 2;
+  const int m1 = idx[(size_t)b * idx_bstride + s];
+  unsigned occ = occluded4(table, R, m1, oy, ox);
+  if (idx2) occ |= occluded4(table, R, idx2[(size_t)b * idx_bstride + s], oy, ox);
   float v[3][4];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -389,23 +476,25 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_fwd(
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    float sx, sy;
-    affine_src(A, w + j, h, sx, sy);
-    const float fx0 = floorf(sx), fy0 = floorf(sy);
-    const int x0 = (int)fx0, y0 = (int)fy0;
-    const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-    const bool inx0 = x0 >= 0 && x0 < W, inx1 = x0 + 1 >= 0 && x0 + 1 < W;
-    const bool iny0 = y0 >= 0 && y0 < H, iny1 = y0 + 1 >= 0 && y0 + 1 < H;
+    float acc[3];
+    if (staged) {
+      float sx, sy;
+      affine_src(A, ox + j, oy, sx, sy);
+      const float fx0 = floorf(sx), fy0 = floorf(sy);
+      const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+      // clamped for memory safety only: with the margin a tap never leaves the staged box
+      const int ix = min(max((int)fx0 - rx0, 0), RW - 2), iy = min(max((int)fy0 - ry0, 0), RH - 2);
+      const float *t = sd + iy * RW + ix;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float *dc = db + (size_t)c * P;
-      float acc = 0.f;  // tap order fixed: (y0,x0), (y0,x1), (y1,x0), (y1,x1)
-      if (iny0 && inx0) acc += (wy0 * wx0) * dc[y0 * W + x0];
-      if (iny0 && inx1) acc += (wy0 * wx1) * dc[y0 * W + x0 + 1];
-      if (iny1 && inx0) acc += (wy1 * wx0) * dc[(y0 + 1) * W + x0];
-      if (iny1 && inx1) acc += (wy1 * wx1) * dc[(y0 + 1) * W + x0 + 1];
-      v[c][j] += acc;
+      for (int c = 0; c < 3; ++c) {  // tap order fixed: (y0,x0), (y0,x1), (y1,x0), (y1,x1); zeros stand for out-of-image taps
+        const float *tc = t + c * kAffCapF;
+        acc[c] = (((wy0 * wx0) * tc[0] + (wy0 * wx1) * tc[1]) + (wy1 * wx0) * tc[RW]) + (wy1 * wx1) * tc[RW + 1];
+      }
+    } else {
+      affine_taps_global(A, db, P, H, W, ox + j, oy, acc);
     }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c][j] += acc[c];
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -415,67 +504,154 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_fwd(
   }
 }
 
-// One thread per source pixel p = (py, px) x 3 channels; grid y = S-slab, z = image.  theta_inv (B,S,6) is the
-// inverse map (source -> output coordinates) supplied by the host; it only positions the search box.
+// Contribution of ONE sample to ONE source pixel by the round-2 walk over the candidate outputs' bounding box (the
+// backward's slow path; reads G from global memory, re-derives every tap and occlusion test).
+__device__ __forceinline__ void affine_bwd_pixel_global(const Affine &A, const Affine &Ai, const float *__restrict__ Gs,
+                                                        const int32_t *__restrict__ t1, const int32_t *__restrict__ t2,
+                                                        int R, int P, int H, int W, int px, int py, float acc[3]) {
+  float cx, cy;
+  affine_src(Ai, px, py, cx, cy);  // output-space centre of the footprint
+  const float ex = fabsf(Ai.a00) + fabsf(Ai.a01), ey = fabsf(Ai.a10) + fabsf(Ai.a11);
+  const int ox0 = max(0, (int)floorf(cx - ex) - 1), ox1 = min(W - 1, (int)ceilf(cx + ex) + 1);
+  const int oy0 = max(0, (int)floorf(cy - ey) - 1), oy1 = min(H - 1, (int)ceilf(cy + ey) + 1);
+  for (int oy = oy0; oy <= oy1; ++oy)
+    for (int ox = ox0; ox <= ox1; ++ox) {
+      float sx, sy;
+      affine_src(A, ox, oy, sx, sy);  // the forward's own expression: identical weights
+      const float fx0 = floorf(sx), fy0 = floorf(sy);
+      const int x0 = (int)fx0, y0 = (int)fy0;
+      float wgt;
+      if (px == x0) wgt = 1.f - (sx - fx0);
+      else if (px == x0 + 1) wgt = sx - fx0;
+      else continue;
+      if (py == y0) wgt = (1.f - (sy - fy0)) * wgt;
+      else if (py == y0 + 1) wgt = (sy - fy0) * wgt;
+      else continue;
+      if (occluded1(t1, R, oy, ox) || (t2 && occluded1(t2, R, oy, ox))) continue;
+      const size_t o = (size_t)oy * W + ox;
+      acc[0] += wgt * Gs[o];
+      acc[1] += wgt * Gs[P + o];
+      acc[2] += wgt * Gs[2 * (size_t)P + o];
+    }
+}
+
+// grid: x = 32 x 32 SOURCE tiles, y = S-slab, z = image.  Thread (ly = tid / 8, lx = 4 * (tid % 8)) owns source pixels
+// (ty0 + ly, tx0 + lx .. + 3) x 3 channels.  theta_inv (B,S,6) is the inverse map supplied by the host; it only
+// positions the staged region and the candidate windows (both carry a margin), never a weight.
 __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
     const float *__restrict__ G, const float *__restrict__ theta, const float *__restrict__ theta_inv,
     const int32_t *__restrict__ table, int R, const int32_t *__restrict__ idx,
-    const int32_t *__restrict__ idx2, int idx_bstride, int B, int S, int H, int W, int s_per_slab,
+    const int32_t *__restrict__ idx2, int idx_bstride, int B, int S, int H, int W, int tiles_x, int s_per_slab,
     NormDev nd, float *__restrict__ slabs) {
+  __shared__ float sg[3 * kAffCapB];
+  __shared__ float swx[kAffCapB], swy[kAffCapB];
+  __shared__ int stap[kAffCapB];
   const int P = H * W;
-  const int p = blockIdx.x * kBlock + threadIdx.x;
-  if (p >= P) return;
   const int b = blockIdx.z, z = blockIdx.y;
-  const int py = p / W, px = p - py * W;
+  const int tx0 = (blockIdx.x % tiles_x) * kAffT, ty0 = (blockIdx.x / tiles_x) * kAffT;
+  const int py = ty0 + (threadIdx.x >> 3), px0 = tx0 + ((threadIdx.x & 7) << 2);
+  const bool mine = py < H && px0 < W;
   const int s_begin = z * s_per_slab, s_end = min(S, s_begin + s_per_slab);
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  float acc[4][3];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[j][c] = 0.f;
+  // source box whose taps this workgroup owns, expanded by one pixel: an output contributes iff floor(src) lies in it
+  const float bx0 = (float)(tx0 - 1), bx1 = (float)min(tx0 + kAffT, W), by0 = (float)(ty0 - 1), by1 = (float)min(ty0 + kAffT, H);
   for (int s = s_begin; s < s_end; ++s) {
     const Affine A = load_affine(theta, (size_t)b * S + s);
     const Affine Ai = load_affine(theta_inv, (size_t)b * S + s);
-    float cx, cy;
-    affine_src(Ai, px, py, cx, cy);  // output-space centre of the footprint
-    const float ex = fabsf(Ai.a00) + fabsf(Ai.a01), ey = fabsf(Ai.a10) + fabsf(Ai.a11);
-    const int ox0 = max(0, (int)floorf(cx - ex) - 1), ox1 = min(W - 1, (int)ceilf(cx + ex) + 1);
-    const int oy0 = max(0, (int)floorf(cy - ey) - 1), oy1 = min(H - 1, (int)ceilf(cy + ey) + 1);
     const int32_t *t1 = table + (size_t)idx[(size_t)b * idx_bstride + s] * R * 4;
     const int32_t *t2 = idx2 ? table + (size_t)idx2[(size_t)b * idx_bstride + s] * R * 4 : nullptr;
     const float *Gs = G + ((size_t)b * S + s) * 3 * P;
-    for (int oy = oy0; oy <= oy1; ++oy)
-      for (int ox = ox0; ox <= ox1; ++ox) {
-        float sx, sy;
-        affine_src(A, ox, oy, sx, sy);  // the forward's own expression: identical weights
-        const float fx0 = floorf(sx), fy0 = floorf(sy);
-        const int x0 = (int)fx0, y0 = (int)fy0;
-        float wgt;
-        if (px == x0) wgt = 1.f - (sx - fx0);
-        else if (px == x0 + 1) wgt = sx - fx0;
-        else continue;
-        if (py == y0) wgt = (1.f - (sy - fy0)) * wgt;
-        else if (py == y0 + 1) wgt = (sy - fy0) * wgt;
-        else continue;
-        bool occ = false;
-        for (int pass = 0; pass < 2; ++pass) {
-          const int32_t *t = pass == 0 ? t1 : t2;
-          if (!t) continue;
-          for (int r = 0; r < R; ++r)
-            occ |= (oy >= t[4 * r] && oy < t[4 * r + 1] && ox >= t[4 * r + 2] && ox < t[4 * r + 3]);
-        }
-        if (occ) continue;
-        const size_t o = (size_t)oy * W + ox;
-        a0 += wgt * Gs[o];
-        a1 += wgt * Gs[P + o];
-        a2 += wgt * Gs[2 * (size_t)P + o];
+    // output region = bounding box of the inverse-mapped source box (+ 2 pixels of margin), clipped to the image
+    const float qxa = Ai.a00 * bx0, qxb = Ai.a00 * bx1, qxc = Ai.a01 * by0, qxd = Ai.a01 * by1;
+    const float qya = Ai.a10 * bx0, qyb = Ai.a10 * bx1, qyc = Ai.a11 * by0, qyd = Ai.a11 * by1;
+    const float qx_lo = (fminf(qxa, qxb) + fminf(qxc, qxd)) + Ai.t0, qx_hi = (fmaxf(qxa, qxb) + fmaxf(qxc, qxd)) + Ai.t0;
+    const float qy_lo = (fminf(qya, qyb) + fminf(qyc, qyd)) + Ai.t1, qy_hi = (fmaxf(qya, qyb) + fmaxf(qyc, qyd)) + Ai.t1;
+    const bool finite = fabsf(qx_lo) < 1e6f && fabsf(qx_hi) < 1e6f && fabsf(qy_lo) < 1e6f && fabsf(qy_hi) < 1e6f;
+    const int qx0 = finite ? max(0, (int)floorf(qx_lo) - 2) : 0, qx1 = finite ? min(W - 1, (int)ceilf(qx_hi) + 2) : W - 1;
+    const int qy0 = finite ? max(0, (int)floorf(qy_lo) - 2) : 0, qy1 = finite ? min(H - 1, (int)ceilf(qy_hi) + 2) : H - 1;
+    const int QW = qx1 - qx0 + 1, QH = qy1 - qy0 + 1;
+    if (finite && (QW <= 0 || QH <= 0)) continue;       // no output maps near this tile (wave-uniform)
+    const float ex = fabsf(Ai.a00) + fabsf(Ai.a01), ey = fabsf(Ai.a10) + fabsf(Ai.a11);
+    const int kx = (int)ceilf(ex + 0.01f), ky = (int)ceilf(ey + 0.01f);
+    const bool staged = finite && QW <= 64 && QW * QH <= kAffCapB && kx <= 4 && ky <= 4;
+    if (!staged) {   // slow path: per-pixel walk over global memory
+      if (mine) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) affine_bwd_pixel_global(A, Ai, Gs, t1, t2, R, P, H, W, px0 + j, py, acc[j]);
       }
+      continue;
+    }
+    __syncthreads();   // the previous sample's gather is done with the staging buffers
+    {
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      const int ox = qx0 + lane;
+      const bool colok = lane < QW;
+      for (int qy = wv; qy < QH; qy += kBlock / 64) {
+        const int oy = qy0 + qy;
+        const size_t o = (size_t)oy * W + (colok ? ox : qx0);
+        const float g0 = Gs[o], g1 = Gs[P + o], g2 = Gs[2 * (size_t)P + o];
+        float sx, sy;
+        affine_src(A, ox, oy, sx, sy);   // the forward's own expression: identical weights
+        const float fx0 = floorf(sx), fy0 = floorf(sy);
+        // tap record: floor(src) relative to (tile origin - 2), 0 = not a neighbour of this tile
+        const float rx = fx0 - (float)(tx0 - 2), ry = fy0 - (float)(ty0 - 2);
+        const bool near = rx >= 0.f && rx < (float)(kAffT + 4) && ry >= 0.f && ry < (float)(kAffT + 4);
+        const bool keep = !(occluded1(t1, R, oy, ox) || (t2 && occluded1(t2, R, oy, ox)));
+        if (colok) {
+          const int e = qy * QW + lane;
+          stap[e] = near ? (1 + (int)rx + ((int)ry << 8)) : 0;
+          swx[e] = sx - fx0;
+          swy[e] = sy - fy0;
+          sg[e] = keep ? g0 : 0.f;
+          sg[kAffCapB + e] = keep ? g1 : 0.f;
+          sg[2 * kAffCapB + e] = keep ? g2 : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    if (mine) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int px = px0 + j;
+        if (px >= W) break;
+        float cx, cy;
+        affine_src(Ai, px, py, cx, cy);
+        // candidates: outputs within (ex, ey) of the inverse image of the pixel; o - floor(c) in [1 - k, k]
+        const int ocx = (int)floorf(cx) - qx0, ocy = (int)floorf(cy) - qy0;
+        const int want = 1 + (px - (tx0 - 2)) + ((py - (ty0 - 2)) << 8);   // tap record of an output whose floor(src) == (px, py)
+        for (int dy = 1 - ky; dy <= ky; ++dy) {
+          const int qy = ocy + dy;
+          if (qy < 0 || qy >= QH) continue;
+          for (int dx = 1 - kx; dx <= kx; ++dx) {
+            const int qx = ocx + dx;
+            if (qx < 0 || qx >= QW) continue;
+            const int e = qy * QW + qx;
+            const int d = want - stap[e];   // (px - x0) + 256 * (py - y0): 0, 1, 256 or 257 for the four taps
+            if (d != 0 && d != 1 && d != 256 && d != 257) continue;
+            if (stap[e] == 0) continue;
+            const float fx = swx[e], fy = swy[e];
+            float wgt = (d & 1) ? fx : 1.f - fx;
+            wgt = ((d >> 8) ? fy : 1.f - fy) * wgt;
+            acc[j][0] += wgt * sg[e];
+            acc[j][1] += wgt * sg[kAffCapB + e];
+            acc[j][2] += wgt * sg[2 * kAffCapB + e];
+          }
+        }
+      }
+    }
   }
-  if (nd.enable) {
-    a0 = a0 / nd.std[0];
-    a1 = a1 / nd.std[1];
-    a2 = a2 / nd.std[2];
+  if (!mine) return;
+  float *dst = slabs + ((size_t)z * B + b) * 3 * P + (size_t)py * W + px0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    f4 o = f4{acc[0][c], acc[1][c], acc[2][c], acc[3][c]};
+    if (nd.enable) o = o / nd.std[c];
+    *reinterpret_cast<f4 *>(dst + (size_t)c * P) = o;
   }
-  float *dst = slabs + ((size_t)z * B + b) * 3 * P;
-  dst[p] = a0;
-  dst[P + p] = a1;
-  dst[2 * (size_t)P + p] = a2;
 }
 
 __global__ __launch_bounds__(kBlock) void k_sum_slabs(const float *__restrict__ slabs,
@@ -1424,13 +1600,25 @@ __global__ __launch_bounds__(kGnStreamT) void k_gn_relu_bwd_stream(
 // divisions per thread, which made these kernels instruction-bound: ~550 instructions per 32 bytes stored.)
 constexpr int kPoolTX = 16, kPoolTY = 8;   // 8 rows: 56 and 112 are multiples (a 16-row block idles 1/8 of the forward)
 
+// MODE (which rows a workgroup owns; tools/kbench sweeps them, the C ABI uses kPoolDefaultMode):
+//   0  grid (plane, row group): consecutive workgroups touch DIFFERENT planes (round-2 form: 3.5 KiB pieces of 32 768
+//      planes interleaved — 3.6 TB/s for the backward in every step trace, profiles/r03a_kbench_pool.txt reproduces it
+//      with cold 512-sample operands);
+//   1  grid.x = plane * row groups + row group: consecutive workgroups write consecutive 3.5 KiB pieces (a linear stream);
+//   2  one workgroup per plane, looping over its row groups (50 KiB contiguous per workgroup).
+template <int MODE>
 __global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_fwd(const float *__restrict__ x, int Hin,
-                                                                       int Win, float *__restrict__ y,
+                                                                       int Win, int nrg, float *__restrict__ y,
                                                                        uint32_t *__restrict__ code4) {
   const int Ho = Hin >> 1, Wq = Win >> 3;  // Wo/4 quads per output row
-  const int oh = blockIdx.y * kPoolTY + threadIdx.y;
-  if (oh >= Ho) return;
-  const long nc = blockIdx.x;
+  long nc;
+  int rg0, rg_step;
+  if (MODE == 0) { nc = blockIdx.x; rg0 = blockIdx.y; rg_step = nrg; }
+  else if (MODE == 1) { nc = blockIdx.x / (unsigned)nrg; rg0 = (int)(blockIdx.x - (unsigned)nc * (unsigned)nrg); rg_step = nrg; }
+  else { nc = blockIdx.x; rg0 = 0; rg_step = 1; }
+  for (int rg = rg0; rg < nrg; rg += rg_step) {
+  const int oh = rg * kPoolTY + threadIdx.y;
+  if (oh >= Ho) continue;
   for (int q = threadIdx.x; q < Wq; q += kPoolTX) {
   const long tid = (nc * Ho + oh) * Wq + q;
   const float *xp = x + nc * (long)Hin * Win;
@@ -1466,20 +1654,27 @@ __global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_fwd(const flo
   reinterpret_cast<f4 *>(y)[tid] = f4{best[0], best[1], best[2], best[3]};
   code4[tid] = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
   }
+  }
 }
 
 // One thread = 8 consecutive input pixels of one row (two float4 stores).  They are covered by the 5 windows
 // ow = 4t .. 4t + 4 of each of the (1 or 2) output rows whose window contains the input row: per output row one
 // aligned float4 of dy + one aligned 4-byte word of codes + the halo element of each (3x fewer memory
 // instructions per byte than a thread per float4 with scalar dy / byte-wide code loads).
+template <int MODE>
 __global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_bwd(const float *__restrict__ dy,
                                                                        const uint8_t *__restrict__ code,
-                                                                       int Hin, int Win,
+                                                                       int Hin, int Win, int nrg,
                                                                        float *__restrict__ dx) {
   const int Ho = Hin >> 1, Wo = Win >> 1, W8 = Win >> 3;
-  const int h = blockIdx.y * kPoolTY + threadIdx.y;
-  if (h >= Hin) return;
-  const long nc = blockIdx.x;
+  long nc;
+  int rg0, rg_step;
+  if (MODE == 0) { nc = blockIdx.x; rg0 = blockIdx.y; rg_step = nrg; }
+  else if (MODE == 1) { nc = blockIdx.x / (unsigned)nrg; rg0 = (int)(blockIdx.x - (unsigned)nc * (unsigned)nrg); rg_step = nrg; }
+  else { nc = blockIdx.x; rg0 = 0; rg_step = 1; }
+  for (int rg = rg0; rg < nrg; rg += rg_step) {
+  const int h = rg * kPoolTY + threadIdx.y;
+  if (h >= Hin) continue;
   for (int t = threadIdx.x; t < W8; t += kPoolTX) {
   const long tid = (nc * Hin + h) * W8 + t;
   const float *dyp = dy + nc * (long)Ho * Wo;
@@ -1514,6 +1709,31 @@ __global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_bwd(const flo
   __builtin_nontemporal_store(f4{o[0], o[1], o[2], o[3]}, dst);
   __builtin_nontemporal_store(f4{o[4], o[5], o[6], o[7]}, dst + 1);
   }
+  }
+}
+
+constexpr int kPoolDefaultMode = 1;
+
+int launch_pad_maxpool_fwd(int mode, const float *x, int64_t NC, int Hin, int Win, float *y, uint32_t *code4,
+                           hipStream_t st) {
+  const int nrg = cdiv(Hin >> 1, kPoolTY);
+  DP_REQUIRE(mode >= 0 && mode <= 2 && (mode != 1 || NC * nrg <= 0x7fffffffL));
+  const dim3 block(kPoolTX, kPoolTY);
+  if (mode == 0) hipLaunchKernelGGL(k_pad_maxpool_fwd<0>, dim3((unsigned)NC, (unsigned)nrg), block, 0, st, x, Hin, Win, nrg, y, code4);
+  else if (mode == 1) hipLaunchKernelGGL(k_pad_maxpool_fwd<1>, dim3((unsigned)(NC * nrg)), block, 0, st, x, Hin, Win, nrg, y, code4);
+  else hipLaunchKernelGGL(k_pad_maxpool_fwd<2>, dim3((unsigned)NC), block, 0, st, x, Hin, Win, nrg, y, code4);
+  return launch_status();
+}
+
+int launch_pad_maxpool_bwd(int mode, const float *dy, const uint8_t *code, int64_t NC, int Hin, int Win, float *dx,
+                           hipStream_t st) {
+  const int nrg = cdiv(Hin, kPoolTY);
+  DP_REQUIRE(mode >= 0 && mode <= 2 && (mode != 1 || NC * nrg <= 0x7fffffffL));
+  const dim3 block(kPoolTX, kPoolTY);
+  if (mode == 0) hipLaunchKernelGGL(k_pad_maxpool_bwd<0>, dim3((unsigned)NC, (unsigned)nrg), block, 0, st, dy, code, Hin, Win, nrg, dx);
+  else if (mode == 1) hipLaunchKernelGGL(k_pad_maxpool_bwd<1>, dim3((unsigned)(NC * nrg)), block, 0, st, dy, code, Hin, Win, nrg, dx);
+  else hipLaunchKernelGGL(k_pad_maxpool_bwd<2>, dim3((unsigned)NC), block, 0, st, dy, code, Hin, Win, nrg, dx);
+  return launch_status();
 }
 
 
@@ -2131,17 +2351,34 @@ int dp_apply_bwd(const float *G, const int32_t *table, int R, const int32_t *idx
   return launch_status();
 }
 
-int dp_apply_affine_fwd(const float *x, const float *delta, const float *theta, const int32_t *table, int R,
-                        const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
-                        const dp_norm_t *norm, float *out, dp_stream_t stream) {
+static int launch_apply_affine_fwd(const float *x, const float *delta, const float *theta, const int32_t *table, int R,
+                                   const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
+                                   const dp_norm_t *norm, float *out, dp_stream_t stream, hipEvent_t ev_start,
+                                   hipEvent_t ev_stop) {
   DP_REQUIRE(x && delta && theta && out && aligned16(x) && aligned16(out));
   const int rc = check_occlusion_args(table, R, idx, idx_bstride, B, S, H, W, norm);
   if (rc) return rc;
   DP_REQUIRE(S <= 65535);
-  hipLaunchKernelGGL(k_apply_affine_fwd, dim3(cdiv((H * W) >> 2, kBlock), S, B), dim3(kBlock), 0,
-                     as_stream(stream), x, delta, theta, table, R, idx, idx2, idx_bstride, S, H, W,
-                     make_norm(norm), out);
+  const int tiles_x = cdiv(W, kAffT), tiles_y = cdiv(H, kAffT);
+  hipExtLaunchKernelGGL(k_apply_affine_fwd, dim3(tiles_x * tiles_y, S, B), dim3(kBlock), 0, as_stream(stream), ev_start,
+                        ev_stop, 0, x, delta, theta, table, R, idx, idx2, idx_bstride, S, H, W, tiles_x, make_norm(norm),
+                        out);
   return launch_status();
+}
+
+int dp_apply_affine_fwd(const float *x, const float *delta, const float *theta, const int32_t *table, int R,
+                        const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
+                        const dp_norm_t *norm, float *out, dp_stream_t stream) {
+  return launch_apply_affine_fwd(x, delta, theta, table, R, idx, idx2, idx_bstride, B, S, H, W, norm, out, stream,
+                                 nullptr, nullptr);
+}
+
+int dp_apply_affine_fwd_timed(const float *x, const float *delta, const float *theta, const int32_t *table, int R,
+                              const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
+                              const dp_norm_t *norm, float *out, dp_stream_t stream, dp_event_t start, dp_event_t stop) {
+  DP_REQUIRE(start && stop);
+  return launch_apply_affine_fwd(x, delta, theta, table, R, idx, idx2, idx_bstride, B, S, H, W, norm, out, stream,
+                                 (hipEvent_t)start, (hipEvent_t)stop);
 }
 
 int dp_apply_affine_bwd(const float *G, const float *theta, const float *theta_inv, const int32_t *table, int R,
@@ -2154,9 +2391,10 @@ int dp_apply_affine_bwd(const float *G, const float *theta, const float *theta_i
   const int s_per_slab = bwd_s_per_slab(B, S, P);
   const int nslab = cdiv(S, s_per_slab);
   DP_REQUIRE(nslab <= 65535);
-  hipLaunchKernelGGL(k_apply_affine_bwd, dim3(cdiv(P, kBlock), nslab, B), dim3(kBlock), 0, as_stream(stream), G,
-                     theta, theta_inv, table, R, idx, idx2, idx_bstride, B, S, H, W, s_per_slab, make_norm(norm),
-                     slabs);
+  const int tiles_x = cdiv(W, kAffT), tiles_y = cdiv(H, kAffT);
+  hipLaunchKernelGGL(k_apply_affine_bwd, dim3(tiles_x * tiles_y, nslab, B), dim3(kBlock), 0, as_stream(stream), G,
+                     theta, theta_inv, table, R, idx, idx2, idx_bstride, B, S, H, W, tiles_x, s_per_slab,
+                     make_norm(norm), slabs);
   return launch_status();
 }
 
@@ -2334,10 +2572,7 @@ int dp_pad_maxpool_fwd(const float *x, int64_t NC, int Hin, int Win, float *y, u
   DP_REQUIRE(x && y && code && aligned16(x) && aligned16(y) && aligned16(code));
   DP_REQUIRE(NC > 0 && Hin >= 2 && Win >= 8 && (Hin & 1) == 0 && (Win & 7) == 0);
   DP_REQUIRE(NC <= 0x7fffffffL);
-  const dim3 grid((unsigned)NC, (unsigned)cdiv(Hin >> 1, kPoolTY));
-  hipLaunchKernelGGL(k_pad_maxpool_fwd, grid, dim3(kPoolTX, kPoolTY), 0, as_stream(stream), x, Hin, Win, y,
-                     reinterpret_cast<uint32_t *>(code));
-  return launch_status();
+  return launch_pad_maxpool_fwd(kPoolDefaultMode, x, NC, Hin, Win, y, reinterpret_cast<uint32_t *>(code), as_stream(stream));
 }
 
 int dp_pad_maxpool_bwd(const float *dy, const uint8_t *code, int64_t NC, int Hin, int Win, float *dx,
@@ -2345,9 +2580,7 @@ int dp_pad_maxpool_bwd(const float *dy, const uint8_t *code, int64_t NC, int Hin
   DP_REQUIRE(dy && dx && code && aligned16(dx) && aligned16(dy) && (reinterpret_cast<uintptr_t>(code) & 3u) == 0);
   DP_REQUIRE(NC > 0 && Hin >= 2 && Win >= 8 && (Hin & 1) == 0 && (Win & 7) == 0);
   DP_REQUIRE(NC <= 0x7fffffffL);
-  const dim3 grid((unsigned)NC, (unsigned)cdiv(Hin, kPoolTY));
-  hipLaunchKernelGGL(k_pad_maxpool_bwd, grid, dim3(kPoolTX, kPoolTY), 0, as_stream(stream), dy, code, Hin, Win, dx);
-  return launch_status();
+  return launch_pad_maxpool_bwd(kPoolDefaultMode, dy, code, NC, Hin, Win, dx, as_stream(stream));
 }
 
 int dp_stem_dgrad(const float *dy, const float *w, int N, int K, int Ho, int Wo, float *dx,

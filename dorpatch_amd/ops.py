@@ -178,8 +178,9 @@ def apply_bwd(G, table, idx, idx2=None, norm=RAW_NORM, B=None, out=None, accumul
 
 
 # ---------------------------------------------------------------- extension: affine placement (dorpatch_amd/placement.py)
-def apply_affine_fwd(x, delta, theta, table, idx, idx2=None, norm=RAW_NORM, out=None):
-    """occlude(norm(x + warp(delta, theta[b,s]))) for B images x S samples -> (B*S,3,H,W); theta (B,S,2,3) fp32."""
+def apply_affine_fwd(x, delta, theta, table, idx, idx2=None, norm=RAW_NORM, out=None, timer=None):
+    """occlude(norm(x + warp(delta, theta[b,s]))) for B images x S samples -> (B*S,3,H,W); theta (B,S,2,3) fp32.
+    ``timer`` (a KernelTimer) makes the launch stamp kernel-begin / kernel-end events."""
     lib = _lib.load()
     _chk(x, torch.float32, "x"), _chk(delta, torch.float32, "delta"), _chk(theta, torch.float32, "theta")
     _chk(table, torch.int32, "table")
@@ -189,9 +190,14 @@ def apply_affine_fwd(x, delta, theta, table, idx, idx2=None, norm=RAW_NORM, out=
     assert tuple(theta.shape) == (B, S, 2, 3)
     if out is None:
         out = torch.empty((B * S, 3, H, W), dtype=torch.float32, device=x.device)
-    _lib.check(lib.dp_apply_affine_fwd(_p(x), _p(delta), _p(theta), _p(table), table.shape[1], _p(idx), _p(idx2),
-                                       bstride, B, S, H, W, ctypes.byref(norm), _p(out), _stream()),
-               "dp_apply_affine_fwd")
+    if timer is None:
+        _lib.check(lib.dp_apply_affine_fwd(_p(x), _p(delta), _p(theta), _p(table), table.shape[1], _p(idx), _p(idx2),
+                                           bstride, B, S, H, W, ctypes.byref(norm), _p(out), _stream()),
+                   "dp_apply_affine_fwd")
+    else:
+        _lib.check(lib.dp_apply_affine_fwd_timed(_p(x), _p(delta), _p(theta), _p(table), table.shape[1], _p(idx),
+                                                 _p(idx2), bstride, B, S, H, W, ctypes.byref(norm), _p(out), _stream(),
+                                                 timer.start, timer.stop), "dp_apply_affine_fwd_timed")
     return out
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DP_ABI_VERSION 6
+#define DP_ABI_VERSION 7
 #define DP_MAX_RECTS 4 /* occlusion windows per mask-table entry */
 
 typedef void *dp_stream_t; /* hipStream_t */
@@ -292,6 +292,11 @@ int dp_apply_fwd_timed(const float *adv_x, const int32_t *table, int R, const in
                        const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
                        const dp_norm_t *norm, float *out, dp_stream_t stream, dp_event_t start,
                        dp_event_t stop);
+/* the same for the placement extension's forward (bench.py --placement) */
+int dp_apply_affine_fwd_timed(const float *x, const float *delta, const float *theta, const int32_t *table, int R,
+                              const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
+                              const dp_norm_t *norm, float *out, dp_stream_t stream, dp_event_t start,
+                              dp_event_t stop);
 
 #ifdef __cplusplus
 }

@@ -445,6 +445,13 @@ int main(int argc, char **argv) {
             [&] { DP(dp_pad_maxpool_fwd(px, NC5, 112, 112, py, pcode, st)); });
       bench("dp_pad_maxpool_bwd 512x64x112x112 rnd", pe5 * 5.25, iters, st,
             [&] { DP(dp_pad_maxpool_bwd(pdy, pcode, NC5, 112, 112, pdx, st)); });
+      for (int mode = 0; mode < 3; ++mode) {   // which rows a workgroup owns (see k_pad_maxpool_fwd)
+        char name[64];
+        snprintf(name, sizeof name, "  pad_maxpool_fwd mode %d, 512 rnd", mode);
+        bench(name, pe5 * 5.25, iters, st, [&] { DP(launch_pad_maxpool_fwd(mode, px, NC5, 112, 112, py, (uint32_t *)pcode, st)); });
+        snprintf(name, sizeof name, "  pad_maxpool_bwd mode %d, 512 rnd", mode);
+        bench(name, pe5 * 5.25, iters, st, [&] { DP(launch_pad_maxpool_bwd(mode, pdy, pcode, NC5, 112, 112, pdx, st)); });
+      }
       CK(hipFree(px)); CK(hipFree(pdx)); CK(hipFree(py)); CK(hipFree(pdy)); CK(hipFree(pcode));
     }
     float *wst = (float *)dmalloc(64 * 147 * 4);
@@ -486,6 +493,44 @@ int main(int argc, char **argv) {
       ms /= iters;
       printf("%-34s %9.4f ms  %12.3e flop  %8.2f TFLOP/s  %5.1f%% of 157.3 TF fp32\n", "dp_stem_dgrad 256x64x112x112", ms,
              flop, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 1.573);
+    }
+  }
+  // ---- a-8 at 384 x 384 (BASELINE configs[2], 64 samples): the large-group GroupNorm backward — register / LDS resident
+  // (k_gn_relu_bwd_big) vs the round-2 streaming kernel (variant bit 8)
+  if (H == 384 && (!g_filter || strstr(g_filter, "gn_relu"))) {
+    const int Nb = 64;
+    struct Shape { int C, HW; const char *what; };
+    const Shape shapes[] = {{256, 9216, "256ch@96x96 (V=18)"}, {128, 9216, "128ch@96x96 (V=9)"}, {512, 2304, "512ch@48x48 (V=9)"}};
+    const size_t maxe = (size_t)Nb * 256 * 9216;
+    float *gx = (float *)dmalloc(maxe * 4), *gy = (float *)dmalloc(maxe * 4), *gr = (float *)dmalloc(maxe * 4);
+    float *gs = (float *)dmalloc(maxe * 4);
+    float *gam = (float *)dmalloc(2048 * 4), *bet = (float *)dmalloc(2048 * 4);
+    float *gmean = (float *)dmalloc(Nb * 32 * 4), *grstd = (float *)dmalloc(Nb * 32 * 4);
+    {
+      std::vector<float> h(1 << 22);
+      std::normal_distribution<float> Nrm(0.3f, 1.5f);
+      for (auto &v : h) v = Nrm(rng);
+      for (float *dst : {gx, gy, gr})
+        for (size_t off = 0; off < maxe; off += h.size())
+          CK(hipMemcpy(dst + off, h.data(), std::min(h.size(), maxe - off) * 4, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(k_fill, dim3(8), dim3(256), 0, st, (f4 *)gam, 512, 1.f);
+    hipLaunchKernelGGL(k_fill, dim3(8), dim3(256), 0, st, (f4 *)bet, 512, 0.05f);
+    for (const Shape &sh : shapes) {
+      const double e = (double)Nb * sh.C * sh.HW;
+      GnArgs A;
+      DP(gn_check(gx, gam, bet, Nb, sh.C, sh.HW, 32, A, 1e-5f));
+      DP(launch_gn_fwd(kGnDefaultVariant, A, Nb, gs, gmean, grstd, st));       // real statistics for the backward
+      char name[96];
+      for (int big = 1; big >= 0; --big) {
+        const int variant = kGnDefaultVariant | (big ? 0 : kGnStreamLarge);
+        snprintf(name, sizeof name, "gn_relu_bwd %s %s", big ? "on-chip  " : "streaming", sh.what);
+        bench(name, e * 12, iters, st, [&] { DP(launch_gn_bwd(variant, A, Nb, gy, gmean, grstd, gs, st)); });
+        GnArgs Ad = A;
+        Ad.dres = gr;
+        snprintf(name, sizeof name, "gn_relu_bwd+dres %s %s", big ? "on-chip  " : "streaming", sh.what);
+        bench(name, e * 16, iters, st, [&] { DP(launch_gn_bwd(variant, Ad, Nb, gy, gmean, grstd, gs, st)); });
+      }
     }
   }
   CK(hipStreamSynchronize(st));
