@@ -380,9 +380,12 @@ __device__ __forceinline__ void affine_src(const Affine &A, int ox, int oy, floa
 //             hits in row-major order of the outputs, samples ascending: deterministic.
 // A footprint that does not fit the LDS budget (extreme scale / rotation) takes the round-2 per-pixel code (slow path,
 // same arithmetic).  Identity placement stays bit-identical to dp_apply_fwd / dp_apply_bwd.
-constexpr int kAffT = 32;            // tile side
+constexpr int kAffT = 32;            // tile side (forward: 32 x 32 outputs; backward: 32 x kAffTB source pixels)
+constexpr int kAffTB = 16;
 constexpr int kAffCapF = 48 * 48;    // forward: source-footprint pixels per channel in LDS (27 KiB for 3 channels)
-constexpr int kAffCapB = 48 * 48;    // backward: staged output pixels (6 dwords each: 54 KiB)
+constexpr int kAffRowsF = 12;        // ... in at most 12 rows per wave (48 rows)
+constexpr int kAffRowsB = 8;         // backward: staged output region of at most 64 x 32 pixels, 8 rows per wave
+constexpr int kAffCapB = 64 * 4 * kAffRowsB;   // 6 dwords each: 48 KiB
 
 __device__ __forceinline__ bool occluded1(const int32_t *__restrict__ t, int R, int h, int w) {
   bool occ = false;
@@ -442,37 +445,56 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_fwd(
   const bool finite = fabsf(fx_lo) < 1e6f && fabsf(fx_hi) < 1e6f && fabsf(fy_lo) < 1e6f && fabsf(fy_hi) < 1e6f;
   const int rx0 = finite ? (int)floorf(fx_lo) - 1 : 0, ry0 = finite ? (int)floorf(fy_lo) - 1 : 0;
   const int RW = finite ? (int)floorf(fx_hi) + 2 - rx0 + 1 : 1 << 20, RH = finite ? (int)floorf(fy_hi) + 2 - ry0 + 1 : 1;
-  const bool staged = RW <= 64 && RW * RH <= kAffCapF;   // wave-uniform
+  const bool staged = RW <= 64 && RH <= kAffRowsF * (kBlock / 64) && RW * RH <= kAffCapF;   // wave-uniform
+
+  // this lane's own pixels of x: requested before the staging traffic, consumed after the barrier
+  const int oy = ty0 + (threadIdx.x >> 3), ox = tx0 + ((threadIdx.x & 7) << 2);
+  const bool mine = oy < H && ox < W;
+  const int g = mine ? (oy * W + ox) >> 2 : 0;
+  f4 xv[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) xv[c] = reinterpret_cast<const f4 *>(xb + (size_t)c * P)[g];
 
   if (staged) {
+    // one wave per footprint row, kAffRowsF rows per wave: ALL loads are issued before the first LDS store (a load /
+    // store pair per loop iteration would serialise ~11 memory round trips per workgroup — the first tiled version,
+    // 0.63 ms per launch, profiles/r03b_kbench_affine.txt)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int gx = rx0 + lane;
     const bool colok = lane < RW && gx >= 0 && gx < W;
-    for (int ry = wv; ry < RH; ry += kBlock / 64) {
-      const int gy = ry0 + ry;
-      const bool ok = colok && gy >= 0 && gy < H;
+    float v[kAffRowsF][3];
+#pragma unroll
+    for (int i = 0; i < kAffRowsF; ++i) {
+      const int gy = ry0 + wv + i * (kBlock / 64);
+      const bool ok = colok && gy >= 0 && gy < H && wv + i * (kBlock / 64) < RH;
       const size_t o = (size_t)(ok ? gy : 0) * W + (ok ? gx : 0);
-      const float v0 = db[o], v1 = db[P + o], v2 = db[2 * (size_t)P + o];   // all three issued before the first use
-      if (lane < RW) {
-        sd[ry * RW + lane] = ok ? v0 : 0.f;
-        sd[kAffCapF + ry * RW + lane] = ok ? v1 : 0.f;
-        sd[2 * kAffCapF + ry * RW + lane] = ok ? v2 : 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float t = db[(size_t)c * P + o];
+        v[i][c] = ok ? t : 0.f;
+      }
+    }
+    if (lane < RW) {
+#pragma unroll
+      for (int i = 0; i < kAffRowsF; ++i) {
+        const int ry = wv + i * (kBlock / 64);
+        if (ry < RH) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) sd[c * kAffCapF + ry * RW + lane] = v[i][c];
+        }
       }
     }
   }
   __syncthreads();
 
-  const int oy = ty0 + (threadIdx.x >> 3), ox = tx0 + ((threadIdx.x & 7) << 2);
-  if (oy >= H || ox >= W) return;
-  const int g = (oy * W + ox) >> 2;
+  if (!mine) return;
   const int m1 = idx[(size_t)b * idx_bstride + s];
   unsigned occ = occluded4(table, R, m1, oy, ox);
   if (idx2) occ |= occluded4(table, R, idx2[(size_t)b * idx_bstride + s], oy, ox);
   float v[3][4];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const f4 xv = reinterpret_cast<const f4 *>(xb + (size_t)c * P)[g];
-    v[c][0] = xv.x; v[c][1] = xv.y; v[c][2] = xv.z; v[c][3] = xv.w;
+    v[c][0] = xv[c].x; v[c][1] = xv[c].y; v[c][2] = xv[c].z; v[c][3] = xv[c].w;
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -535,8 +557,8 @@ __device__ __forceinline__ void affine_bwd_pixel_global(const Affine &A, const A
     }
 }
 
-// grid: x = 32 x 32 SOURCE tiles, y = S-slab, z = image.  Thread (ly = tid / 8, lx = 4 * (tid % 8)) owns source pixels
-// (ty0 + ly, tx0 + lx .. + 3) x 3 channels.  theta_inv (B,S,6) is the inverse map supplied by the host; it only
+// grid: x = 32 x 16 SOURCE tiles, y = S-slab, z = image.  Thread (ly = tid / 16, lx = 2 * (tid % 16)) owns source pixels
+// (ty0 + ly, tx0 + lx .. + 1) x 3 channels.  theta_inv (B,S,6) is the inverse map supplied by the host; it only
 // positions the staged region and the candidate windows (both carry a margin), never a weight.
 __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
     const float *__restrict__ G, const float *__restrict__ theta, const float *__restrict__ theta_inv,
@@ -548,17 +570,17 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
   __shared__ int stap[kAffCapB];
   const int P = H * W;
   const int b = blockIdx.z, z = blockIdx.y;
-  const int tx0 = (blockIdx.x % tiles_x) * kAffT, ty0 = (blockIdx.x / tiles_x) * kAffT;
-  const int py = ty0 + (threadIdx.x >> 3), px0 = tx0 + ((threadIdx.x & 7) << 2);
-  const bool mine = py < H && px0 < W;
+  const int tx0 = (blockIdx.x % tiles_x) * kAffT, ty0 = (blockIdx.x / tiles_x) * kAffTB;
+  const int py = ty0 + (threadIdx.x >> 4), px0 = tx0 + ((threadIdx.x & 15) << 1);
+  const bool mine = py < H && px0 < W;   // W % 4 == 0: px0 + 1 < W as well
   const int s_begin = z * s_per_slab, s_end = min(S, s_begin + s_per_slab);
-  float acc[4][3];
+  float acc[2][3];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int c = 0; c < 3; ++c) acc[j][c] = 0.f;
   // source box whose taps this workgroup owns, expanded by one pixel: an output contributes iff floor(src) lies in it
-  const float bx0 = (float)(tx0 - 1), bx1 = (float)min(tx0 + kAffT, W), by0 = (float)(ty0 - 1), by1 = (float)min(ty0 + kAffT, H);
+  const float bx0 = (float)(tx0 - 1), bx1 = (float)min(tx0 + kAffT, W), by0 = (float)(ty0 - 1), by1 = (float)min(ty0 + kAffTB, H);
   for (int s = s_begin; s < s_end; ++s) {
     const Affine A = load_affine(theta, (size_t)b * S + s);
     const Affine Ai = load_affine(theta_inv, (size_t)b * S + s);
@@ -574,50 +596,60 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
     const int qx0 = finite ? max(0, (int)floorf(qx_lo) - 2) : 0, qx1 = finite ? min(W - 1, (int)ceilf(qx_hi) + 2) : W - 1;
     const int qy0 = finite ? max(0, (int)floorf(qy_lo) - 2) : 0, qy1 = finite ? min(H - 1, (int)ceilf(qy_hi) + 2) : H - 1;
     const int QW = qx1 - qx0 + 1, QH = qy1 - qy0 + 1;
-    if (finite && (QW <= 0 || QH <= 0)) continue;       // no output maps near this tile (wave-uniform)
+    if (finite && (QW <= 0 || QH <= 0)) continue;       // no output maps near this tile (block-uniform)
     const float ex = fabsf(Ai.a00) + fabsf(Ai.a01), ey = fabsf(Ai.a10) + fabsf(Ai.a11);
     const int kx = (int)ceilf(ex + 0.01f), ky = (int)ceilf(ey + 0.01f);
-    const bool staged = finite && QW <= 64 && QW * QH <= kAffCapB && kx <= 4 && ky <= 4;
+    const bool staged = finite && QW <= 64 && QH <= kAffRowsB * (kBlock / 64) && kx <= 4 && ky <= 4;
     if (!staged) {   // slow path: per-pixel walk over global memory
       if (mine) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) affine_bwd_pixel_global(A, Ai, Gs, t1, t2, R, P, H, W, px0 + j, py, acc[j]);
+        for (int j = 0; j < 2; ++j) affine_bwd_pixel_global(A, Ai, Gs, t1, t2, R, P, H, W, px0 + j, py, acc[j]);
       }
       continue;
     }
-    __syncthreads();   // the previous sample's gather is done with the staging buffers
     {
+      // stage the region: one wave per output row, kAffRowsB rows per wave, all 3 * kAffRowsB loads in flight at once
       const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
       const int ox = qx0 + lane;
       const bool colok = lane < QW;
-      for (int qy = wv; qy < QH; qy += kBlock / 64) {
+      float gv[kAffRowsB][3];
+#pragma unroll
+      for (int i = 0; i < kAffRowsB; ++i) {
+        const int qy = wv + i * (kBlock / 64);
+        const bool ok = colok && qy < QH;
+        const size_t o = (size_t)(ok ? qy0 + qy : qy0) * W + (ok ? ox : qx0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gv[i][c] = Gs[(size_t)c * P + o];
+      }
+      __syncthreads();   // the previous sample's gather is done with the staging buffers
+#pragma unroll
+      for (int i = 0; i < kAffRowsB; ++i) {
+        const int qy = wv + i * (kBlock / 64);
+        if (qy >= QH) break;            // wave-uniform
         const int oy = qy0 + qy;
-        const size_t o = (size_t)oy * W + (colok ? ox : qx0);
-        const float g0 = Gs[o], g1 = Gs[P + o], g2 = Gs[2 * (size_t)P + o];
         float sx, sy;
         affine_src(A, ox, oy, sx, sy);   // the forward's own expression: identical weights
         const float fx0 = floorf(sx), fy0 = floorf(sy);
         // tap record: floor(src) relative to (tile origin - 2), 0 = not a neighbour of this tile
         const float rx = fx0 - (float)(tx0 - 2), ry = fy0 - (float)(ty0 - 2);
-        const bool near = rx >= 0.f && rx < (float)(kAffT + 4) && ry >= 0.f && ry < (float)(kAffT + 4);
+        const bool near = rx >= 0.f && rx < (float)(kAffT + 4) && ry >= 0.f && ry < (float)(kAffTB + 4);
         const bool keep = !(occluded1(t1, R, oy, ox) || (t2 && occluded1(t2, R, oy, ox)));
         if (colok) {
           const int e = qy * QW + lane;
           stap[e] = near ? (1 + (int)rx + ((int)ry << 8)) : 0;
           swx[e] = sx - fx0;
           swy[e] = sy - fy0;
-          sg[e] = keep ? g0 : 0.f;
-          sg[kAffCapB + e] = keep ? g1 : 0.f;
-          sg[2 * kAffCapB + e] = keep ? g2 : 0.f;
+          sg[e] = keep ? gv[i][0] : 0.f;
+          sg[kAffCapB + e] = keep ? gv[i][1] : 0.f;
+          sg[2 * kAffCapB + e] = keep ? gv[i][2] : 0.f;
         }
       }
     }
     __syncthreads();
     if (mine) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 2; ++j) {
         const int px = px0 + j;
-        if (px >= W) break;
         float cx, cy;
         affine_src(Ai, px, py, cx, cy);
         // candidates: outputs within (ex, ey) of the inverse image of the pixel; o - floor(c) in [1 - k, k]
@@ -632,7 +664,6 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
             const int e = qy * QW + qx;
             const int d = want - stap[e];   // (px - x0) + 256 * (py - y0): 0, 1, 256 or 257 for the four taps
             if (d != 0 && d != 1 && d != 256 && d != 257) continue;
-            if (stap[e] == 0) continue;
             const float fx = swx[e], fy = swy[e];
             float wgt = (d & 1) ? fx : 1.f - fx;
             wgt = ((d >> 8) ? fy : 1.f - fy) * wgt;
@@ -648,9 +679,10 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
   float *dst = slabs + ((size_t)z * B + b) * 3 * P + (size_t)py * W + px0;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    f4 o = f4{acc[0][c], acc[1][c], acc[2][c], acc[3][c]};
-    if (nd.enable) o = o / nd.std[c];
-    *reinterpret_cast<f4 *>(dst + (size_t)c * P) = o;
+    float o0 = acc[0][c], o1 = acc[1][c];
+    if (nd.enable) { o0 = o0 / nd.std[c]; o1 = o1 / nd.std[c]; }
+    dst[(size_t)c * P] = o0;
+    dst[(size_t)c * P + 1] = o1;
   }
 }
 
@@ -1712,7 +1744,66 @@ __global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_bwd(const flo
   }
 }
 
-constexpr int kPoolDefaultMode = 1;
+// MODE 3 of the backward: one thread = 8 consecutive input pixels of BOTH rows 2a and 2a + 1 (four float4 stores).  The
+// pair needs output rows a and a + 1 only (the even row's single window row is shared with the odd row), i.e. 2 instead
+// of 3 (dy float4 + code word + halo) load groups per 64 bytes stored, and ALL of them are issued before the first use
+// (the per-row form fetched the odd rows' second window row only after finishing the first: two dependent round trips).
+// Same summation order per pixel as the per-row form: bit-identical.  Workgroups in linear order (as MODE 1).
+__global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_bwd_pair(const float *__restrict__ dy,
+                                                                            const uint8_t *__restrict__ code,
+                                                                            int Hin, int Win, int nrg,
+                                                                            float *__restrict__ dx) {
+  const int Ho = Hin >> 1, Wo = Win >> 1, W8 = Win >> 3;
+  const long nc = blockIdx.x / (unsigned)nrg;
+  const int rg = (int)(blockIdx.x - (unsigned)nc * (unsigned)nrg);
+  const int a = rg * kPoolTY + threadIdx.y;
+  if (a >= Ho) return;
+  const float *dyp = dy + nc * (long)Ho * Wo;
+  const uint8_t *cp = code + nc * (long)Ho * Wo;
+  for (int t = threadIdx.x; t < W8; t += kPoolTX) {
+    const bool has_b = a + 1 < Ho, has4 = (4 * t + 4) < Wo;
+    const long base_a = (long)a * Wo + 4 * t, base_b = (long)(has_b ? a + 1 : a) * Wo + 4 * t;
+    const f4 ga4 = *reinterpret_cast<const f4 *>(dyp + base_a);
+    const f4 gb4 = *reinterpret_cast<const f4 *>(dyp + base_b);
+    const uint32_t ca4 = *reinterpret_cast<const uint32_t *>(cp + base_a);
+    const uint32_t cb4 = *reinterpret_cast<const uint32_t *>(cp + base_b);
+    const float gah = dyp[base_a + (has4 ? 4 : 0)], gbh = dyp[base_b + (has4 ? 4 : 0)];
+    const unsigned cah = cp[base_a + (has4 ? 4 : 0)], cbh = cp[base_b + (has4 ? 4 : 0)];
+    const float ga[5] = {ga4.x, ga4.y, ga4.z, ga4.w, has4 ? gah : 0.f};
+    const float gb[5] = {gb4.x, gb4.y, gb4.z, gb4.w, has4 ? gbh : 0.f};
+    const unsigned ca[5] = {ca4 & 255u, (ca4 >> 8) & 255u, (ca4 >> 16) & 255u, ca4 >> 24, has4 ? cah : 255u};
+    const unsigned cb[5] = {has_b ? (cb4 & 255u) : 255u, has_b ? ((cb4 >> 8) & 255u) : 255u, has_b ? ((cb4 >> 16) & 255u) : 255u,
+                            has_b ? (cb4 >> 24) : 255u, (has_b && has4) ? cbh : 255u};
+    float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {  // even input row 2a: window row a at r = 1 (codes 3, 4, 5)
+      e[2 * l] += (ca[l] == 4u) ? ga[l] : 0.f;
+      e[2 * l + 1] += (ca[l] == 5u) ? ga[l] : 0.f;
+      e[2 * l + 1] += (ca[l + 1] == 3u) ? ga[l + 1] : 0.f;
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {  // odd input row 2a + 1: window row a at r = 2 (codes 6, 7, 8) ...
+      o[2 * l] += (ca[l] == 7u) ? ga[l] : 0.f;
+      o[2 * l + 1] += (ca[l] == 8u) ? ga[l] : 0.f;
+      o[2 * l + 1] += (ca[l + 1] == 6u) ? ga[l + 1] : 0.f;
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {  // ... then window row a + 1 at r = 0 (codes 0, 1, 2)
+      o[2 * l] += (cb[l] == 1u) ? gb[l] : 0.f;
+      o[2 * l + 1] += (cb[l] == 2u) ? gb[l] : 0.f;
+      o[2 * l + 1] += (cb[l + 1] == 0u) ? gb[l + 1] : 0.f;
+    }
+    f4 *dst0 = reinterpret_cast<f4 *>(dx) + 2 * ((nc * Hin + 2 * a) * W8 + t);
+    f4 *dst1 = dst0 + 2 * W8;
+    __builtin_nontemporal_store(f4{e[0], e[1], e[2], e[3]}, dst0);
+    __builtin_nontemporal_store(f4{e[4], e[5], e[6], e[7]}, dst0 + 1);
+    __builtin_nontemporal_store(f4{o[0], o[1], o[2], o[3]}, dst1);
+    __builtin_nontemporal_store(f4{o[4], o[5], o[6], o[7]}, dst1 + 1);
+  }
+}
+
+constexpr int kPoolDefaultMode = 1;      // forward (profiles/r03b_kbench_pool.txt)
+constexpr int kPoolBwdDefaultMode = 3;   // backward
 
 int launch_pad_maxpool_fwd(int mode, const float *x, int64_t NC, int Hin, int Win, float *y, uint32_t *code4,
                            hipStream_t st) {
@@ -1728,8 +1819,13 @@ int launch_pad_maxpool_fwd(int mode, const float *x, int64_t NC, int Hin, int Wi
 int launch_pad_maxpool_bwd(int mode, const float *dy, const uint8_t *code, int64_t NC, int Hin, int Win, float *dx,
                            hipStream_t st) {
   const int nrg = cdiv(Hin, kPoolTY);
-  DP_REQUIRE(mode >= 0 && mode <= 2 && (mode != 1 || NC * nrg <= 0x7fffffffL));
+  DP_REQUIRE(mode >= 0 && mode <= 3 && (mode == 0 || mode == 2 || NC * nrg <= 0x7fffffffL));
   const dim3 block(kPoolTX, kPoolTY);
+  if (mode == 3) {
+    const int nrg2 = cdiv(Hin >> 1, kPoolTY);
+    hipLaunchKernelGGL(k_pad_maxpool_bwd_pair, dim3((unsigned)(NC * nrg2)), block, 0, st, dy, code, Hin, Win, nrg2, dx);
+    return launch_status();
+  }
   if (mode == 0) hipLaunchKernelGGL(k_pad_maxpool_bwd<0>, dim3((unsigned)NC, (unsigned)nrg), block, 0, st, dy, code, Hin, Win, nrg, dx);
   else if (mode == 1) hipLaunchKernelGGL(k_pad_maxpool_bwd<1>, dim3((unsigned)(NC * nrg)), block, 0, st, dy, code, Hin, Win, nrg, dx);
   else hipLaunchKernelGGL(k_pad_maxpool_bwd<2>, dim3((unsigned)NC), block, 0, st, dy, code, Hin, Win, nrg, dx);
@@ -2113,7 +2209,8 @@ inline void gn_pick(int L4, int &V, int &T) {
 // (shape, direction, residual) cases, by 8-21 % over neither; MW8 wins only for the forward without residual
 // (256ch@56x56: 0.270 vs 0.284 ms) and loses with it, so it is applied to that case alone.
 //   8 = (kbench A/B only) groups larger than V = 7 through the streaming backward, as in round 2.
-constexpr int kGnNT = 1, kGnLC = 2, kGnMW8 = 4, kGnStreamLarge = 8;
+//  16 = (kbench A/B) the large-group backward loads all of an operand half at once (9 float4 per batch instead of 3).
+constexpr int kGnNT = 1, kGnLC = 2, kGnMW8 = 4, kGnStreamLarge = 8, kGnBigBatch = 16;
 constexpr int kGnDefaultVariant = kGnNT | kGnLC;
 
 #define DP_GN_FWD_VT(V_, T_, NT_, LC_, MW_) \
@@ -2170,11 +2267,13 @@ int launch_gn_bwd(int variant, const GnArgs &A, int N, const float *dy, const fl
   // gamma / beta in LDS, so groups of more than kGnLdsCh channels (and anything larger) take the streaming kernel.
   if (V > 7 && (A.Cg > kGnLdsCh || (A.HW & 3) != 0 || (variant & kGnStreamLarge))) V = 0;
   if (V == 9) {
-    hipLaunchKernelGGL((k_gn_relu_bwd_big<9, 9, 0, 3>), grid, dim3(kGnBigT), 0, st, A, dy, mean, rstd, dx);
+    if (variant & kGnBigBatch) hipLaunchKernelGGL((k_gn_relu_bwd_big<9, 9, 0, 9>), grid, dim3(kGnBigT), 0, st, A, dy, mean, rstd, dx);
+    else hipLaunchKernelGGL((k_gn_relu_bwd_big<9, 9, 0, 3>), grid, dim3(kGnBigT), 0, st, A, dy, mean, rstd, dx);
     return launch_status();
   }
-  if (V == 18) {
-    hipLaunchKernelGGL((k_gn_relu_bwd_big<18, 0, 9, 3>), grid, dim3(kGnBigT), 0, st, A, dy, mean, rstd, dx);
+  if (V == 18) {   // batches of 3 float4 per operand (120 B of scratch per lane) or of 9 (156 B, a third of the round trips)
+    if (variant & kGnBigBatch) hipLaunchKernelGGL((k_gn_relu_bwd_big<18, 0, 9, 9>), grid, dim3(kGnBigT), 0, st, A, dy, mean, rstd, dx);
+    else hipLaunchKernelGGL((k_gn_relu_bwd_big<18, 0, 9, 3>), grid, dim3(kGnBigT), 0, st, A, dy, mean, rstd, dx);
     return launch_status();
   }
   if (V == 0) {
@@ -2391,7 +2490,7 @@ int dp_apply_affine_bwd(const float *G, const float *theta, const float *theta_i
   const int s_per_slab = bwd_s_per_slab(B, S, P);
   const int nslab = cdiv(S, s_per_slab);
   DP_REQUIRE(nslab <= 65535);
-  const int tiles_x = cdiv(W, kAffT), tiles_y = cdiv(H, kAffT);
+  const int tiles_x = cdiv(W, kAffT), tiles_y = cdiv(H, kAffTB);
   hipLaunchKernelGGL(k_apply_affine_bwd, dim3(tiles_x * tiles_y, nslab, B), dim3(kBlock), 0, as_stream(stream), G,
                      theta, theta_inv, table, R, idx, idx2, idx_bstride, B, S, H, W, tiles_x, s_per_slab,
                      make_norm(norm), slabs);
@@ -2580,7 +2679,7 @@ int dp_pad_maxpool_bwd(const float *dy, const uint8_t *code, int64_t NC, int Hin
   DP_REQUIRE(dy && dx && code && aligned16(dx) && aligned16(dy) && (reinterpret_cast<uintptr_t>(code) & 3u) == 0);
   DP_REQUIRE(NC > 0 && Hin >= 2 && Win >= 8 && (Hin & 1) == 0 && (Win & 7) == 0);
   DP_REQUIRE(NC <= 0x7fffffffL);
-  return launch_pad_maxpool_bwd(kPoolDefaultMode, dy, code, NC, Hin, Win, dx, as_stream(stream));
+  return launch_pad_maxpool_bwd(kPoolBwdDefaultMode, dy, code, NC, Hin, Win, dx, as_stream(stream));
 }
 
 int dp_stem_dgrad(const float *dy, const float *w, int N, int K, int Ho, int Wo, float *dx,

