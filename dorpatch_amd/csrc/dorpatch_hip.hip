@@ -26,6 +26,7 @@
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef int i4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBlock = 256;  // threads per workgroup: 4 waves of 64
 
@@ -382,10 +383,23 @@ __device__ __forceinline__ void affine_src(const Affine &A, int ox, int oy, floa
 // same arithmetic).  Identity placement stays bit-identical to dp_apply_fwd / dp_apply_bwd.
 constexpr int kAffT = 32;            // tile side (forward: 32 x 32 outputs; backward: 32 x kAffTB source pixels)
 constexpr int kAffTB = 16;
-constexpr int kAffCapF = 48 * 48;    // forward: source-footprint pixels per channel in LDS (27 KiB for 3 channels)
-constexpr int kAffRowsF = 12;        // ... in at most 12 rows per wave (48 rows)
-constexpr int kAffRowsB = 8;         // backward: staged output region of at most 64 x 32 pixels, 8 rows per wave
-constexpr int kAffCapB = 64 * 4 * kAffRowsB;   // 6 dwords each: 48 KiB
+constexpr int kAffRowsF = 3;         // forward: footprint of at most 64 x 48 source pixels, staged 16 rows x 16 float4 per pass
+constexpr int kAffCapF = 64 * 16 * kAffRowsF;  // ... per channel: 36 KiB of LDS for the 3 channels
+constexpr int kAffRowsB = 2;         // backward: staged output region of at most 64 x 32 pixels
+constexpr int kAffCapB = 64 * 16 * kAffRowsB;  // 6 dwords each: 48 KiB
+
+// occluded4 for a table entry given by pointer
+__device__ __forceinline__ unsigned occluded4t(const int32_t *__restrict__ t, int R, int h, int w) {
+  unsigned occ = 0u;
+  for (int r = 0; r < R; ++r) {
+    const int r0 = t[4 * r + 0], r1 = t[4 * r + 1], c0 = t[4 * r + 2], c1 = t[4 * r + 3];
+    if (h >= r0 && h < r1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) occ |= (unsigned)((w + j >= c0) & (w + j < c1)) << j;
+    }
+  }
+  return occ;
+}
 
 __device__ __forceinline__ bool occluded1(const int32_t *__restrict__ t, int R, int h, int w) {
   bool occ = false;
@@ -424,8 +438,8 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_fwd(
     const int32_t *__restrict__ table, int R, const int32_t *__restrict__ idx,
     const int32_t *__restrict__ idx2, int idx_bstride, int S, int H, int W, int tiles_x, NormDev nd,
     float *__restrict__ out) {
-  __shared__ float sd[3 * kAffCapF];
-  const int P = H * W, P4 = P >> 2;
+  __shared__ __attribute__((aligned(16))) float sd[3 * kAffCapF];
+  const int P = H * W;
   const int s = blockIdx.y, b = blockIdx.z;
   const int tx0 = (blockIdx.x % tiles_x) * kAffT, ty0 = (blockIdx.x / tiles_x) * kAffT;
   const Affine A = load_affine(theta, (size_t)b * S + s);
@@ -441,11 +455,13 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_fwd(
   affine_src(A, cx1, cy1, sx11, sy11);
   const float fx_lo = fminf(fminf(sx00, sx01), fminf(sx10, sx11)), fx_hi = fmaxf(fmaxf(sx00, sx01), fmaxf(sx10, sx11));
   const float fy_lo = fminf(fminf(sy00, sy01), fminf(sy10, sy11)), fy_hi = fmaxf(fmaxf(sy00, sy01), fmaxf(sy10, sy11));
-  // [floor(lo) - 1, floor(hi) + 2]: the +1 tap and one pixel of margin either side (rounding of interior points)
+  // [floor(lo) - 1, floor(hi) + 2]: the +1 tap and one pixel of margin either side (rounding of interior points); the
+  // left edge is aligned down to a multiple of 4 pixels so that every lane stages whole, 16-byte aligned float4s
   const bool finite = fabsf(fx_lo) < 1e6f && fabsf(fx_hi) < 1e6f && fabsf(fy_lo) < 1e6f && fabsf(fy_hi) < 1e6f;
-  const int rx0 = finite ? (int)floorf(fx_lo) - 1 : 0, ry0 = finite ? (int)floorf(fy_lo) - 1 : 0;
-  const int RW = finite ? (int)floorf(fx_hi) + 2 - rx0 + 1 : 1 << 20, RH = finite ? (int)floorf(fy_hi) + 2 - ry0 + 1 : 1;
-  const bool staged = RW <= 64 && RH <= kAffRowsF * (kBlock / 64) && RW * RH <= kAffCapF;   // wave-uniform
+  const int rx0 = finite ? ((int)floorf(fx_lo) - 1) & ~3 : 0, ry0 = finite ? (int)floorf(fy_lo) - 1 : 0;
+  const int RW4 = finite ? (((int)floorf(fx_hi) + 2 - rx0) >> 2) + 1 : 1 << 20, RH = finite ? (int)floorf(fy_hi) + 2 - ry0 + 1 : 1;
+  const int RW = RW4 << 2;   // LDS row pitch
+  const bool staged = RW4 <= 16 && RH <= kAffRowsF * 16 && RW * RH <= kAffCapF;   // block-uniform
 
   // this lane's own pixels of x: requested before the staging traffic, consumed after the barrier
   const int oy = ty0 + (threadIdx.x >> 3), ox = tx0 + ((threadIdx.x & 7) << 2);
@@ -456,31 +472,31 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_fwd(
   for (int c = 0; c < 3; ++c) xv[c] = reinterpret_cast<const f4 *>(xb + (size_t)c * P)[g];
 
   if (staged) {
-    // one wave per footprint row, kAffRowsF rows per wave: ALL loads are issued before the first LDS store (a load /
-    // store pair per loop iteration would serialise ~11 memory round trips per workgroup — the first tiled version,
-    // 0.63 ms per launch, profiles/r03b_kbench_affine.txt)
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int gx = rx0 + lane;
-    const bool colok = lane < RW && gx >= 0 && gx < W;
-    float v[kAffRowsF][3];
+    // lane (row = tid / 16, col4 = tid % 16) stages one float4 of 16 footprint rows per iteration, 3 channels; ALL
+    // 3 * kAffRowsF loads are issued before the first LDS store (first tiled version: dword loads, a load / store pair
+    // per loop iteration = ~11 serialised round trips and 4x the instructions: 0.63 ms, profiles/r03b_kbench_affine.txt)
+    const int col4 = threadIdx.x & 15, row = threadIdx.x >> 4;
+    const int gx = rx0 + (col4 << 2);
+    const bool colok = col4 < RW4 && gx >= 0 && gx < W;     // aligned and W % 4 == 0: a float4 is inside or outside as a whole
+    f4 v[kAffRowsF][3];
 #pragma unroll
     for (int i = 0; i < kAffRowsF; ++i) {
-      const int gy = ry0 + wv + i * (kBlock / 64);
-      const bool ok = colok && gy >= 0 && gy < H && wv + i * (kBlock / 64) < RH;
-      const size_t o = (size_t)(ok ? gy : 0) * W + (ok ? gx : 0);
+      const int ry = row + i * 16, gy = ry0 + ry;
+      const bool ok = colok && gy >= 0 && gy < H && ry < RH;
+      const size_t o = ((size_t)(ok ? gy : 0) * W + (ok ? gx : 0)) >> 2;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        const float t = db[(size_t)c * P + o];
-        v[i][c] = ok ? t : 0.f;
+        const f4 t = reinterpret_cast<const f4 *>(db + (size_t)c * P)[o];
+        v[i][c] = ok ? t : f4{0.f, 0.f, 0.f, 0.f};
       }
     }
-    if (lane < RW) {
+    if (col4 < RW4) {
 #pragma unroll
       for (int i = 0; i < kAffRowsF; ++i) {
-        const int ry = wv + i * (kBlock / 64);
+        const int ry = row + i * 16;
         if (ry < RH) {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) sd[c * kAffCapF + ry * RW + lane] = v[i][c];
+          for (int c = 0; c < 3; ++c) *reinterpret_cast<f4 *>(sd + c * kAffCapF + ry * RW + (col4 << 2)) = v[i][c];
         }
       }
     }
@@ -565,9 +581,9 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
     const int32_t *__restrict__ table, int R, const int32_t *__restrict__ idx,
     const int32_t *__restrict__ idx2, int idx_bstride, int B, int S, int H, int W, int tiles_x, int s_per_slab,
     NormDev nd, float *__restrict__ slabs) {
-  __shared__ float sg[3 * kAffCapB];
-  __shared__ float swx[kAffCapB], swy[kAffCapB];
-  __shared__ int stap[kAffCapB];
+  __shared__ __attribute__((aligned(16))) float sg[3 * kAffCapB];
+  __shared__ __attribute__((aligned(16))) float swx[kAffCapB], swy[kAffCapB];
+  __shared__ __attribute__((aligned(16))) int stap[kAffCapB];
   const int P = H * W;
   const int b = blockIdx.z, z = blockIdx.y;
   const int tx0 = (blockIdx.x % tiles_x) * kAffT, ty0 = (blockIdx.x / tiles_x) * kAffTB;
@@ -599,7 +615,8 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
     if (finite && (QW <= 0 || QH <= 0)) continue;       // no output maps near this tile (block-uniform)
     const float ex = fabsf(Ai.a00) + fabsf(Ai.a01), ey = fabsf(Ai.a10) + fabsf(Ai.a11);
     const int kx = (int)ceilf(ex + 0.01f), ky = (int)ceilf(ey + 0.01f);
-    const bool staged = finite && QW <= 64 && QH <= kAffRowsB * (kBlock / 64) && kx <= 4 && ky <= 4;
+    const int qx0a = qx0 & ~3, QW4 = ((qx1 - qx0a) >> 2) + 1, QWp = QW4 << 2;   // left edge aligned to whole float4s
+    const bool staged = finite && QW4 <= 16 && QH <= kAffRowsB * 16 && kx <= 4 && ky <= 4;
     if (!staged) {   // slow path: per-pixel walk over global memory
       if (mine) {
 #pragma unroll
@@ -608,68 +625,83 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
       continue;
     }
     {
-      // stage the region: one wave per output row, kAffRowsB rows per wave, all 3 * kAffRowsB loads in flight at once
-      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-      const int ox = qx0 + lane;
-      const bool colok = lane < QW;
-      float gv[kAffRowsB][3];
+      // stage the region: lane (row = tid / 16, col4 = tid % 16) takes 4 consecutive outputs of 16 rows per pass; all
+      // 3 * kAffRowsB float4 loads are in flight before the barrier that retires the previous sample's gather
+      const int col4 = threadIdx.x & 15, row = threadIdx.x >> 4;
+      const int ox = qx0a + (col4 << 2);
+      const bool colok = col4 < QW4;       // qx0a >= 0 and the aligned right edge <= W - 1 (W % 4 == 0): always inside the image
+      f4 gv[kAffRowsB][3];
 #pragma unroll
       for (int i = 0; i < kAffRowsB; ++i) {
-        const int qy = wv + i * (kBlock / 64);
+        const int qy = row + i * 16;
         const bool ok = colok && qy < QH;
-        const size_t o = (size_t)(ok ? qy0 + qy : qy0) * W + (ok ? ox : qx0);
+        const size_t o = ((size_t)(ok ? qy0 + qy : qy0) * W + (ok ? ox : qx0a)) >> 2;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) gv[i][c] = Gs[(size_t)c * P + o];
+        for (int c = 0; c < 3; ++c) gv[i][c] = reinterpret_cast<const f4 *>(Gs + (size_t)c * P)[o];
       }
       __syncthreads();   // the previous sample's gather is done with the staging buffers
 #pragma unroll
       for (int i = 0; i < kAffRowsB; ++i) {
-        const int qy = wv + i * (kBlock / 64);
-        if (qy >= QH) break;            // wave-uniform
+        const int qy = row + i * 16;
+        if (!(colok && qy < QH)) continue;
         const int oy = qy0 + qy;
-        float sx, sy;
-        affine_src(A, ox, oy, sx, sy);   // the forward's own expression: identical weights
-        const float fx0 = floorf(sx), fy0 = floorf(sy);
-        // tap record: floor(src) relative to (tile origin - 2), 0 = not a neighbour of this tile
-        const float rx = fx0 - (float)(tx0 - 2), ry = fy0 - (float)(ty0 - 2);
-        const bool near = rx >= 0.f && rx < (float)(kAffT + 4) && ry >= 0.f && ry < (float)(kAffTB + 4);
-        const bool keep = !(occluded1(t1, R, oy, ox) || (t2 && occluded1(t2, R, oy, ox)));
-        if (colok) {
-          const int e = qy * QW + lane;
-          stap[e] = near ? (1 + (int)rx + ((int)ry << 8)) : 0;
-          swx[e] = sx - fx0;
-          swy[e] = sy - fy0;
-          sg[e] = keep ? gv[i][0] : 0.f;
-          sg[kAffCapB + e] = keep ? gv[i][1] : 0.f;
-          sg[2 * kAffCapB + e] = keep ? gv[i][2] : 0.f;
+        unsigned occ = occluded4t(t1, R, oy, ox);
+        if (t2) occ |= occluded4t(t2, R, oy, ox);
+        float fxs[4], fys[4];
+        int tap[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float sx, sy;
+          affine_src(A, ox + j, oy, sx, sy);   // the forward's own expression: identical weights
+          const float fx0 = floorf(sx), fy0 = floorf(sy);
+          // tap record: floor(src) relative to (tile origin - 2), 0 = not a neighbour of this tile
+          const float rx = fx0 - (float)(tx0 - 2), ry = fy0 - (float)(ty0 - 2);
+          const bool near = rx >= 0.f && rx < (float)(kAffT + 4) && ry >= 0.f && ry < (float)(kAffTB + 4);
+          tap[j] = near ? (1 + (int)rx + ((int)ry << 8)) : 0;
+          fxs[j] = sx - fx0;
+          fys[j] = sy - fy0;
         }
+        const int e = qy * QWp + (col4 << 2);
+        *reinterpret_cast<i4 *>(stap + e) = i4{tap[0], tap[1], tap[2], tap[3]};
+        *reinterpret_cast<f4 *>(swx + e) = f4{fxs[0], fxs[1], fxs[2], fxs[3]};
+        *reinterpret_cast<f4 *>(swy + e) = f4{fys[0], fys[1], fys[2], fys[3]};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) *reinterpret_cast<f4 *>(sg + c * kAffCapB + e) = select4(occ, gv[i][c], 0.f);
       }
     }
     __syncthreads();
     if (mine) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int px = px0 + j;
-        float cx, cy;
-        affine_src(Ai, px, py, cx, cy);
-        // candidates: outputs within (ex, ey) of the inverse image of the pixel; o - floor(c) in [1 - k, k]
-        const int ocx = (int)floorf(cx) - qx0, ocy = (int)floorf(cy) - qy0;
-        const int want = 1 + (px - (tx0 - 2)) + ((py - (ty0 - 2)) << 8);   // tap record of an output whose floor(src) == (px, py)
-        for (int dy = 1 - ky; dy <= ky; ++dy) {
-          const int qy = ocy + dy;
-          if (qy < 0 || qy >= QH) continue;
-          for (int dx = 1 - kx; dx <= kx; ++dx) {
-            const int qx = ocx + dx;
-            if (qx < 0 || qx >= QW) continue;
-            const int e = qy * QW + qx;
-            const int d = want - stap[e];   // (px - x0) + 256 * (py - y0): 0, 1, 256 or 257 for the four taps
-            if (d != 0 && d != 1 && d != 256 && d != 257) continue;
-            const float fx = swx[e], fy = swy[e];
-            float wgt = (d & 1) ? fx : 1.f - fx;
-            wgt = ((d >> 8) ? fy : 1.f - fy) * wgt;
-            acc[j][0] += wgt * sg[e];
-            acc[j][1] += wgt * sg[kAffCapB + e];
-            acc[j][2] += wgt * sg[2 * kAffCapB + e];
+      // the thread's two pixels share one candidate window (their inverse images are one output step apart): every
+      // staged record is read once and tested against both.  o - floor(c) lies in [1 - k, k] for either pixel.
+      float c0x, c0y, c1x, c1y;
+      affine_src(Ai, px0, py, c0x, c0y);
+      affine_src(Ai, px0 + 1, py, c1x, c1y);
+      const int fx_a = (int)floorf(fminf(c0x, c1x)), fx_b = (int)floorf(fmaxf(c0x, c1x));
+      const int fy_a = (int)floorf(fminf(c0y, c1y)), fy_b = (int)floorf(fmaxf(c0y, c1y));
+      const int cqx0 = max(fx_a + 1 - kx - qx0a, 0), cqx1 = min(fx_b + kx - qx0a, QWp - 1);
+      const int cqy0 = max(fy_a + 1 - ky - qy0, 0), cqy1 = min(fy_b + ky - qy0, QH - 1);
+      const int want0 = 1 + (px0 - (tx0 - 2)) + ((py - (ty0 - 2)) << 8);   // record of an output whose floor(src) == (px0, py)
+      for (int qy = cqy0; qy <= cqy1; ++qy) {
+        for (int e = qy * QWp + cqx0; e <= qy * QWp + cqx1; ++e) {
+          const int d0 = want0 - stap[e];   // (px - x0) + 256 * (py - y0): 0, 1, 256 or 257 for the four taps
+          const int d1 = d0 + 1;
+          const bool hit0 = ((unsigned)d0 & ~0x101u) == 0u, hit1 = ((unsigned)d1 & ~0x101u) == 0u;
+          if (!(hit0 || hit1)) continue;
+          const float fx = swx[e], fy = swy[e];
+          const float g0 = sg[e], g1 = sg[kAffCapB + e], g2 = sg[2 * kAffCapB + e];
+          if (hit0) {
+            float wgt = (d0 & 1) ? fx : 1.f - fx;
+            wgt = ((d0 >> 8) ? fy : 1.f - fy) * wgt;
+            acc[0][0] += wgt * g0;
+            acc[0][1] += wgt * g1;
+            acc[0][2] += wgt * g2;
+          }
+          if (hit1) {
+            float wgt = (d1 & 1) ? fx : 1.f - fx;
+            wgt = ((d1 >> 8) ? fy : 1.f - fy) * wgt;
+            acc[1][0] += wgt * g0;
+            acc[1][1] += wgt * g1;
+            acc[1][2] += wgt * g2;
           }
         }
       }
@@ -1630,6 +1662,7 @@ __global__ __launch_bounds__(kGnStreamT) void k_gn_relu_bwd_stream(
 // Launch geometry of both pooling kernels: blockDim (16, 8), grid (NC, rows / 8): a thread's plane, row and
 // 8-pixel column group come straight from the block / thread indices.  (A flat 1-D index needs two 64-bit
 // divisions per thread, which made these kernels instruction-bound: ~550 instructions per 32 bytes stored.)
+constexpr int kPoolRunGroups = 8;
 constexpr int kPoolTX = 16, kPoolTY = 8;   // 8 rows: 56 and 112 are multiples (a 16-row block idles 1/8 of the forward)
 
 // MODE (which rows a workgroup owns; tools/kbench sweeps them, the C ABI uses kPoolDefaultMode):
@@ -1637,7 +1670,10 @@ constexpr int kPoolTX = 16, kPoolTY = 8;   // 8 rows: 56 and 112 are multiples (
 //      planes interleaved — 3.6 TB/s for the backward in every step trace, profiles/r03a_kbench_pool.txt reproduces it
 //      with cold 512-sample operands);
 //   1  grid.x = plane * row groups + row group: consecutive workgroups write consecutive 3.5 KiB pieces (a linear stream);
-//   2  one workgroup per plane, looping over its row groups (50 KiB contiguous per workgroup).
+//   2  one workgroup per plane, looping over its row groups (50 KiB contiguous per workgroup, but the workgroups in
+//      flight are again spread over thousands of planes: as slow as 0);
+//   4  linear order like 1, each workgroup a run of kPoolRunGroups consecutive row groups (28 KiB contiguous in the
+//      backward): the write-only calibration reaches 5.7 TB/s for exactly that shape (32 KiB per workgroup, in order).
 template <int MODE>
 __global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_fwd(const float *__restrict__ x, int Hin,
                                                                        int Win, int nrg, float *__restrict__ y,
@@ -1645,10 +1681,17 @@ __global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_fwd(const flo
   const int Ho = Hin >> 1, Wq = Win >> 3;  // Wo/4 quads per output row
   long nc;
   int rg0, rg_step;
+  int rg_end = nrg;
   if (MODE == 0) { nc = blockIdx.x; rg0 = blockIdx.y; rg_step = nrg; }
   else if (MODE == 1) { nc = blockIdx.x / (unsigned)nrg; rg0 = (int)(blockIdx.x - (unsigned)nc * (unsigned)nrg); rg_step = nrg; }
-  else { nc = blockIdx.x; rg0 = 0; rg_step = 1; }
-  for (int rg = rg0; rg < nrg; rg += rg_step) {
+  else if (MODE == 4) {
+    const unsigned runs = (unsigned)((nrg + kPoolRunGroups - 1) / kPoolRunGroups);
+    nc = blockIdx.x / runs;
+    rg0 = (int)(blockIdx.x - (unsigned)nc * runs) * kPoolRunGroups;
+    rg_step = 1;
+    rg_end = min(nrg, rg0 + kPoolRunGroups);
+  } else { nc = blockIdx.x; rg0 = 0; rg_step = 1; }
+  for (int rg = rg0; rg < rg_end; rg += rg_step) {
   const int oh = rg * kPoolTY + threadIdx.y;
   if (oh >= Ho) continue;
   for (int q = threadIdx.x; q < Wq; q += kPoolTX) {
@@ -1701,10 +1744,17 @@ __global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_bwd(const flo
   const int Ho = Hin >> 1, Wo = Win >> 1, W8 = Win >> 3;
   long nc;
   int rg0, rg_step;
+  int rg_end = nrg;
   if (MODE == 0) { nc = blockIdx.x; rg0 = blockIdx.y; rg_step = nrg; }
   else if (MODE == 1) { nc = blockIdx.x / (unsigned)nrg; rg0 = (int)(blockIdx.x - (unsigned)nc * (unsigned)nrg); rg_step = nrg; }
-  else { nc = blockIdx.x; rg0 = 0; rg_step = 1; }
-  for (int rg = rg0; rg < nrg; rg += rg_step) {
+  else if (MODE == 4) {
+    const unsigned runs = (unsigned)((nrg + kPoolRunGroups - 1) / kPoolRunGroups);
+    nc = blockIdx.x / runs;
+    rg0 = (int)(blockIdx.x - (unsigned)nc * runs) * kPoolRunGroups;
+    rg_step = 1;
+    rg_end = min(nrg, rg0 + kPoolRunGroups);
+  } else { nc = blockIdx.x; rg0 = 0; rg_step = 1; }
+  for (int rg = rg0; rg < rg_end; rg += rg_step) {
   const int h = rg * kPoolTY + threadIdx.y;
   if (h >= Hin) continue;
   for (int t = threadIdx.x; t < W8; t += kPoolTX) {
@@ -1803,13 +1853,17 @@ __global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_bwd_pair(cons
 }
 
 constexpr int kPoolDefaultMode = 1;      // forward (profiles/r03b_kbench_pool.txt)
-constexpr int kPoolBwdDefaultMode = 3;   // backward
+constexpr int kPoolBwdDefaultMode = 1;   // backward (the row-pair form, 3, measured 0.84 vs 0.51 ms: half the threads, twice the registers)
 
 int launch_pad_maxpool_fwd(int mode, const float *x, int64_t NC, int Hin, int Win, float *y, uint32_t *code4,
                            hipStream_t st) {
   const int nrg = cdiv(Hin >> 1, kPoolTY);
-  DP_REQUIRE(mode >= 0 && mode <= 2 && (mode != 1 || NC * nrg <= 0x7fffffffL));
+  DP_REQUIRE(((mode >= 0 && mode <= 2) || mode == 4) && (mode == 0 || mode == 2 || NC * nrg <= 0x7fffffffL));
   const dim3 block(kPoolTX, kPoolTY);
+  if (mode == 4) {
+    hipLaunchKernelGGL(k_pad_maxpool_fwd<4>, dim3((unsigned)(NC * cdiv(nrg, kPoolRunGroups))), block, 0, st, x, Hin, Win, nrg, y, code4);
+    return launch_status();
+  }
   if (mode == 0) hipLaunchKernelGGL(k_pad_maxpool_fwd<0>, dim3((unsigned)NC, (unsigned)nrg), block, 0, st, x, Hin, Win, nrg, y, code4);
   else if (mode == 1) hipLaunchKernelGGL(k_pad_maxpool_fwd<1>, dim3((unsigned)(NC * nrg)), block, 0, st, x, Hin, Win, nrg, y, code4);
   else hipLaunchKernelGGL(k_pad_maxpool_fwd<2>, dim3((unsigned)NC), block, 0, st, x, Hin, Win, nrg, y, code4);
@@ -1819,7 +1873,11 @@ int launch_pad_maxpool_fwd(int mode, const float *x, int64_t NC, int Hin, int Wi
 int launch_pad_maxpool_bwd(int mode, const float *dy, const uint8_t *code, int64_t NC, int Hin, int Win, float *dx,
                            hipStream_t st) {
   const int nrg = cdiv(Hin, kPoolTY);
-  DP_REQUIRE(mode >= 0 && mode <= 3 && (mode == 0 || mode == 2 || NC * nrg <= 0x7fffffffL));
+  DP_REQUIRE(mode >= 0 && mode <= 4 && (mode == 0 || mode == 2 || NC * nrg <= 0x7fffffffL));
+  if (mode == 4) {
+    hipLaunchKernelGGL(k_pad_maxpool_bwd<4>, dim3((unsigned)(NC * cdiv(nrg, kPoolRunGroups))), dim3(kPoolTX, kPoolTY), 0, st, dy, code, Hin, Win, nrg, dx);
+    return launch_status();
+  }
   const dim3 block(kPoolTX, kPoolTY);
   if (mode == 3) {
     const int nrg2 = cdiv(Hin >> 1, kPoolTY);

@@ -196,7 +196,17 @@ class _Head(nn.Module):
 
     def forward(self, x):
         x = F.adaptive_avg_pool2d(x, 1)
-        return self.fc(x).flatten(1)
+        fc = self.fc
+        if not fc.weight.requires_grad and not (fc.bias is not None and fc.bias.requires_grad):
+            # frozen: the 2048 -> n_classes 1x1 convolution on a (N, 2048, 1, 1) tensor is a library call like any other —
+            # and at small N MIOpen runs it with a split-K kernel whose float atomics made the LOGITS differ between two
+            # passes (round 3, scripts/det_trace.py) while every StdConv2d was already under the determinism policy
+            from . import libconv
+            y = libconv.FrozenConvFunction.apply(x, fc.weight, (1, 1), (0, 0))
+            if fc.bias is not None:
+                y = y + fc.bias.view(1, -1, 1, 1)
+            return y.flatten(1)
+        return fc(x).flatten(1)
 
 
 class ResNetV2(nn.Module):

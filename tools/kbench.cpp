@@ -445,12 +445,41 @@ int main(int argc, char **argv) {
             [&] { DP(dp_pad_maxpool_fwd(px, NC5, 112, 112, py, pcode, st)); });
       bench("dp_pad_maxpool_bwd 512x64x112x112 rnd", pe5 * 5.25, iters, st,
             [&] { DP(dp_pad_maxpool_bwd(pdy, pcode, NC5, 112, 112, pdx, st)); });
-      for (int mode = 0; mode < 4; ++mode) {   // which rows a workgroup owns (see k_pad_maxpool_fwd)
+      for (int mode = 0; mode < 5; ++mode) {   // which rows a workgroup owns (see k_pad_maxpool_fwd)
         char name[64];
         snprintf(name, sizeof name, "  pad_maxpool_fwd mode %d, 512 rnd", mode);
-        if (mode < 3) bench(name, pe5 * 5.25, iters, st, [&] { DP(launch_pad_maxpool_fwd(mode, px, NC5, 112, 112, py, (uint32_t *)pcode, st)); });
+        if (mode != 3) bench(name, pe5 * 5.25, iters, st, [&] { DP(launch_pad_maxpool_fwd(mode, px, NC5, 112, 112, py, (uint32_t *)pcode, st)); });
         snprintf(name, sizeof name, "  pad_maxpool_bwd mode %d, 512 rnd", mode);
         bench(name, pe5 * 5.25, iters, st, [&] { DP(launch_pad_maxpool_bwd(mode, pdy, pcode, NC5, 112, 112, pdx, st)); });
+      }
+      {  // every launch mode must produce mode 1's bytes
+        int *d_diff = (int *)dmalloc(4);
+        float *py2 = (float *)dmalloc(e_out * 4);
+        uint8_t *pcode2 = (uint8_t *)dmalloc(e_out);
+        DP(launch_pad_maxpool_fwd(1, px, NC5, 112, 112, py, (uint32_t *)pcode, st));
+        for (int mode : {0, 2, 4}) {
+          DP(launch_pad_maxpool_fwd(mode, px, NC5, 112, 112, py2, (uint32_t *)pcode2, st));
+          CK(hipMemsetAsync(d_diff, 0, 4, st));
+          hipLaunchKernelGGL(k_count_diff, dim3(2048), dim3(256), 0, st, (const uint32_t *)py, (const uint32_t *)py2, e_out, d_diff);
+          hipLaunchKernelGGL(k_count_diff, dim3(2048), dim3(256), 0, st, (const uint32_t *)pcode, (const uint32_t *)pcode2, e_out / 4, d_diff);
+          int h_diff = -1;
+          CK(hipMemcpyAsync(&h_diff, d_diff, 4, hipMemcpyDeviceToHost, st));
+          CK(hipStreamSynchronize(st));
+          printf("  pad_maxpool_fwd check: mode %d vs mode 1: %d differing words\n", mode, h_diff);
+        }
+        CK(hipFree(py2)); CK(hipFree(pcode2));
+        float *pdx2 = (float *)dmalloc(e_in * 4);
+        DP(launch_pad_maxpool_bwd(1, pdy, pcode, NC5, 112, 112, pdx, st));
+        for (int mode : {0, 2, 3, 4}) {
+          DP(launch_pad_maxpool_bwd(mode, pdy, pcode, NC5, 112, 112, pdx2, st));
+          CK(hipMemsetAsync(d_diff, 0, 4, st));
+          hipLaunchKernelGGL(k_count_diff, dim3(2048), dim3(256), 0, st, (const uint32_t *)pdx, (const uint32_t *)pdx2, e_in, d_diff);
+          int h_diff = -1;
+          CK(hipMemcpyAsync(&h_diff, d_diff, 4, hipMemcpyDeviceToHost, st));
+          CK(hipStreamSynchronize(st));
+          printf("  pad_maxpool_bwd check: mode %d vs mode 1: %d differing words\n", mode, h_diff);
+        }
+        CK(hipFree(pdx2));
       }
       CK(hipFree(px)); CK(hipFree(pdx)); CK(hipFree(py)); CK(hipFree(pdy)); CK(hipFree(pcode));
     }
