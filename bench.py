@@ -263,7 +263,15 @@ def main():
     else:
         dev = torch.device(DEVICE_OVERRIDE)
     pg = None
+    json_fd = None
     if world > 1 or args.force_pg:
+        # RCCL prints a version banner ("RCCL version : ...", 5 lines) on the C stdout of rank 0; stdout must carry exactly
+        # one JSON line, so file descriptor 1 is pointed at stderr for the rest of the run and the JSON line goes to a
+        # duplicate of the original descriptor
+        if args.backend == "nccl":
+            sys.stdout.flush()
+            json_fd = os.dup(1)
+            os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -413,7 +421,10 @@ def main():
             out["value_with_sweep_amortised"] = round(B * S * 100 / (100 * dt / args.steps + dt_sweep), 2)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(H, threads=args.cpu_threads or None)
-        print(json.dumps(out))
+        if json_fd is None:
+            print(json.dumps(out))
+        else:
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
     if pg is not None:
         import torch.distributed as dist
         dist.destroy_process_group()

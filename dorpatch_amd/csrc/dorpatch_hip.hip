@@ -171,7 +171,9 @@ __device__ __forceinline__ f4 select4(unsigned occ, f4 v, float fill) {
 
 struct NormDev {
   float mean[3], std[3], fill[3];
+  float rstd[3];     // 1 / std
   int enable;
+  int rstd_exact;    // every std is a power of two: v / std == v * rstd bit for bit (the reference's NormModel: std = 0.5)
 };
 
 inline NormDev make_norm(const dp_norm_t *n) {
@@ -182,6 +184,13 @@ inline NormDev make_norm(const dp_norm_t *n) {
     d.std[c] = n->std[c];
     // occluded pixel value after the (optional) normalisation: (fill - mean) / std
     d.fill[c] = n->enable ? (n->fill - n->mean[c]) / n->std[c] : n->fill;
+    d.rstd[c] = 1.f / n->std[c];
+  }
+  d.rstd_exact = 1;
+  for (int c = 0; c < 3; ++c) {
+    int e = 0;
+    const float m = frexpf(n->std[c], &e);
+    if (!(m == 0.5f && e > -100 && e < 100)) d.rstd_exact = 0;
   }
   return d;
 }
@@ -360,9 +369,11 @@ __device__ __forceinline__ Affine load_affine(const float *__restrict__ theta, s
   return Affine{t[0], t[1], t[2], t[3], t[4], t[5]};
 }
 
+// THE source coordinate of an output pixel: every weight of the forward and of its adjoint comes from this one expression
+// (explicit fma: the file is built with -ffp-contract=off; the row term is shared by the pixels of a row).
 __device__ __forceinline__ void affine_src(const Affine &A, int ox, int oy, float &sx, float &sy) {
-  sx = (A.a00 * (float)ox + A.a01 * (float)oy) + A.t0;
-  sy = (A.a10 * (float)ox + A.a11 * (float)oy) + A.t1;
+  sx = __builtin_fmaf(A.a00, (float)ox, __builtin_fmaf(A.a01, (float)oy, A.t0));
+  sy = __builtin_fmaf(A.a10, (float)ox, __builtin_fmaf(A.a11, (float)oy, A.t1));
 }
 
 // Tiling (round 3).  Round 2's kernels issued 48 scalar global gathers per lane (forward: 1.24 ms per 64 x 32 x 224^2
@@ -387,6 +398,14 @@ constexpr int kAffRowsF = 3;         // forward: footprint of at most 64 x 48 so
 constexpr int kAffCapF = 64 * 16 * kAffRowsF;  // ... per channel: 36 KiB of LDS for the 3 channels
 constexpr int kAffRowsB = 2;         // backward: staged output region of at most 64 x 32 pixels
 constexpr int kAffCapB = 64 * 16 * kAffRowsB;  // 6 dwords each: 48 KiB
+
+// Does any window of table entry t intersect rows [h0, h1) x columns [w0, w1)?  Scalar (block-uniform) code: lets a
+// workgroup whose tile no window touches skip the per-pixel occlusion tests altogether.
+__device__ __forceinline__ bool windows_touch(const int32_t *__restrict__ t, int R, int h0, int h1, int w0, int w1) {
+  bool hit = false;
+  for (int r = 0; r < R; ++r) hit |= (t[4 * r] < h1 && t[4 * r + 1] > h0 && t[4 * r + 2] < w1 && t[4 * r + 3] > w0);
+  return hit;
+}
 
 // occluded4 for a table entry given by pointer
 __device__ __forceinline__ unsigned occluded4t(const int32_t *__restrict__ t, int R, int h, int w) {
@@ -504,9 +523,11 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_fwd(
   __syncthreads();
 
   if (!mine) return;
-  const int m1 = idx[(size_t)b * idx_bstride + s];
-  unsigned occ = occluded4(table, R, m1, oy, ox);
-  if (idx2) occ |= occluded4(table, R, idx2[(size_t)b * idx_bstride + s], oy, ox);
+  const int32_t *t1 = table + (size_t)idx[(size_t)b * idx_bstride + s] * R * 4;
+  const int32_t *t2 = idx2 ? table + (size_t)idx2[(size_t)b * idx_bstride + s] * R * 4 : nullptr;
+  unsigned occ = 0u;
+  if (windows_touch(t1, R, ty0, ty0 + kAffT, tx0, tx0 + kAffT)) occ |= occluded4t(t1, R, oy, ox);
+  if (t2 && windows_touch(t2, R, ty0, ty0 + kAffT, tx0, tx0 + kAffT)) occ |= occluded4t(t2, R, oy, ox);
   float v[3][4];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -526,7 +547,8 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_fwd(
 #pragma unroll
       for (int c = 0; c < 3; ++c) {  // tap order fixed: (y0,x0), (y0,x1), (y1,x0), (y1,x1); zeros stand for out-of-image taps
         const float *tc = t + c * kAffCapF;
-        acc[c] = (((wy0 * wx0) * tc[0] + (wy0 * wx1) * tc[1]) + (wy1 * wx0) * tc[RW]) + (wy1 * wx1) * tc[RW + 1];
+        acc[c] = __builtin_fmaf(wy1 * wx1, tc[RW + 1],
+                                __builtin_fmaf(wy1 * wx0, tc[RW], __builtin_fmaf(wy0 * wx1, tc[1], (wy0 * wx0) * tc[0])));
       }
     } else {
       affine_taps_global(A, db, P, H, W, ox + j, oy, acc);
@@ -537,7 +559,10 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_fwd(
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     f4 t = f4{v[c][0], v[c][1], v[c][2], v[c][3]};
-    if (nd.enable) t = (t - nd.mean[c]) / nd.std[c];
+    if (nd.enable) {   // reference NormModel: true division; a power-of-two std makes the reciprocal multiply identical
+      if (nd.rstd_exact) t = (t - nd.mean[c]) * nd.rstd[c];
+      else t = (t - nd.mean[c]) / nd.std[c];
+    }
     __builtin_nontemporal_store(select4(occ, t, nd.fill[c]), reinterpret_cast<f4 *>(ob + (size_t)c * P) + g);
   }
 }
@@ -639,14 +664,17 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
 #pragma unroll
         for (int c = 0; c < 3; ++c) gv[i][c] = reinterpret_cast<const f4 *>(Gs + (size_t)c * P)[o];
       }
+      const bool touch1 = windows_touch(t1, R, qy0, qy0 + QH, qx0a, qx0a + QWp);
+      const bool touch2 = t2 && windows_touch(t2, R, qy0, qy0 + QH, qx0a, qx0a + QWp);
       __syncthreads();   // the previous sample's gather is done with the staging buffers
 #pragma unroll
       for (int i = 0; i < kAffRowsB; ++i) {
         const int qy = row + i * 16;
         if (!(colok && qy < QH)) continue;
         const int oy = qy0 + qy;
-        unsigned occ = occluded4t(t1, R, oy, ox);
-        if (t2) occ |= occluded4t(t2, R, oy, ox);
+        unsigned occ = 0u;
+        if (touch1) occ |= occluded4t(t1, R, oy, ox);
+        if (touch2) occ |= occluded4t(t2, R, oy, ox);
         float fxs[4], fys[4];
         int tap[4];
 #pragma unroll
@@ -1794,6 +1822,64 @@ __global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_bwd(const flo
   }
 }
 
+// MODE 5 of the backward: MODE 1's work distribution, but the two float4 of a thread (32 adjacent bytes) are exchanged
+// through LDS so that every store INSTRUCTION writes lane-contiguous 16-byte pieces (1 KiB per wave, whole 128-byte lines)
+// instead of the first / second half of 64 thirty-two-byte chunks.  Win <= 128 (one column group per thread).
+__global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_bwd_t(const float *__restrict__ dy,
+                                                                         const uint8_t *__restrict__ code,
+                                                                         int Hin, int Win, int nrg,
+                                                                         float *__restrict__ dx) {
+  __shared__ f4 sst[kPoolTX * kPoolTY * 2];
+  const int Ho = Hin >> 1, Wo = Win >> 1, W8 = Win >> 3;
+  const long nc = blockIdx.x / (unsigned)nrg;
+  const int rg = (int)(blockIdx.x - (unsigned)nc * (unsigned)nrg);
+  const int h = rg * kPoolTY + threadIdx.y, t = threadIdx.x;
+  const bool live = h < Hin && t < W8;
+  const float *dyp = dy + nc * (long)Ho * Wo;
+  const uint8_t *cp = code + nc * (long)Ho * Wo;
+  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    const int a = h >> 1;
+    const int n_rows = (h & 1) ? 2 : 1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (k >= n_rows) break;
+      const int oh = (h & 1) ? a + k : a;
+      const int r = (h & 1) ? (k == 0 ? 2 : 0) : 1;
+      if (oh >= Ho) continue;
+      const long base = (long)oh * Wo + 4 * t;
+      const f4 g4 = *reinterpret_cast<const f4 *>(dyp + base);
+      const uint32_t c4 = *reinterpret_cast<const uint32_t *>(cp + base);
+      const bool has4 = (4 * t + 4) < Wo;
+      const float g[5] = {g4.x, g4.y, g4.z, g4.w, has4 ? dyp[base + 4] : 0.f};
+      const unsigned c[5] = {c4 & 255u, (c4 >> 8) & 255u, (c4 >> 16) & 255u, c4 >> 24, has4 ? cp[base + 4] : 255u};
+      const unsigned rc = 3u * (unsigned)r;
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        o[2 * l] += (c[l] == rc + 1u) ? g[l] : 0.f;
+        o[2 * l + 1] += (c[l] == rc + 2u) ? g[l] : 0.f;
+        o[2 * l + 1] += (c[l + 1] == rc + 0u) ? g[l + 1] : 0.f;
+      }
+    }
+  }
+  const int tl = threadIdx.y * kPoolTX + threadIdx.x;
+  sst[2 * tl] = f4{o[0], o[1], o[2], o[3]};
+  sst[2 * tl + 1] = f4{o[4], o[5], o[6], o[7]};
+  __syncthreads();
+  const int wbase = tl & ~63, lane = tl & 63;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int q = k * 64 + lane;             // 16-byte piece of this wave's 2 KiB, in address order
+    const int src = wbase + (q >> 1), half = q & 1;
+    const int sy = src / kPoolTX, sx = src - sy * kPoolTX;
+    const int hs = rg * kPoolTY + sy;
+    if (hs < Hin && sx < W8) {
+      f4 *dst = reinterpret_cast<f4 *>(dx) + 2 * ((nc * Hin + hs) * W8 + sx) + half;
+      __builtin_nontemporal_store(sst[2 * src + half], dst);
+    }
+  }
+}
+
 // MODE 3 of the backward: one thread = 8 consecutive input pixels of BOTH rows 2a and 2a + 1 (four float4 stores).  The
 // pair needs output rows a and a + 1 only (the even row's single window row is shared with the odd row), i.e. 2 instead
 // of 3 (dy float4 + code word + halo) load groups per 64 bytes stored, and ALL of them are issued before the first use
@@ -1873,7 +1959,12 @@ int launch_pad_maxpool_fwd(int mode, const float *x, int64_t NC, int Hin, int Wi
 int launch_pad_maxpool_bwd(int mode, const float *dy, const uint8_t *code, int64_t NC, int Hin, int Win, float *dx,
                            hipStream_t st) {
   const int nrg = cdiv(Hin, kPoolTY);
-  DP_REQUIRE(mode >= 0 && mode <= 4 && (mode == 0 || mode == 2 || NC * nrg <= 0x7fffffffL));
+  DP_REQUIRE(mode >= 0 && mode <= 5 && (mode == 0 || mode == 2 || NC * nrg <= 0x7fffffffL));
+  if (mode == 5 && (Win >> 3) > kPoolTX) mode = 1;      // the LDS-transposed stores handle one column group per thread
+  if (mode == 5) {
+    hipLaunchKernelGGL(k_pad_maxpool_bwd_t, dim3((unsigned)(NC * nrg)), dim3(kPoolTX, kPoolTY), 0, st, dy, code, Hin, Win, nrg, dx);
+    return launch_status();
+  }
   if (mode == 4) {
     hipLaunchKernelGGL(k_pad_maxpool_bwd<4>, dim3((unsigned)(NC * cdiv(nrg, kPoolRunGroups))), dim3(kPoolTX, kPoolTY), 0, st, dy, code, Hin, Win, nrg, dx);
     return launch_status();
