@@ -399,6 +399,44 @@ constexpr int kAffCapF = 64 * 16 * kAffRowsF;  // ... per channel: 36 KiB of LDS
 constexpr int kAffRowsB = 2;         // backward: staged output region of at most 64 x 32 pixels
 constexpr int kAffCapB = 64 * 16 * kAffRowsB;  // 6 dwords each: 48 KiB
 
+// The (<= DP_MAX_RECTS) windows of one table entry in registers (SGPRs: the entry is block-uniform).  Loaded ONCE, at the
+// top of a kernel, with straight-line scalar loads — a loop over r with a scalar load + wait per window inside the pixel
+// code costs a memory round trip per window per use.  Unused slots are empty windows.
+struct Windows {
+  int r0[DP_MAX_RECTS], r1[DP_MAX_RECTS], c0[DP_MAX_RECTS], c1[DP_MAX_RECTS];
+};
+
+__device__ __forceinline__ Windows load_windows(const int32_t *__restrict__ t, int R) {
+  Windows w;
+#pragma unroll
+  for (int r = 0; r < DP_MAX_RECTS; ++r) {
+    const bool on = t != nullptr && r < R;
+    w.r0[r] = on ? t[4 * r] : 0;
+    w.r1[r] = on ? t[4 * r + 1] : 0;
+    w.c0[r] = on ? t[4 * r + 2] : 0;
+    w.c1[r] = on ? t[4 * r + 3] : 0;
+  }
+  return w;
+}
+
+__device__ __forceinline__ bool windows_touch(const Windows &w, int h0, int h1, int w0, int w1) {
+  bool hit = false;
+#pragma unroll
+  for (int r = 0; r < DP_MAX_RECTS; ++r) hit |= (w.r0[r] < h1 && w.r1[r] > h0 && w.c0[r] < w1 && w.c1[r] > w0);
+  return hit;
+}
+
+__device__ __forceinline__ unsigned occluded4w(const Windows &w, int h, int x) {
+  unsigned occ = 0u;
+#pragma unroll
+  for (int r = 0; r < DP_MAX_RECTS; ++r) {
+    const bool row = h >= w.r0[r] && h < w.r1[r];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) occ |= (unsigned)(row & (x + j >= w.c0[r]) & (x + j < w.c1[r])) << j;
+  }
+  return occ;
+}
+
 // Does any window of table entry t intersect rows [h0, h1) x columns [w0, w1)?  Scalar (block-uniform) code: lets a
 // workgroup whose tile no window touches skip the per-pixel occlusion tests altogether.
 __device__ __forceinline__ bool windows_touch(const int32_t *__restrict__ t, int R, int h0, int h1, int w0, int w1) {
@@ -462,6 +500,8 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_fwd(
   const int s = blockIdx.y, b = blockIdx.z;
   const int tx0 = (blockIdx.x % tiles_x) * kAffT, ty0 = (blockIdx.x / tiles_x) * kAffT;
   const Affine A = load_affine(theta, (size_t)b * S + s);
+  const Windows w1 = load_windows(table + (size_t)idx[(size_t)b * idx_bstride + s] * R * 4, R);
+  const Windows w2 = load_windows(idx2 ? table + (size_t)idx2[(size_t)b * idx_bstride + s] * R * 4 : nullptr, R);
   const float *xb = x + (size_t)b * 3 * P, *db = delta + (size_t)b * 3 * P;
   float *ob = out + ((size_t)b * S + s) * 3 * P;
 
@@ -523,11 +563,9 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_fwd(
   __syncthreads();
 
   if (!mine) return;
-  const int32_t *t1 = table + (size_t)idx[(size_t)b * idx_bstride + s] * R * 4;
-  const int32_t *t2 = idx2 ? table + (size_t)idx2[(size_t)b * idx_bstride + s] * R * 4 : nullptr;
-  unsigned occ = 0u;
-  if (windows_touch(t1, R, ty0, ty0 + kAffT, tx0, tx0 + kAffT)) occ |= occluded4t(t1, R, oy, ox);
-  if (t2 && windows_touch(t2, R, ty0, ty0 + kAffT, tx0, tx0 + kAffT)) occ |= occluded4t(t2, R, oy, ox);
+  unsigned occ = 0u;   // tiles no window touches (block-uniform test) skip the per-pixel compares
+  if (windows_touch(w1, ty0, ty0 + kAffT, tx0, tx0 + kAffT)) occ |= occluded4w(w1, oy, ox);
+  if (windows_touch(w2, ty0, ty0 + kAffT, tx0, tx0 + kAffT)) occ |= occluded4w(w2, oy, ox);
   float v[3][4];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -664,8 +702,9 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
 #pragma unroll
         for (int c = 0; c < 3; ++c) gv[i][c] = reinterpret_cast<const f4 *>(Gs + (size_t)c * P)[o];
       }
-      const bool touch1 = windows_touch(t1, R, qy0, qy0 + QH, qx0a, qx0a + QWp);
-      const bool touch2 = t2 && windows_touch(t2, R, qy0, qy0 + QH, qx0a, qx0a + QWp);
+      const Windows w1 = load_windows(t1, R), w2 = load_windows(t2, R);
+      const bool touch1 = windows_touch(w1, qy0, qy0 + QH, qx0a, qx0a + QWp);
+      const bool touch2 = windows_touch(w2, qy0, qy0 + QH, qx0a, qx0a + QWp);
       __syncthreads();   // the previous sample's gather is done with the staging buffers
 #pragma unroll
       for (int i = 0; i < kAffRowsB; ++i) {
@@ -673,8 +712,8 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
         if (!(colok && qy < QH)) continue;
         const int oy = qy0 + qy;
         unsigned occ = 0u;
-        if (touch1) occ |= occluded4t(t1, R, oy, ox);
-        if (touch2) occ |= occluded4t(t2, R, oy, ox);
+        if (touch1) occ |= occluded4w(w1, oy, ox);
+        if (touch2) occ |= occluded4w(w2, oy, ox);
         float fxs[4], fys[4];
         int tap[4];
 #pragma unroll
@@ -1939,7 +1978,7 @@ __global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_bwd_pair(cons
 }
 
 constexpr int kPoolDefaultMode = 1;      // forward (profiles/r03b_kbench_pool.txt)
-constexpr int kPoolBwdDefaultMode = 1;   // backward (the row-pair form, 3, measured 0.84 vs 0.51 ms: half the threads, twice the registers)
+constexpr int kPoolBwdDefaultMode = 5;   // backward: LDS-transposed stores 0.450 ms vs 0.508 (mode 1) vs 0.837 (row pairs, 3) — profiles/r03e_kbench_pool.txt
 
 int launch_pad_maxpool_fwd(int mode, const float *x, int64_t NC, int Hin, int Win, float *y, uint32_t *code4,
                            hipStream_t st) {

@@ -39,7 +39,7 @@ def main():
     rows = load(args.path)
     t_begin = rows[0][1]
     if not args.all:
-        applies = [r for r in rows if "k_apply_fwd" in r[0]]
+        applies = [r for r in rows if "k_apply_fwd" in r[0] or "k_apply_affine_fwd" in r[0]]   # the latter: bench.py --placement
         zmax = max(r[3] for r in applies)
         full = [r for r in applies if r[3] == zmax]
         first_timed = full[-args.timed_steps][1]
