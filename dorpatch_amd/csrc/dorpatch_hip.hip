@@ -702,9 +702,10 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
 #pragma unroll
         for (int c = 0; c < 3; ++c) gv[i][c] = reinterpret_cast<const f4 *>(Gs + (size_t)c * P)[o];
       }
-      const Windows w1 = load_windows(t1, R), w2 = load_windows(t2, R);
-      const bool touch1 = windows_touch(w1, qy0, qy0 + QH, qx0a, qx0a + QWp);
-      const bool touch2 = windows_touch(w2, qy0, qy0 + QH, qx0a, qx0a + QWp);
+      // (window coordinates through the scalar cache here: holding both masks' windows in SGPRs across the sample loop
+      // measured 22 % slower — 1.90 vs 1.55 ms, profiles/r03f_kbench_affine.txt vs r03e — the kernel already uses 106 SGPRs)
+      const bool touch1 = windows_touch(t1, R, qy0, qy0 + QH, qx0a, qx0a + QWp);
+      const bool touch2 = t2 && windows_touch(t2, R, qy0, qy0 + QH, qx0a, qx0a + QWp);
       __syncthreads();   // the previous sample's gather is done with the staging buffers
 #pragma unroll
       for (int i = 0; i < kAffRowsB; ++i) {
@@ -712,8 +713,8 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
         if (!(colok && qy < QH)) continue;
         const int oy = qy0 + qy;
         unsigned occ = 0u;
-        if (touch1) occ |= occluded4w(w1, oy, ox);
-        if (touch2) occ |= occluded4w(w2, oy, ox);
+        if (touch1) occ |= occluded4t(t1, R, oy, ox);
+        if (touch2) occ |= occluded4t(t2, R, oy, ox);
         float fxs[4], fys[4];
         int tap[4];
 #pragma unroll
@@ -2155,6 +2156,77 @@ __global__ __launch_bounds__(kStemBlock) void k_stem_dgrad(const float *__restri
   }
 }
 
+// The same input gradient on the MATRIX cores (round 3, VERDICT r2 item 8: "89 TFLOP/s on paper vs today's 67: try it").
+// One GEMM instead of four: rows = 16 output quads along a row, columns = the 12 outputs of a quad (2 x 2 parities x 3
+// channels, padded to 16), K = (input channel, tap of the 4 x 4 dy patch); taps a parity does not use get a ZERO weight,
+// so 147 * 4 of the 16 * 16 MACs per (quad, channel) are useful: 57 % of the f32 MFMA rate (= the vector rate).
+//   v_mfma_f32_16x16x4_f32:  A[i][k] in lane i + 16 k,  B[k][j] in lane j + 16 k,  D[i][j] in lane j + 16 (i / 4), reg i % 4
+// A workgroup = 16 x 16 quads of one sample, 4 waves x 4 quad rows each (4 accumulators of 4 VGPRs); per group of 4
+// input channels it stages the 19 x 19 x 4 dy patch and the zero-padded 4 x 16 x 16 weight block in LDS (one barrier
+// pair), then every wave issues 16 taps x 4 rows = 64 MFMAs, each fed by one LDS read (A; B is read once per tap).
+constexpr int kMT = 16;                 // quads per tile side
+constexpr int kMP = kMT + 3;            // dy patch side
+constexpr int kMPP = 20;                // LDS row pitch of the patch
+
+__global__ __launch_bounds__(256) void k_stem_dgrad_mfma(const float *__restrict__ dy, const float *__restrict__ w,
+                                                         int K, int Ho, int Wo, float *__restrict__ dx) {
+  __shared__ float s_dy[4][kMP][kMPP];
+  __shared__ float s_w[4][16][16];      // [kk][tap = 4 r + s][col = 3 (2 ph + pw) + c]
+  const int n = blockIdx.z;
+  const int a0 = blockIdx.y * kMT, b0 = blockIdx.x * kMT;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const float *dyn = dy + (size_t)n * K * Ho * Wo;
+  f4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    __syncthreads();   // the previous group's MFMAs are done with the LDS blocks
+    for (int e = threadIdx.x; e < 4 * kMP * kMP; e += 256) {
+      const int kk = e / (kMP * kMP), rem = e - kk * (kMP * kMP);
+      const int pr = rem / kMP, pc = rem - pr * kMP;
+      const int a = a0 - 1 + pr, b = b0 - 1 + pc;
+      const bool ok = a >= 0 && a < Ho && b >= 0 && b < Wo;
+      s_dy[kk][pr][pc] = ok ? dyn[((size_t)(k0 + kk) * Ho + a) * Wo + b] : 0.f;
+    }
+    for (int e = threadIdx.x; e < 4 * 16 * 16; e += 256) {
+      const int kk = e >> 8, tap = (e >> 4) & 15, col = e & 15;
+      const int r = tap >> 2, q = tap & 3;
+      const int par = col / 3, c = col - 3 * par, ph = par >> 1, pw = par & 1;
+      const int i = ph + 5 - 2 * r, j = pw + 5 - 2 * q;
+      const bool ok = col < 12 && i >= 0 && i <= 6 && j >= 0 && j <= 6;
+      s_w[kk][tap][col] = ok ? w[((size_t)(k0 + kk) * 3 + c) * 49 + i * 7 + j] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 16; ++tap) {
+      const int r = tap >> 2, q = tap & 3;
+      const float bv = s_w[lk][tap][li];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float av = s_dy[lk][4 * wv + t + r][li + q];   // dy[k0 + lk][a - 1 + r][b0 + li - 1 + q], a = a0 + 4 wv + t
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  if (li >= 12) return;   // padding columns
+  const int par = li / 3, c = li - 3 * par, ph = par >> 1, pw = par & 1;
+  const int H = 2 * Ho, W = 2 * Wo;
+  float *dxc = dx + ((size_t)n * 3 + c) * H * W;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int a = a0 + 4 * wv + t;
+    if (a >= Ho) continue;
+    const float vals[4] = {acc[t].x, acc[t].y, acc[t].z, acc[t].w};
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int b = b0 + 4 * lk + rr;
+      if (b < Wo) dxc[(size_t)(2 * a + ph) * W + 2 * b + pw] = vals[rr];
+    }
+  }
+}
+
+
 // ----------------------------------------------------------------------------
 // a-8 + a-4 backward, fused: the stem input gradient of every EOT sample of an image, occlusion-masked and summed
 // over the samples in the same launch (k_stem_dgrad followed by k_apply_bwd, without the (N,3,H,W) per-sample
@@ -2545,6 +2617,19 @@ int launch_apply_fwd(int variant, const float *adv_x, const int32_t *table, int 
   return launch_status();
 }
 
+// variant 0: fp32 VALU gather (k_stem_dgrad); 1: matrix cores (k_stem_dgrad_mfma; needs K % 4 == 0, else 0 is used)
+constexpr int kStemDefaultVariant = 0;
+
+int launch_stem_dgrad(int variant, const float *dy, const float *w, int N, int K, int Ho, int Wo, float *dx,
+                      hipStream_t st) {
+  if (variant == 1 && (K & 3) == 0) {
+    hipLaunchKernelGGL(k_stem_dgrad_mfma, dim3(cdiv(Wo, kMT), cdiv(Ho, kMT), N), dim3(256), 0, st, dy, w, K, Ho, Wo, dx);
+    return launch_status();
+  }
+  hipLaunchKernelGGL(k_stem_dgrad, dim3(cdiv(Wo, SQ), cdiv(Ho, SQ), N), dim3(kStemBlock), 0, st, dy, w, K, Ho, Wo, dx);
+  return launch_status();
+}
+
 }  // namespace
 
 // ============================================================================
@@ -2874,9 +2959,7 @@ int dp_stem_dgrad(const float *dy, const float *w, int N, int K, int Ho, int Wo,
                   dp_stream_t stream) {
   DP_REQUIRE(dy && w && dx && N > 0 && N <= 65535 && K > 0 && Ho > 0 && Wo > 0);
   DP_REQUIRE((reinterpret_cast<uintptr_t>(dx) & 7u) == 0);
-  hipLaunchKernelGGL(k_stem_dgrad, dim3(cdiv(Wo, SQ), cdiv(Ho, SQ), N), dim3(kStemBlock), 0,
-                     as_stream(stream), dy, w, K, Ho, Wo, dx);
-  return launch_status();
+  return launch_stem_dgrad(kStemDefaultVariant, dy, w, N, K, Ho, Wo, dx, as_stream(stream));
 }
 
 int dp_stem_dgrad_reduce(const float *dy, const float *w, const int32_t *table, int R, const int32_t *idx,

@@ -536,8 +536,6 @@ def main():
         print({k: o[k].tolist() for k in ("target", "clean", "adv_pred", "n_fail", "pc_pred", "pc_cert", "steps")})
         return
     make_end_metric_fixture(os.path.join(GOLDEN_DIR, "end_metric_56.npz"))
-    make_end_metric_null_fixture(os.path.join(GOLDEN_DIR, "end_metric_null_56.npz"))
-    make_end_metric_bit_fixture(os.path.join(GOLDEN_DIR, "end_metric_bit_56.npz"))
     make_patchcleanser_fixture(os.path.join(GOLDEN_DIR, "patchcleanser_56.npz"))
     make_geometry_fixture(os.path.join(GOLDEN_DIR, "geometry.npz"))
     make_steps_fixture(56, 8, 1.0, os.path.join(GOLDEN_DIR, "steps_56.npz"))
@@ -551,6 +549,9 @@ def main():
     make_untargeted_trace_fixture(os.path.join(GOLDEN_DIR, "trace_56_untargeted.npz"))
     make_steps_fixture(56, 8, 1.5, os.path.join(GOLDEN_DIR, "steps_56_dropout1.npz"), dropout=1)
     make_untargeted_steps_fixture(os.path.join(GOLDEN_DIR, "steps_56_untargeted.npz"))
+    if "--quick" not in sys.argv:          # the two long ones last: ~6 and ~40 minutes on 8 cores
+        make_end_metric_null_fixture(os.path.join(GOLDEN_DIR, "end_metric_null_56.npz"))
+        make_end_metric_bit_fixture(os.path.join(GOLDEN_DIR, "end_metric_bit_56.npz"))
     for f in sorted(os.listdir(GOLDEN_DIR)):
         print(f, os.path.getsize(os.path.join(GOLDEN_DIR, f)))
 

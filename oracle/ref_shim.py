@@ -64,8 +64,16 @@ def _install_stubs():
     _stub("timm")
 
     if not torch.cuda.is_available():
-        # reference hard-codes .cuda(); on the CPU-only build box make it a no-op
-        torch.Tensor.cuda = lambda self, *a, **k: self
+        # The reference hard-codes .cuda() and reads results back with .cpu().numpy().  On its own platform both calls
+        # COPY (host <-> device); on the CPU-only build box they must keep doing so, or the reference silently becomes a
+        # different program: with an identity .cuda() / the stock no-op .cpu(), `adv_pattern_best_np = adv_x.cpu().numpy()`
+        # (attack.py:159) ALIASES the storage that `adv_pattern.data = adv_pattern_best.data` (attack.py:165) hands to the
+        # optimised pattern, so stage 1 returns the LAST iterate instead of the best-so-far copy it keeps on a GPU
+        # (attack.py:287-289) — found in round 3 when the product's failure counts came out 6 % below a 32-image null
+        # recorded through the aliasing shim (profiles/r03g_end_metric_debug.txt).  Tensor.cuda / Tensor.cpu therefore
+        # return differentiable copies, as a real transfer does; modules stay where they are.
+        torch.Tensor.cuda = lambda self, *a, **k: self.clone()
+        torch.Tensor.cpu = lambda self, *a, **k: self.clone()
         torch.nn.Module.cuda = lambda self, *a, **k: self
 
 

@@ -105,6 +105,18 @@ __global__ __launch_bounds__(256) void k_count_diff(const uint32_t *__restrict__
   if (local) atomicAdd(count, local);
 }
 
+// max |a - b| and max |b| over two fp32 arrays (variants that sum in another order are compared by value, not by bytes)
+__global__ __launch_bounds__(256) void k_max_diff(const float *__restrict__ a, const float *__restrict__ b, size_t n,
+                                                  unsigned *__restrict__ out /* [2]: bits of max diff, max |b| */) {
+  float d = 0.f, m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    d = fmaxf(d, fabsf(a[i] - b[i]));
+    m = fmaxf(m, fabsf(b[i]));
+  }
+  atomicMax(out, __float_as_uint(d));       // non-negative floats order like their bit patterns
+  atomicMax(out + 1, __float_as_uint(m));
+}
+
 __global__ __launch_bounds__(256) void k_readsum(const f4 *__restrict__ in, float *__restrict__ out, size_t n4) {
   f4 acc = {0.f, 0.f, 0.f, 0.f};
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
@@ -522,6 +534,31 @@ int main(int argc, char **argv) {
       ms /= iters;
       printf("%-34s %9.4f ms  %12.3e flop  %8.2f TFLOP/s  %5.1f%% of 157.3 TF fp32\n", "dp_stem_dgrad 256x64x112x112", ms,
              flop, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 1.573);
+      // the matrix-core formulation (k_stem_dgrad_mfma): same useful flops, 57 % of the issued MACs useful
+      std::vector<float> hw(64 * 147);
+      std::normal_distribution<float> Nw(0.f, 0.1f);
+      for (auto &v : hw) v = Nw(rng);
+      CK(hipMemcpy(wst, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+      for (int i = 0; i < 2; ++i) DP(launch_stem_dgrad(1, gx, wst, Nb, 64, 112, 112, gs, st));
+      CK(hipEventRecord(e0, st));
+      for (int i = 0; i < iters; ++i) DP(launch_stem_dgrad(1, gx, wst, Nb, 64, 112, 112, gs, st));
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= iters;
+      printf("%-34s %9.4f ms  %12.3e flop  %8.2f TFLOP/s  %5.1f%% of 157.3 TF fp32 (useful flops)\n", "  stem_dgrad MFMA 16x16x4 f32", ms,
+             flop, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 1.573);
+      DP(launch_stem_dgrad(0, gx, wst, Nb, 64, 112, 112, gy, st));
+      unsigned *d_md = (unsigned *)dmalloc(8);
+      CK(hipMemsetAsync(d_md, 0, 8, st));
+      hipLaunchKernelGGL(k_max_diff, dim3(2048), dim3(256), 0, st, gs, gy, (size_t)Nb * 3 * 224 * 224, d_md);
+      unsigned h_md[2];
+      CK(hipMemcpyAsync(h_md, d_md, 8, hipMemcpyDeviceToHost, st));
+      CK(hipStreamSynchronize(st));
+      float fd, fm;
+      memcpy(&fd, &h_md[0], 4);
+      memcpy(&fm, &h_md[1], 4);
+      printf("  stem_dgrad MFMA vs VALU: max |diff| %.3e of max |value| %.3e (%.2e relative)\n", fd, fm, fd / fm);
     }
   }
   // ---- a-8 at 384 x 384 (BASELINE configs[2], 64 samples): the large-group GroupNorm backward — register / LDS resident
