@@ -8,7 +8,9 @@ image and the build container has no GPU, so this shim
 
 * installs empty stub modules for ``torchvision{,.utils,.transforms,.datasets}``
   and ``timm`` (only attribute look-ups that the hot path never executes),
-* makes ``Tensor.cuda`` / ``Module.cuda`` the identity when no GPU is present,
+* when no GPU is present, makes ``Tensor.cuda`` AND ``Tensor.cpu`` return (differentiable) COPIES — what a real
+  host <-> device transfer does; an identity ``.cuda()`` plus the stock no-op ``.cpu()`` alias buffers the reference keeps
+  apart on its own platform and change what its stage 1 returns (see ``_install_stubs``) — and ``Module.cuda`` the identity,
 * loads the reference source files *from where they lie* under a private module
   namespace (``_dorpatch_ref.*``) so they never shadow this repo's own
   ``attack`` / ``utils`` / ``defenses`` drop-in modules,

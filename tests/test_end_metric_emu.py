@@ -1,7 +1,8 @@
 """tests/test_end_metric_gpu.py on CPU tensors through the HIP emulation (tests/hipemu): ~10 minutes for the 8
-two-stage runs, so opt-in (DORPATCH_EMU_FULL=1); the `-m gpu` run is the gate.  Last run in the build
-container: certified ASR [12.5, 12.5, 12.5, 37.5] vs the reference's [12.5, 12.5, 25.0, 37.5], certified ACC
-identical, failure counts within 161 masks."""
+two-stage runs (27 minutes for the 32-problem null test), so opt-in (DORPATCH_EMU_FULL=1); the `-m gpu` run is the gate.
+Round 3: the null test run here FAILED exactly like on the GPU (product total 22 635 failures vs a null of 24 362-25 010)
+while the old 8-image bands passed — which is what located the aliasing in oracle/ref_shim.py: the
+fixtures have since been re-recorded through the corrected shim."""
 import importlib.util
 import os
 
