@@ -1920,60 +1920,6 @@ __global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_bwd_t(const f
   }
 }
 
-// MODE 6 of the backward: MODE 5 with the plane treated as a LINEAR array of 8-pixel items (item = h * W8 + t): a
-// workgroup takes 128 consecutive items, so no lane idles on the 14-of-16 column groups of a 112-wide row and the
-// workgroup's output is one contiguous 4 KiB run, written lane-contiguously after the LDS exchange.  W8 is a template
-// parameter (the item -> (row, column group) division is by a constant): 14 (224 x 224 inputs) and 24 (384 x 384).
-template <int W8C>
-__global__ __launch_bounds__(128) void k_pad_maxpool_bwd_lin(const float *__restrict__ dy,
-                                                             const uint8_t *__restrict__ code, int Hin,
-                                                             int blocks_per_plane, float *__restrict__ dx) {
-  __shared__ f4 sst[256];
-  constexpr int Win = 8 * W8C, Wo = Win >> 1;
-  const int Ho = Hin >> 1, items = Hin * W8C;
-  const long nc = blockIdx.x / (unsigned)blocks_per_plane;
-  const int item0 = (int)(blockIdx.x - (unsigned)nc * (unsigned)blocks_per_plane) * 128;
-  const int item = item0 + (int)threadIdx.x;
-  const float *dyp = dy + nc * (long)Ho * Wo;
-  const uint8_t *cp = code + nc * (long)Ho * Wo;
-  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (item < items) {
-    const int h = item / W8C, t = item - h * W8C;
-    const int a = h >> 1;
-    const int n_rows = (h & 1) ? 2 : 1;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      if (k >= n_rows) break;
-      const int oh = (h & 1) ? a + k : a;
-      const int r = (h & 1) ? (k == 0 ? 2 : 0) : 1;
-      if (oh >= Ho) continue;
-      const long base = (long)oh * Wo + 4 * t;
-      const f4 g4 = *reinterpret_cast<const f4 *>(dyp + base);
-      const uint32_t c4 = *reinterpret_cast<const uint32_t *>(cp + base);
-      const bool has4 = (4 * t + 4) < Wo;
-      const float g[5] = {g4.x, g4.y, g4.z, g4.w, has4 ? dyp[base + 4] : 0.f};
-      const unsigned c[5] = {c4 & 255u, (c4 >> 8) & 255u, (c4 >> 16) & 255u, c4 >> 24, has4 ? cp[base + 4] : 255u};
-      const unsigned rc = 3u * (unsigned)r;
-#pragma unroll
-      for (int l = 0; l < 4; ++l) {
-        o[2 * l] += (c[l] == rc + 1u) ? g[l] : 0.f;
-        o[2 * l + 1] += (c[l] == rc + 2u) ? g[l] : 0.f;
-        o[2 * l + 1] += (c[l + 1] == rc + 0u) ? g[l + 1] : 0.f;
-      }
-    }
-  }
-  sst[2 * threadIdx.x] = f4{o[0], o[1], o[2], o[3]};
-  sst[2 * threadIdx.x + 1] = f4{o[4], o[5], o[6], o[7]};
-  __syncthreads();
-  f4 *dst = reinterpret_cast<f4 *>(dx) + 2 * (nc * items + item0);
-  const int n16 = 2 * min(128, items - item0);   // 16-byte pieces this workgroup owns
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int q = k * 128 + (int)threadIdx.x;
-    if (q < n16) __builtin_nontemporal_store(sst[q], dst + q);
-  }
-}
-
 // MODE 3 of the backward: one thread = 8 consecutive input pixels of BOTH rows 2a and 2a + 1 (four float4 stores).  The
 // pair needs output rows a and a + 1 only (the even row's single window row is shared with the odd row), i.e. 2 instead
 // of 3 (dy float4 + code word + halo) load groups per 64 bytes stored, and ALL of them are issued before the first use
@@ -2033,7 +1979,9 @@ __global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_bwd_pair(cons
 }
 
 constexpr int kPoolDefaultMode = 1;      // forward (profiles/r03b_kbench_pool.txt)
-constexpr int kPoolBwdDefaultMode = 6;   // backward: LDS-transposed stores 0.450 ms vs 0.508 (mode 1) vs 0.837 (row pairs, 3) — profiles/r03e_kbench_pool.txt
+constexpr int kPoolBwdDefaultMode = 5;   // backward: LDS-transposed stores 0.450 ms vs 0.508 (mode 1) vs 0.837 (row pairs, 3) — profiles/r03e_kbench_pool.txt.
+                                         // (A variant over linear 8-pixel items — no idle lanes on 14-of-16 column groups —
+                                         // measured exactly the same 0.453 ms and was removed.)
 
 int launch_pad_maxpool_fwd(int mode, const float *x, int64_t NC, int Hin, int Win, float *y, uint32_t *code4,
                            hipStream_t st) {
@@ -2053,16 +2001,7 @@ int launch_pad_maxpool_fwd(int mode, const float *x, int64_t NC, int Hin, int Wi
 int launch_pad_maxpool_bwd(int mode, const float *dy, const uint8_t *code, int64_t NC, int Hin, int Win, float *dx,
                            hipStream_t st) {
   const int nrg = cdiv(Hin, kPoolTY);
-  DP_REQUIRE(mode >= 0 && mode <= 6 && (mode == 0 || mode == 2 || NC * nrg <= 0x7fffffffL));
-  if (mode == 6) {   // linear items: instantiated for the two widths the stem sees (224 / 384 inputs), else mode 5
-    const int W8 = Win >> 3, bpp = cdiv(Hin * W8, 128);
-    if ((W8 == 14 || W8 == 24) && NC * bpp <= 0x7fffffffL) {
-      if (W8 == 14) hipLaunchKernelGGL(k_pad_maxpool_bwd_lin<14>, dim3((unsigned)(NC * bpp)), dim3(128), 0, st, dy, code, Hin, bpp, dx);
-      else hipLaunchKernelGGL(k_pad_maxpool_bwd_lin<24>, dim3((unsigned)(NC * bpp)), dim3(128), 0, st, dy, code, Hin, bpp, dx);
-      return launch_status();
-    }
-    mode = 5;
-  }
+  DP_REQUIRE(mode >= 0 && mode <= 5 && (mode == 0 || mode == 2 || NC * nrg <= 0x7fffffffL));
   if (mode == 5 && (Win >> 3) > kPoolTX) mode = 1;      // the LDS-transposed stores handle one column group per thread
   if (mode == 5) {
     hipLaunchKernelGGL(k_pad_maxpool_bwd_t, dim3((unsigned)(NC * nrg)), dim3(kPoolTX, kPoolTY), 0, st, dy, code, Hin, Win, nrg, dx);

@@ -81,7 +81,20 @@ def _worker(rank, world, port, out_dir):
         bitmap = torch.zeros((B, n_mask), dtype=torch.int32)
         bitmap[:, mlo:mhi] = (torch.arange(mlo, mhi) % 7 == 0).int()
         dp_dist.allreduce_max_(bitmap, pg)
-        torch.save(dict(g=g, loss=loss, bitmap=bitmap), os.path.join(out_dir, "rank%d.pt" % rank))
+        # feature agreement (round 3): one rank's refusal is every rank's; per-problem determinism decisions are OR-merged
+        from dorpatch_amd import conv1x1, libconv
+        agree = (dp_dist.all_true(True, pg), dp_dist.all_true(rank != world - 1, pg))
+        libconv.POLICY.clear()
+        libconv.POLICY.update({("fwd", 8, 1, 1, 3, 1, 4, 4): rank == 0, ("bwd", 8 + rank, 1, 1, 3, 1, 4, 4): False})
+        libconv.merge_across(pg)
+        policy = dict(libconv.POLICY)
+        # the tuned-GEMM verdict is rank 0's self-test, broadcast, AND-ed with every rank's own load of the file: here
+        # no GPU, so _decide() must come out False everywhere without running anything
+        ran = []
+        conv1x1._selftest_tuned = lambda: ran.append(rank) or True
+        verdict = conv1x1._decide(pg)
+        torch.save(dict(g=g, loss=loss, bitmap=bitmap, agree=agree, policy=policy, verdict=verdict, ran=ran),
+                   os.path.join(out_dir, "rank%d.pt" % rank))
     finally:
         dist.destroy_process_group()
 
@@ -102,6 +115,13 @@ def test_sharded_step_equals_unsharded(world, tmp_path):
     # all ranks hold bit-identical reduced tensors => identical signed updates everywhere
     for o in outs[1:]:
         assert torch.equal(o["g"], outs[0]["g"]) and torch.equal(o["loss"], outs[0]["loss"])
+    want_policy = {("fwd", 8, 1, 1, 3, 1, 4, 4): True}
+    want_policy.update({("bwd", 8 + r, 1, 1, 3, 1, 4, 4): False for r in range(world)})
+    for r, o in enumerate(outs):
+        assert o["agree"] == (True, False)
+        assert o["policy"] == want_policy                        # the union of the ranks' findings, on every rank
+        assert o["verdict"] is False                             # torch.cuda.tunable cannot load the file without a GPU ...
+        assert o["ran"] == ([0] if r == 0 else [])               # ... and only rank 0 ran the (stubbed) self-test
 
 
 def test_shard_bounds_and_mask_bounds():
