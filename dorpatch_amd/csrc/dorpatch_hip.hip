@@ -2044,24 +2044,35 @@ constexpr int ST = SQ + 3;        // dy tile side (halo: 1 before, 2 after)
 constexpr int STP = 24;           // LDS row pitch: 2 * STP mod 32 == 16 -> the 4 quad-row pairs of a wave hit disjoint banks
 constexpr int kStemBlock = (SQ / 2) * SQ;
 
-// Thread (ta, tb) owns output quads (2ta, tb) and (2ta + 1, tb) of the tile x 3 channels x 2 x 2 parities =
-// 24 accumulators, fed from a 5 x 4 patch of the dy tile (20 LDS reads per input channel k for 294 FMAs).
+// Thread (ta, tb) owns the U vertically adjacent output quads (U ta .. U ta + U - 1, tb) of the tile x 3 channels x 2 x 2
+// parities = 12 U accumulators, fed from a (U + 3) x 4 patch of the dy tile; the tile is 8 U x 16 quads, 128 threads.
+// U = 2 (shipped): 20 LDS reads and 147 scalar dwords per input channel for 294 FMAs.
+// What bounds it (round 3, tools/kbench fma_rate): on this GPU a plain v_fma_f32 loop with VGPR operands sustains 110
+// TFLOP/s, v_pk_fma_f32 123, but **v_fmac_f32 with an SGPR multiplier — this kernel's instruction — only 71.7**: the 68
+// TFLOP/s measured here is 95 % of THAT ceiling (43 % of the 157.3 TFLOP/s spec, which needs all-VGPR or packed operands).
+// U = 4 (half the scalar loads per FMA, 103 VGPRs, 4 waves/SIMD, a 32-row tile that wastes 1/8 of a 112-row plane) was
+// tried on the hypothesis that the scalar cache was the limit: 1.012 vs 0.887 ms — slower, bit-identical — and stays only
+// as kbench variant 2.  Getting past 72 TFLOP/s needs the filter taps as VGPR operands (e.g. row_newbcast DPP from a
+// lane-distributed tap vector): not attempted.
 // The filter taps are wave-uniform: they arrive through scalar loads and are SGPR operands of the FMAs.
 // One input channel's 147 taps exceed the ~100 SGPRs a wave has, and a compiler left to schedule them all at
 // once spills SGPRs into VGPR lanes (v_writelane / v_readlane: as many instructions as the FMAs themselves —
 // the r01 kernel, 24.9 % of the fp32 VALU peak); so the taps are consumed one output channel (49) at a time,
 // fenced by scheduling barriers.
+template <int U>
 __global__ __launch_bounds__(kStemBlock) void k_stem_dgrad(const float *__restrict__ dy,
                                                            const float *__restrict__ w, int K, int Ho,
                                                            int Wo, float *__restrict__ dx) {
-  __shared__ float tile[2][ST + 1][STP];  // + 1 row: the dummy slot of lanes that stage nothing
+  constexpr int SR = (kStemBlock / SQ) * U;   // quad rows per tile (16 or 32)
+  constexpr int STR = SR + 3;                 // dy tile rows (halo: 1 before, 2 after)
+  __shared__ float tile[2][STR + 1][STP];     // + 1 row: the dummy slot of lanes that stage nothing
   const int n = blockIdx.z;
-  const int a0 = blockIdx.y * SQ, b0 = blockIdx.x * SQ;
-  const int ta = threadIdx.x / SQ, tb = threadIdx.x % SQ;  // ta: pair of quad rows 2ta, 2ta + 1
+  const int a0 = blockIdx.y * SR, b0 = blockIdx.x * SQ;
+  const int ta = threadIdx.x / SQ, tb = threadIdx.x % SQ;  // ta: group of quad rows U ta .. U ta + U - 1
   const float *dyn = dy + (size_t)n * K * Ho * Wo;
-  float acc[2][3][2][2];
+  float acc[U][3][2][2];
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < U; ++u)
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -2073,7 +2084,7 @@ __global__ __launch_bounds__(kStemBlock) void k_stem_dgrad(const float *__restri
   // offsets do not depend on k, so they are computed once; the loads for channel k + 1 are issued BEFORE the
   // FMAs of channel k and only written to LDS after them (software pipeline: their latency hides behind 294 FMAs
   // instead of stalling the wave three times per channel).
-  constexpr int kStage = (ST * ST + kStemBlock - 1) / kStemBlock;  // 3
+  constexpr int kStage = (STR * ST + kStemBlock - 1) / kStemBlock;  // 3 (U = 2), 6 (U = 4)
   // Branch-free on purpose (one basic block per channel, so the order loads -> FMAs -> LDS stores survives the
   // compiler): lanes with nothing to stage write a dummy slot behind the tile, halo lanes read element 0 of the
   // plane and select 0.
@@ -2084,8 +2095,8 @@ __global__ __launch_bounds__(kStemBlock) void k_stem_dgrad(const float *__restri
     const int e = threadIdx.x + j * kStemBlock;
     const int r = e / ST, c = e - r * ST;
     const int oh = a0 - 1 + r, ow = b0 - 1 + c;
-    lds_off[j] = e < ST * ST ? r * STP + c : ST * STP;
-    g_ok[j] = e < ST * ST && oh >= 0 && oh < Ho && ow >= 0 && ow < Wo;
+    lds_off[j] = e < STR * ST ? r * STP + c : STR * STP;
+    g_ok[j] = e < STR * ST && oh >= 0 && oh < Ho && ow >= 0 && ow < Wo;
     g_off[j] = g_ok[j] ? oh * Wo + ow : 0;
   }
   float pre[kStage];
@@ -2107,11 +2118,11 @@ __global__ __launch_bounds__(kStemBlock) void k_stem_dgrad(const float *__restri
     const int buf = k & 1;
     stage_load(k + 1 < K ? k + 1 : k);  // in flight during this channel's FMAs (last channel: a harmless re-read)
     __builtin_amdgcn_sched_barrier(0);
-    float p[5][4];
+    float p[U + 3][4];
 #pragma unroll
-    for (int r = 0; r < 5; ++r)
+    for (int r = 0; r < U + 3; ++r)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) p[r][q] = tile[buf][2 * ta + r][tb + q];
+      for (int q = 0; q < 4; ++q) p[r][q] = tile[buf][U * ta + r][tb + q];
     const float *wk = w + (size_t)k * 147;  // wave-uniform: scalar loads
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -2120,7 +2131,7 @@ __global__ __launch_bounds__(kStemBlock) void k_stem_dgrad(const float *__restri
 #pragma unroll
       for (int t = 0; t < 49; ++t) wc[t] = wk[c * 49 + t];
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
@@ -2143,8 +2154,8 @@ __global__ __launch_bounds__(kStemBlock) void k_stem_dgrad(const float *__restri
   const int H = 2 * Ho, W = 2 * Wo;
   float *dxn = dx + (size_t)n * 3 * H * W;
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int a = a0 + 2 * ta + u;
+  for (int u = 0; u < U; ++u) {
+    const int a = a0 + U * ta + u;
     if (a >= Ho) continue;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -2619,7 +2630,8 @@ int launch_apply_fwd(int variant, const float *adv_x, const int32_t *table, int 
   return launch_status();
 }
 
-// variant 0: fp32 VALU gather (k_stem_dgrad); 1: matrix cores (k_stem_dgrad_mfma; needs K % 4 == 0, else 0 is used)
+// variant 0: fp32 VALU gather, 2 quads per thread (shipped); 2: the same with 4 quads per thread (measured slower, see
+// k_stem_dgrad); 1: matrix cores (k_stem_dgrad_mfma; needs K % 4 == 0, else the default is used; measured slower)
 constexpr int kStemDefaultVariant = 0;
 
 int launch_stem_dgrad(int variant, const float *dy, const float *w, int N, int K, int Ho, int Wo, float *dx,
@@ -2628,7 +2640,8 @@ int launch_stem_dgrad(int variant, const float *dy, const float *w, int N, int K
     hipLaunchKernelGGL(k_stem_dgrad_mfma, dim3(cdiv(Wo, kMT), cdiv(Ho, kMT), N), dim3(256), 0, st, dy, w, K, Ho, Wo, dx);
     return launch_status();
   }
-  hipLaunchKernelGGL(k_stem_dgrad, dim3(cdiv(Wo, SQ), cdiv(Ho, SQ), N), dim3(kStemBlock), 0, st, dy, w, K, Ho, Wo, dx);
+  if (variant == 0) hipLaunchKernelGGL(k_stem_dgrad<2>, dim3(cdiv(Wo, SQ), cdiv(Ho, 16), N), dim3(kStemBlock), 0, st, dy, w, K, Ho, Wo, dx);
+  else hipLaunchKernelGGL(k_stem_dgrad<4>, dim3(cdiv(Wo, SQ), cdiv(Ho, 32), N), dim3(kStemBlock), 0, st, dy, w, K, Ho, Wo, dx);
   return launch_status();
 }
 

@@ -124,6 +124,39 @@ __global__ __launch_bounds__(256) void k_readsum(const f4 *__restrict__ in, floa
   if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = 1.f;  // keep the loads alive
 }
 
+// fp32 VALU issue rates: N dependent-chain-free FMAs per lane, scalar (v_fma_f32) vs packed (v_pk_fma_f32: 2 FMAs per
+// instruction).  The 157.3 TFLOP/s vector spec counts the packed form; what does this GPU sustain?
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <int PACKED>   // 0: v_fma_f32 all-VGPR, 1: v_pk_fma_f32, 2: v_fmac_f32 with an SGPR multiplier (k_stem_dgrad's form)
+__global__ __launch_bounds__(256) void k_fma_rate(float *__restrict__ out, int iters, float seed) {
+  float a[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) a[i] = seed + (float)(threadIdx.x + i);
+  const float m = 1.0000001f, c = 1e-7f;
+  for (int it = 0; it < iters; ++it) {
+    if (PACKED == 2) {
+      const float sm = __builtin_amdgcn_readfirstlane(m);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "s"(sm), "v"(c));
+    } else if (PACKED == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        f2 v = {a[i], a[i + 1]};
+        asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(v) : "v"(f2{m, m}), "v"(f2{c, c}));
+        a[i] = v.x;
+        a[i + 1] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += a[i];
+  if (s == 12345.678f) out[0] = s;
+}
+
 static const char *g_filter = nullptr;  // 5th argument: run only the entries whose name contains it
 
 static double bench(const char *name, double bytes, int iters, hipStream_t st, const std::function<void()> &fn) {
@@ -239,6 +272,30 @@ int main(int argc, char **argv) {
   dp_norm_t norm = {1, {0.5f, 0.5f, 0.5f}, {0.5f, 0.5f, 0.5f}, 0.5f};
   const double out_bytes = (double)N * img;
 
+  if (g_filter && strstr(g_filter, "fma_rate")) {
+    const int it = 4096, blocks = 256 * 16;
+    for (int packed = 0; packed < 3; ++packed) {
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0));
+      CK(hipEventCreate(&e1));
+      auto run = [&] {
+        if (packed == 1) hipLaunchKernelGGL((k_fma_rate<1>), dim3(blocks), dim3(256), 0, st, loss, it, 0.5f);
+        else if (packed == 2) hipLaunchKernelGGL((k_fma_rate<2>), dim3(blocks), dim3(256), 0, st, loss, it, 0.5f);
+        else hipLaunchKernelGGL((k_fma_rate<0>), dim3(blocks), dim3(256), 0, st, loss, it, 0.5f);
+      };
+      run();
+      CK(hipEventRecord(e0, st));
+      for (int i = 0; i < 5; ++i) run();
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= 5;
+      const double flop = 2.0 * 16 * it * 256.0 * blocks;   // v_fmac a += s * c: also 16 FMAs per iteration
+      printf("fma_rate %-22s %8.3f ms  %7.1f TFLOP/s\n", packed == 1 ? "v_pk_fma_f32 (8/iter)" : packed == 2 ? "v_fmac_f32 v,s,v (16/iter)" : "v_fma_f32 (16/iter)", ms, flop / (ms * 1e-3) / 1e12);
+    }
+    return 0;
+  }
   // ---- calibration: what this box's HBM does for the same footprint
   bench("calib: fill (write-only)", out_bytes, iters, st,
         [&] { hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, st, (f4 *)big, n4_big, 1.f); });
@@ -534,6 +591,17 @@ int main(int argc, char **argv) {
       ms /= iters;
       printf("%-34s %9.4f ms  %12.3e flop  %8.2f TFLOP/s  %5.1f%% of 157.3 TF fp32\n", "dp_stem_dgrad 256x64x112x112", ms,
              flop, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 1.573);
+      for (int variant : {0, 2}) {   // quads per thread: 2 (round 2) / 4
+        for (int i = 0; i < 2; ++i) DP(launch_stem_dgrad(variant, gx, wst, Nb, 64, 112, 112, gs, st));
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < iters; ++i) DP(launch_stem_dgrad(variant, gx, wst, Nb, 64, 112, 112, gs, st));
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= iters;
+        printf("  stem_dgrad VALU, %d quads/thread    %9.4f ms  %8.2f TFLOP/s  %5.1f%% of 157.3 TF fp32\n", variant == 0 ? 2 : 4, ms,
+               flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 1.573);
+      }
       // the matrix-core formulation (k_stem_dgrad_mfma): same useful flops, 57 % of the issued MACs useful
       std::vector<float> hw(64 * 147);
       std::normal_distribution<float> Nw(0.f, 0.1f);
@@ -559,6 +627,13 @@ int main(int argc, char **argv) {
       memcpy(&fd, &h_md[0], 4);
       memcpy(&fm, &h_md[1], 4);
       printf("  stem_dgrad MFMA vs VALU: max |diff| %.3e of max |value| %.3e (%.2e relative)\n", fd, fm, fd / fm);
+      DP(launch_stem_dgrad(2, gx, wst, Nb, 64, 112, 112, gs, st));
+      CK(hipMemsetAsync(d_md, 0, 8, st));
+      hipLaunchKernelGGL(k_max_diff, dim3(2048), dim3(256), 0, st, gs, gy, (size_t)Nb * 3 * 224 * 224, d_md);
+      CK(hipMemcpyAsync(h_md, d_md, 8, hipMemcpyDeviceToHost, st));
+      CK(hipStreamSynchronize(st));
+      memcpy(&fd, &h_md[0], 4);
+      printf("  stem_dgrad 4 quads/thread vs 2: max |diff| %.3e (same summation order per output: 0 expected)\n", fd);
     }
   }
   // ---- a-8 at 384 x 384 (BASELINE configs[2], 64 samples): the large-group GroupNorm backward — register / LDS resident
