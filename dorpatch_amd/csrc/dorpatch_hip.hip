@@ -2047,13 +2047,15 @@ constexpr int kStemBlock = (SQ / 2) * SQ;
 // Thread (ta, tb) owns the U vertically adjacent output quads (U ta .. U ta + U - 1, tb) of the tile x 3 channels x 2 x 2
 // parities = 12 U accumulators, fed from a (U + 3) x 4 patch of the dy tile; the tile is 8 U x 16 quads, 128 threads.
 // U = 2 (shipped): 20 LDS reads and 147 scalar dwords per input channel for 294 FMAs.
-// What bounds it (round 3, tools/kbench fma_rate): on this GPU a plain v_fma_f32 loop with VGPR operands sustains 110
-// TFLOP/s, v_pk_fma_f32 123, but **v_fmac_f32 with an SGPR multiplier — this kernel's instruction — only 71.7**: the 68
-// TFLOP/s measured here is 95 % of THAT ceiling (43 % of the 157.3 TFLOP/s spec, which needs all-VGPR or packed operands).
+// What bounds it (round 3, tools/kbench fma_rate): on this GPU v_fmac_f32 / v_fma_f32 with all-VGPR operands sustain
+// 127 / 103-110 TFLOP/s and v_pk_fma_f32 121-123, but an FMA with an SGPR operand (either opcode) or a DPP-broadcast
+// operand (row_newbcast) only 71.5 — the half-rate path.  This kernel's FMAs take their tap from an SGPR: the 68 TFLOP/s
+// measured here is 95 % of THAT ceiling (43 % of the 157.3 TFLOP/s spec, which needs all-VGPR or packed operands).
 // U = 4 (half the scalar loads per FMA, 103 VGPRs, 4 waves/SIMD, a 32-row tile that wastes 1/8 of a 112-row plane) was
 // tried on the hypothesis that the scalar cache was the limit: 1.012 vs 0.887 ms — slower, bit-identical — and stays only
-// as kbench variant 2.  Getting past 72 TFLOP/s needs the filter taps as VGPR operands (e.g. row_newbcast DPP from a
-// lane-distributed tap vector): not attempted.
+// as kbench variant 2.  Getting past 72 TFLOP/s needs the taps as plain VGPR operands: a v_mov per tap eats the gain at 2
+// quads per thread, LDS broadcast reads of the taps would need twice the LDS bandwidth there is, DPP is half-rate too —
+// which leaves the matrix-core formulation (k_stem_dgrad_mfma below, ceiling 89).
 // The filter taps are wave-uniform: they arrive through scalar loads and are SGPR operands of the FMAs.
 // One input channel's 147 taps exceed the ~100 SGPRs a wave has, and a compiler left to schedule them all at
 // once spills SGPRs into VGPR lanes (v_writelane / v_readlane: as many instructions as the FMAs themselves —

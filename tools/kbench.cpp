@@ -134,7 +134,19 @@ __global__ __launch_bounds__(256) void k_fma_rate(float *__restrict__ out, int i
   for (int i = 0; i < 16; ++i) a[i] = seed + (float)(threadIdx.x + i);
   const float m = 1.0000001f, c = 1e-7f;
   for (int it = 0; it < iters; ++it) {
-    if (PACKED == 2) {
+    if (PACKED == 4) {   // VOP2 fmac, all operands VGPRs
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+    } else if (PACKED == 5) {   // VOP3 fma with an SGPR multiplier
+      const float sm = __builtin_amdgcn_readfirstlane(m);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "s"(sm), "v"(c));
+    } else if (PACKED == 3) {   // multiplier broadcast from lane 3 of each row of 16 lanes of a VGPR (DPP row_newbcast)
+      float mv = m;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(mv), "v"(c));
+    } else if (PACKED == 2) {
       const float sm = __builtin_amdgcn_readfirstlane(m);
 #pragma unroll
       for (int i = 0; i < 16; ++i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "s"(sm), "v"(c));
@@ -274,13 +286,16 @@ int main(int argc, char **argv) {
 
   if (g_filter && strstr(g_filter, "fma_rate")) {
     const int it = 4096, blocks = 256 * 16;
-    for (int packed = 0; packed < 3; ++packed) {
+    for (int packed = 0; packed < 6; ++packed) {
       hipEvent_t e0, e1;
       CK(hipEventCreate(&e0));
       CK(hipEventCreate(&e1));
       auto run = [&] {
         if (packed == 1) hipLaunchKernelGGL((k_fma_rate<1>), dim3(blocks), dim3(256), 0, st, loss, it, 0.5f);
         else if (packed == 2) hipLaunchKernelGGL((k_fma_rate<2>), dim3(blocks), dim3(256), 0, st, loss, it, 0.5f);
+        else if (packed == 3) hipLaunchKernelGGL((k_fma_rate<3>), dim3(blocks), dim3(256), 0, st, loss, it, 0.5f);
+        else if (packed == 4) hipLaunchKernelGGL((k_fma_rate<4>), dim3(blocks), dim3(256), 0, st, loss, it, 0.5f);
+        else if (packed == 5) hipLaunchKernelGGL((k_fma_rate<5>), dim3(blocks), dim3(256), 0, st, loss, it, 0.5f);
         else hipLaunchKernelGGL((k_fma_rate<0>), dim3(blocks), dim3(256), 0, st, loss, it, 0.5f);
       };
       run();
@@ -292,7 +307,7 @@ int main(int argc, char **argv) {
       CK(hipEventElapsedTime(&ms, e0, e1));
       ms /= 5;
       const double flop = 2.0 * 16 * it * 256.0 * blocks;   // v_fmac a += s * c: also 16 FMAs per iteration
-      printf("fma_rate %-22s %8.3f ms  %7.1f TFLOP/s\n", packed == 1 ? "v_pk_fma_f32 (8/iter)" : packed == 2 ? "v_fmac_f32 v,s,v (16/iter)" : "v_fma_f32 (16/iter)", ms, flop / (ms * 1e-3) / 1e12);
+      printf("fma_rate %-22s %8.3f ms  %7.1f TFLOP/s\n", packed == 1 ? "v_pk_fma_f32 (8/iter)" : packed == 2 ? "v_fmac_f32 v,s,v (16/iter)" : packed == 3 ? "v_fmac_f32_dpp row_newbcast" : packed == 4 ? "v_fmac_f32 v,v,v" : packed == 5 ? "v_fma_f32 v,s,v,v" : "v_fma_f32 (16/iter)", ms, flop / (ms * 1e-3) / 1e12);
     }
     return 0;
   }
