@@ -124,21 +124,42 @@ class PatchCleanser(object):
     def mask(self, img, msk):
         return img * msk + 0.5 * ~msk
 
+    # Batch sizes a sweep may present to the classifier: the GEMM batches the committed 1x1 route tables / tuned solutions
+    # exist for (conv1x1.TUNED).  Every distinct batch size costs MIOpen a solution lookup + code-object load per layer
+    # (seconds in total), and a second-round sweep produces arbitrary sizes (minority masks x 36): measured 235 masked
+    # forwards/s with free-form chunks vs ~10 k/s for the hot loop's fixed-size failure sweep (scripts/pc_bench.py).
+    LADDER = (512, 128, 64, 32)
+
     @torch.no_grad()
     def _sweep(self, imgs, table, idx, idx2=None):
         """argmax of model(occlude(imgs[b], idx[.., s])) -> (B, S) int32 device tensor.
-        idx (S,) shared by all images or (B,S)."""
+        idx (S,) shared by all images or (B,S).  Chunked so that the classifier only ever sees the LADDER batch sizes
+        (the last chunk is padded by repeating its last mask; the padding's predictions are dropped)."""
         net, dn = _unwrap(self.model)
         B = imgs.shape[0]
         S = idx.shape[-1]
-        per = max(1, self.max_batch // B)
-        outs = []
-        for s0 in range(0, S, per):
-            sl = slice(s0, min(S, s0 + per))
-            i1 = idx[..., sl].contiguous()
-            i2 = None if idx2 is None else idx2[..., sl].contiguous()
-            inp = ops.apply_fwd(imgs, table, i1, i2, dn)
-            outs.append(ops.argmax(net(inp).float().contiguous()).view(B, -1))
+        ladder = [L for L in self.LADDER if L <= max(self.max_batch, self.LADDER[-1])]
+        if B & (B - 1) or B > ladder[0]:          # not a power of two (or huge): image by image, B = 1 fits every size
+            return torch.cat([self._sweep(imgs[b:b + 1], table, idx if idx.dim() == 1 else idx[b:b + 1],
+                                          None if idx2 is None else (idx2 if idx2.dim() == 1 else idx2[b:b + 1]))
+                              for b in range(B)], dim=0)
+        sizes = [L // B for L in ladder if L >= B]          # masks per chunk, descending
+        outs, s0 = [], 0
+        while s0 < S:
+            rem = S - s0
+            s = next((c for c in sizes if c <= rem), sizes[-1])
+            take = min(s, rem)
+
+            def chunk(t):
+                if t is None:
+                    return None
+                c = t[..., s0:s0 + take]
+                if take < s:                                  # pad with the chunk's last mask
+                    c = torch.cat([c, c[..., -1:].expand(c.shape[:-1] + (s - take,))], dim=-1)
+                return c.contiguous()
+            inp = ops.apply_fwd(imgs, table, chunk(idx), chunk(idx2), dn)
+            outs.append(ops.argmax(net(inp).float().contiguous()).view(B, s)[:, :take])
+            s0 += take
         return torch.cat(outs, dim=1)
 
     def _prep(self, img):
@@ -162,8 +183,22 @@ class PatchCleanser(object):
         """``PatchCleanser.py:68-97`` for one image (3,H,W) or (1,3,H,W)."""
         return self.robust_predict_batch(self._prep(img), certify)[0]
 
-    @torch.no_grad()
     def robust_predict_batch(self, imgs, certify=False):
+        """Both rounds for a batch of images.  With dorpatch_amd's own ResNetV2 the tuned GEMM solutions of the 1x1 routes
+        are in effect for the duration of the call (conv1x1.activate / deactivate, like DorPatch.generate)."""
+        from . import conv1x1, resnetv2
+        net, _ = _unwrap(self.model)
+        scoped = False
+        if isinstance(net, torch.nn.Module) and any(isinstance(m, resnetv2.StdConv2d) for m in net.modules()):
+            scoped = conv1x1.activate(None, self._prep(imgs).is_cuda)
+        try:
+            return self._robust_predict_batch(imgs, certify)
+        finally:
+            if scoped:
+                conv1x1.deactivate()
+
+    @torch.no_grad()
+    def _robust_predict_batch(self, imgs, certify=False):
         imgs = self._prep(imgs)
         dev, B = imgs.device, imgs.shape[0]
         mw = self.mask_window
