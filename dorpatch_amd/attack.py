@@ -210,7 +210,8 @@ class DorPatch(object):
     ``False``: leave MIOpen alone; ``"auto"`` (default): decide PER CONVOLUTION PROBLEM — the first time a
     (direction, batch, shape) is seen it runs three times on its real operands, and only a problem whose results
     differ in any bit is run with deterministic kernels from then on (``dorpatch_amd/libconv.py``; with
-    dorpatch_amd's own ResNetV2; another classifier's convolutions are outside its reach — use ``True`` there).
+    dorpatch_amd's own ResNetV2; for any other classifier the first micro-batch of each row count runs twice and the
+    global flag is switched on only if the two gradients differ in a bit, as in round 2).
     With the table-routed 1x1 convolutions and the fixed-order reductions of every HIP kernel, identical inputs
     then give identical bits.  The reference sets ``cudnn.benchmark = True`` (``utils.py:17``) and is not run-to-run
     reproducible on a GPU.
@@ -450,6 +451,12 @@ class HotLoop(object):
         elif owner.deterministic == "auto" and not torch.backends.cudnn.deterministic:
             libconv.MODE = "auto"
         self._det_rows_merged = set()        # micro-batch row counts whose per-problem decisions the ranks have agreed on
+        # The per-problem policy only reaches the library calls of dorpatch_amd's own ResNetV2.  Any other classifier is
+        # checked as a whole, as in round 2: the first micro-batch of each row count runs twice, and if the two input
+        # gradients differ in any bit the global flag is switched on for the rest of the run (restored by close()).
+        self._det_whole_net = (owner.deterministic == "auto" and not torch.backends.cudnn.deterministic
+                               and not isinstance(self.net, resnetv2.ResNetV2))
+        self._det_rows_checked = set()
 
         owner.criterion = CW_loss(n_classes, targeted, confidence)     # attack.py:57
         # attack.py:59-60 — CPU generator, mask first then pattern
@@ -556,8 +563,11 @@ class HotLoop(object):
             return "on (torch.backends.cudnn.deterministic for the whole run)"
         if libconv.MODE == "auto":
             d = libconv.summary()
-            return "per problem: %d of %d probed (direction, batch, shape) problems forced to deterministic kernels" % (
+            what = "per problem: %d of %d probed (direction, batch, shape) problems forced to deterministic kernels" % (
                 d["forced"], d["problems"])
+            if self._det_whole_net:
+                what += "; foreign classifier: first micro-batch of each row count verified bit-identical twice"
+            return what
         return "off"
 
     def close(self):
@@ -1051,6 +1061,16 @@ class HotLoop(object):
         G = self._fb_chunk_once(inp, y, flags, S_chunk, upstream, loss_out, pred_out)
         from . import libconv
         rows = inp.shape[0]
+        if self._det_whole_net and rows not in self._det_rows_checked and not torch.backends.cudnn.deterministic:
+            self._det_rows_checked.add(rows)
+            again = self._fb_chunk_once(inp, y, flags, S_chunk, upstream, loss_out, pred_out)
+            differ = torch.tensor([0 if torch.equal(G, again) else 1], dtype=torch.int32, device=self.dev)
+            dp_dist.allreduce_max_(differ, self.o.pg)        # every replica takes the same decision
+            if int(differ.item()):
+                torch.backends.cudnn.deterministic = True      # restored by close()
+                self.o._log(">> this classifier's library kernels are not run-to-run deterministic at batch %d: "
+                            "deterministic kernels for the rest of the run" % rows)
+                G = self._fb_chunk_once(inp, y, flags, S_chunk, upstream, loss_out, pred_out)
         if libconv.MODE == "auto" and self.world > 1 and rows not in self._det_rows_merged:
             # the first micro-batch of a new row count probed new convolution problems: every replica adopts the union
             # of the ranks' findings (rank-symmetric: the chunking is the same on every rank)

@@ -53,16 +53,16 @@ def guard(key, fn, forced_fn=None):
         return (forced_fn or fn)()
 
 
-def _key(direction, n, w, stride, hw_in):
+def _key(direction, n, w, stride, hw_in, padding=(0, 0)):
     return (direction, int(n), int(w.shape[1]), int(w.shape[0]), int(w.shape[2]), int(stride[0]), int(hw_in[0]),
-            int(hw_in[1]))
+            int(hw_in[1])) + ((int(padding[0]),) if int(padding[0]) != int(w.shape[2]) // 2 else ())   # "same" padding implied
 
 
 def conv_fwd(x, w, stride=(1, 1), padding=(0, 0)):
     """``F.conv2d(x, w, None, stride, padding)`` for a frozen filter."""
     if MODE != "auto":
         return F.conv2d(x, w, None, stride, padding)
-    return guard(_key("fwd", x.shape[0], w, stride, x.shape[2:]), lambda: F.conv2d(x, w, None, stride, padding))
+    return guard(_key("fwd", x.shape[0], w, stride, x.shape[2:], padding), lambda: F.conv2d(x, w, None, stride, padding))
 
 
 def conv_bwd_data(dy, x_ref, w, stride=(1, 1), padding=(0, 0)):
@@ -73,7 +73,7 @@ def conv_bwd_data(dy, x_ref, w, stride=(1, 1), padding=(0, 0)):
                                                    (0, 0), 1, (True, False, False))[0]
     if MODE != "auto":
         return call()
-    return guard(_key("bwd", dy.shape[0], w, stride, x_ref.shape[2:]), call)
+    return guard(_key("bwd", dy.shape[0], w, stride, x_ref.shape[2:], padding), call)
 
 
 class FrozenConvFunction(torch.autograd.Function):
