@@ -399,42 +399,18 @@ constexpr int kAffCapF = 64 * 16 * kAffRowsF;  // ... per channel: 36 KiB of LDS
 constexpr int kAffRowsB = 2;         // backward: staged output region of at most 64 x 32 pixels
 constexpr int kAffCapB = 64 * 16 * kAffRowsB;  // 6 dwords each: 48 KiB
 
-// The (<= DP_MAX_RECTS) windows of one table entry in registers (SGPRs: the entry is block-uniform).  Loaded ONCE, at the
-// top of a kernel, with straight-line scalar loads — a loop over r with a scalar load + wait per window inside the pixel
-// code costs a memory round trip per window per use.  Unused slots are empty windows.
-struct Windows {
-  int r0[DP_MAX_RECTS], r1[DP_MAX_RECTS], c0[DP_MAX_RECTS], c1[DP_MAX_RECTS];
-};
-
-__device__ __forceinline__ Windows load_windows(const int32_t *__restrict__ t, int R) {
-  Windows w;
-#pragma unroll
-  for (int r = 0; r < DP_MAX_RECTS; ++r) {
-    const bool on = t != nullptr && r < R;
-    w.r0[r] = on ? t[4 * r] : 0;
-    w.r1[r] = on ? t[4 * r + 1] : 0;
-    w.c0[r] = on ? t[4 * r + 2] : 0;
-    w.c1[r] = on ? t[4 * r + 3] : 0;
-  }
-  return w;
+// Bits [c0 - x, c1 - x) clamped to the 4 pixels (h, x .. x + 3) of a lane, if row h lies in [r0, r1): a bit-field mask
+// instead of 4 x 2 compares per window (c1 > c0 and r1 > r0 required: callers test liveness first).
+__device__ __forceinline__ unsigned window_bits4(int r0, int r1, int c0, int c1, int h, int x) {
+  const int lo = min(max(c0 - x, 0), 4), hi = min(max(c1 - x, 0), 4);
+  const unsigned m = ((1u << (hi - lo)) - 1u) << lo;
+  return ((unsigned)(h - r0) < (unsigned)(r1 - r0)) ? m : 0u;
 }
 
-__device__ __forceinline__ bool windows_touch(const Windows &w, int h0, int h1, int w0, int w1) {
-  bool hit = false;
-#pragma unroll
-  for (int r = 0; r < DP_MAX_RECTS; ++r) hit |= (w.r0[r] < h1 && w.r1[r] > h0 && w.c0[r] < w1 && w.c1[r] > w0);
-  return hit;
-}
-
-__device__ __forceinline__ unsigned occluded4w(const Windows &w, int h, int x) {
-  unsigned occ = 0u;
-#pragma unroll
-  for (int r = 0; r < DP_MAX_RECTS; ++r) {
-    const bool row = h >= w.r0[r] && h < w.r1[r];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) occ |= (unsigned)(row & (x + j >= w.c0[r]) & (x + j < w.c1[r])) << j;
-  }
-  return occ;
+// Is window t = {r0, r1, c0, c1} non-empty and does it intersect rows [h0, h1) x columns [x0, x1)?
+__device__ __forceinline__ bool window_live(const int32_t *__restrict__ t, int h0, int h1, int x0, int x1) {
+  const int r0 = t[0], r1 = t[1], c0 = t[2], c1 = t[3];
+  return r1 > r0 && c1 > c0 && r0 < h1 && r1 > h0 && c0 < x1 && c1 > x0;
 }
 
 // Does any window of table entry t intersect rows [h0, h1) x columns [w0, w1)?  Scalar (block-uniform) code: lets a
@@ -488,24 +464,33 @@ __device__ __forceinline__ void affine_taps_global(const Affine &A, const float 
   }
 }
 
-// grid: x = 32 x 32 output tiles (row-major), y = sample, z = image.  Thread (ly = tid / 8, lx = 4 * (tid % 8)) owns
-// output pixels (ty0 + ly, tx0 + lx .. + 3) of all 3 channels.
-__global__ __launch_bounds__(kBlock) void k_apply_affine_fwd(
-    const float *__restrict__ x, const float *__restrict__ delta, const float *__restrict__ theta,
-    const int32_t *__restrict__ table, int R, const int32_t *__restrict__ idx,
-    const int32_t *__restrict__ idx2, int idx_bstride, int S, int H, int W, int tiles_x, NormDev nd,
-    float *__restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float sd[3 * kAffCapF];
-  const int P = H * W;
-  const int s = blockIdx.y, b = blockIdx.z;
-  const int tx0 = (blockIdx.x % tiles_x) * kAffT, ty0 = (blockIdx.x / tiles_x) * kAffT;
-  const Affine A = load_affine(theta, (size_t)b * S + s);
-  const Windows w1 = load_windows(table + (size_t)idx[(size_t)b * idx_bstride + s] * R * 4, R);
-  const Windows w2 = load_windows(idx2 ? table + (size_t)idx2[(size_t)b * idx_bstride + s] * R * 4 : nullptr, R);
-  const float *xb = x + (size_t)b * 3 * P, *db = delta + (size_t)b * 3 * P;
-  float *ob = out + ((size_t)b * S + s) * 3 * P;
+// Value of lane `lane` (wave-uniform index) in every lane: v_readlane_b32, the result lives in an SGPR.
+__device__ __forceinline__ int lane_bcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 
-  // source footprint of the tile: the map is affine, so its extremes are at the tile's corners
+// 16-byte loads through a raw buffer descriptor over [p, p + bytes): a byte offset at or beyond `bytes` returns zeros
+// (hardware range check), so "this float4 lies outside the image" costs one select on the OFFSET instead of four on the
+// data, and the address is a 32-bit offset instead of a 64-bit pointer.  Descriptor word 3 = 0x00020000: raw dword data
+// format for gfx9 / CDNA.
+constexpr unsigned kBufOutOfRange = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_plane_buffer(const float *p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f4 buffer_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+
+// Source footprint of a 32 x 32 output tile under one sample's map: the map is affine, so its extremes are at the tile's
+// corners.  Box = [floor(lo) - 1, floor(hi) + 2] (the +1 tap and one pixel of margin either side: rounding of interior
+// points); the left edge is aligned down to a multiple of 4 pixels so that every lane stages whole, 16-byte aligned float4s.
+struct AffFoot {
+  int rx0, ry0, RW4, RH;   // origin, width in float4s (LDS row pitch = 4 * RW4), height
+  bool staged;             // fits the LDS budget (block-uniform)
+};
+
+__device__ __forceinline__ AffFoot affine_footprint(const Affine &A, int tx0, int ty0, int H, int W) {
   const int cx1 = min(tx0 + kAffT - 1, W - 1), cy1 = min(ty0 + kAffT - 1, H - 1);
   float sx00, sy00, sx01, sy01, sx10, sy10, sx11, sy11;
   affine_src(A, tx0, ty0, sx00, sy00);
@@ -514,94 +499,179 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_fwd(
   affine_src(A, cx1, cy1, sx11, sy11);
   const float fx_lo = fminf(fminf(sx00, sx01), fminf(sx10, sx11)), fx_hi = fmaxf(fmaxf(sx00, sx01), fmaxf(sx10, sx11));
   const float fy_lo = fminf(fminf(sy00, sy01), fminf(sy10, sy11)), fy_hi = fmaxf(fmaxf(sy00, sy01), fmaxf(sy10, sy11));
-  // [floor(lo) - 1, floor(hi) + 2]: the +1 tap and one pixel of margin either side (rounding of interior points); the
-  // left edge is aligned down to a multiple of 4 pixels so that every lane stages whole, 16-byte aligned float4s
   const bool finite = fabsf(fx_lo) < 1e6f && fabsf(fx_hi) < 1e6f && fabsf(fy_lo) < 1e6f && fabsf(fy_hi) < 1e6f;
-  const int rx0 = finite ? ((int)floorf(fx_lo) - 1) & ~3 : 0, ry0 = finite ? (int)floorf(fy_lo) - 1 : 0;
-  const int RW4 = finite ? (((int)floorf(fx_hi) + 2 - rx0) >> 2) + 1 : 1 << 20, RH = finite ? (int)floorf(fy_hi) + 2 - ry0 + 1 : 1;
-  const int RW = RW4 << 2;   // LDS row pitch
-  const bool staged = RW4 <= 16 && RH <= kAffRowsF * 16 && RW * RH <= kAffCapF;   // block-uniform
+  AffFoot F;
+  F.rx0 = finite ? ((int)floorf(fx_lo) - 1) & ~3 : 0;
+  F.ry0 = finite ? (int)floorf(fy_lo) - 1 : 0;
+  F.RW4 = finite ? (((int)floorf(fx_hi) + 2 - F.rx0) >> 2) + 1 : 1 << 20;
+  F.RH = finite ? (int)floorf(fy_hi) + 2 - F.ry0 + 1 : 1;
+  F.staged = F.RW4 <= 16 && F.RH <= kAffRowsF * 16 && (F.RW4 << 2) * F.RH <= kAffCapF;
+  return F;
+}
 
-  // this lane's own pixels of x: requested before the staging traffic, consumed after the barrier
+// Lane (row = tid / 16, col4 = tid % 16) requests one float4 of 16 footprint rows per pass, 3 channels: ALL 3 * kAffRowsF
+// loads are issued back to back (first tiled version: dword loads, a load / store pair per loop iteration = ~11 serialised
+// round trips and 4x the instructions: 0.63 ms, profiles/r03b_kbench_affine.txt).  Zeros stand for out-of-image pixels:
+// `db` is a buffer descriptor over the image's 3 planes and an outside float4 gets an out-of-range offset.
+__device__ __forceinline__ void affine_foot_load(const AffFoot &F, __amdgpu_buffer_rsrc_t db, int P, int H, int W,
+                                                 f4 v[kAffRowsF][3]) {
+  const int col4 = threadIdx.x & 15, row = threadIdx.x >> 4;
+  const int gx = F.rx0 + (col4 << 2);
+  const bool colok = col4 < F.RW4 && gx >= 0 && gx < W;     // aligned and W % 4 == 0: a float4 is inside or outside as a whole
+#pragma unroll
+  for (int i = 0; i < kAffRowsF; ++i) {
+    const int ry = row + i * 16, gy = F.ry0 + ry;
+    const bool ok = colok && gy >= 0 && gy < H && ry < F.RH;
+    const unsigned o = ok ? (unsigned)(gy * W + gx) << 2 : kBufOutOfRange;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[i][c] = buffer_load4(db, o + (unsigned)c * ((unsigned)P << 2));
+  }
+}
+
+__device__ __forceinline__ void affine_foot_store(const AffFoot &F, const f4 v[kAffRowsF][3], float *__restrict__ sd) {
+  const int col4 = threadIdx.x & 15, row = threadIdx.x >> 4;
+  if (col4 < F.RW4) {
+#pragma unroll
+    for (int i = 0; i < kAffRowsF; ++i) {
+      const int ry = row + i * 16;
+      if (ry < F.RH) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) *reinterpret_cast<f4 *>(sd + c * kAffCapF + ry * (F.RW4 << 2) + (col4 << 2)) = v[i][c];
+      }
+    }
+  }
+}
+
+// grid: x = 32 x 32 output tiles (row-major), y = chunk of s_per_block samples, z = image.  Thread (ly = tid / 8,
+// lx = 4 * (tid % 8)) owns output pixels (ty0 + ly, tx0 + lx .. + 3) of all 3 channels.  The workgroup walks its samples
+// with the NEXT sample's footprint in flight (registers) while it takes the CURRENT sample's taps from LDS: the
+// one-sample-per-workgroup version spent 40 % of a wave's cycles parked at the footprint's waitcnt / the barrier with
+// only 4 workgroups per CU (36 KiB of LDS each) to cover for it (profiles/r03j_sq_counters_affine_kernels.txt).  The
+// tile of x is read once per chunk instead of once per sample.
+__global__ __launch_bounds__(kBlock) void k_apply_affine_fwd(
+    const float *__restrict__ x, const float *__restrict__ delta, const float *__restrict__ theta,
+    const int32_t *__restrict__ table, int R, const int32_t *__restrict__ idx,
+    const int32_t *__restrict__ idx2, int idx_bstride, int S, int H, int W, int tiles_x, int s_per_block, NormDev nd,
+    float *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float sd[3 * kAffCapF];
+  const int P = H * W;
+  const int b = blockIdx.z;
+  const int s_begin = blockIdx.y * s_per_block, s_end = min(S, s_begin + s_per_block);
+  const int tx0 = (blockIdx.x % tiles_x) * kAffT, ty0 = (blockIdx.x / tiles_x) * kAffT;
+  const float *xb = x + (size_t)b * 3 * P, *db = delta + (size_t)b * 3 * P;
+
+  // this lane's own pixels of x: requested before the staging traffic, consumed after the first barrier
   const int oy = ty0 + (threadIdx.x >> 3), ox = tx0 + ((threadIdx.x & 7) << 2);
   const bool mine = oy < H && ox < W;
   const int g = mine ? (oy * W + ox) >> 2 : 0;
   f4 xv[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) xv[c] = reinterpret_cast<const f4 *>(xb + (size_t)c * P)[g];
+  const __amdgpu_buffer_rsrc_t dbuf = make_plane_buffer(db, (unsigned)(3 * P) << 2);
 
-  if (staged) {
-    // lane (row = tid / 16, col4 = tid % 16) stages one float4 of 16 footprint rows per iteration, 3 channels; ALL
-    // 3 * kAffRowsF loads are issued before the first LDS store (first tiled version: dword loads, a load / store pair
-    // per loop iteration = ~11 serialised round trips and 4x the instructions: 0.63 ms, profiles/r03b_kbench_affine.txt)
-    const int col4 = threadIdx.x & 15, row = threadIdx.x >> 4;
-    const int gx = rx0 + (col4 << 2);
-    const bool colok = col4 < RW4 && gx >= 0 && gx < W;     // aligned and W % 4 == 0: a float4 is inside or outside as a whole
-    f4 v[kAffRowsF][3];
+  // Per-sample block-uniform values of ALL the chunk's samples, once: lane l of every wave takes sample s_begin + l; a
+  // sample's values are then broadcast from its lane (v_readlane into SGPRs).
+  //  * the map and the tile's footprint (~60 vector instructions on uniform values — per sample that was a fifth of the
+  //    kernel); RW4 = 0 encodes "not staged";
+  //  * which of the sample's <= 2 * DP_MAX_RECTS occlusion windows touch this tile at all (bit r: window r of idx, bit
+  //    DP_MAX_RECTS + r: of idx2).  Most (tile, window) pairs do not: such a sample costs one v_readlane and a scalar
+  //    branch; a live window costs 4 scalar loads and 11 vector instructions.  (First version: both entries' windows in
+  //    32 SGPRs per sample, every slot tested per pixel: a quarter of the vector instructions, and SGPR spills.)
+  const int lane = threadIdx.x & 63;
+  const int sl = min(s_begin + lane, s_end - 1);
+  const int m1l = idx[(size_t)b * idx_bstride + sl], m2l = idx2 ? idx2[(size_t)b * idx_bstride + sl] : 0;
+  unsigned livel = 0u;
+  for (int r = 0; r < R; ++r) {
+    livel |= (unsigned)window_live(table + ((size_t)m1l * R + r) * 4, ty0, ty0 + kAffT, tx0, tx0 + kAffT) << r;
+    if (idx2)
+      livel |= (unsigned)window_live(table + ((size_t)m2l * R + r) * 4, ty0, ty0 + kAffT, tx0, tx0 + kAffT) << (DP_MAX_RECTS + r);
+  }
+  const Affine Al = [&] {
+    const float *t = theta + ((size_t)b * S + min(s_begin + lane, s_end - 1)) * 6;
+    return Affine{t[0], t[1], t[2], t[3], t[4], t[5]};
+  }();
+  AffFoot Fl = affine_footprint(Al, tx0, ty0, H, W);
+  if (!Fl.staged) Fl.RW4 = 0;
+  auto foot_of = [&](int k) {
+    AffFoot F;
+    F.rx0 = lane_bcast(Fl.rx0, k);
+    F.ry0 = lane_bcast(Fl.ry0, k);
+    F.RW4 = lane_bcast(Fl.RW4, k);
+    F.RH = lane_bcast(Fl.RH, k);
+    F.staged = F.RW4 > 0;
+    return F;
+  };
+
+  AffFoot Fn = foot_of(0);
+  f4 fv[kAffRowsF][3];
+  if (Fn.staged) affine_foot_load(Fn, dbuf, P, H, W, fv);
+
+  for (int s = s_begin; s < s_end; ++s) {
+    const int k = s - s_begin;
+    const AffFoot F = Fn;
+    __syncthreads();   // the previous sample's taps are done with the buffer
+    if (F.staged) affine_foot_store(F, fv, sd);
+    __syncthreads();
+    if (s + 1 < s_end) {   // next sample's footprint: in flight while this sample's taps are taken (block-uniform branches)
+      Fn = foot_of(k + 1);
+      if (Fn.staged) affine_foot_load(Fn, dbuf, P, H, W, fv);
+    }
+    const Affine A = Affine{lane_bcast(Al.a00, k), lane_bcast(Al.a01, k), lane_bcast(Al.t0, k),
+                            lane_bcast(Al.a10, k), lane_bcast(Al.a11, k), lane_bcast(Al.t1, k)};
+    const unsigned live = (unsigned)lane_bcast((int)livel, k);   // block-uniform
+    const int m1 = lane_bcast(m1l, k), m2 = lane_bcast(m2l, k);
+    if (!mine) continue;
+    unsigned occ = 0u;
+    if (live) {
+      const int32_t *t1 = table + (size_t)m1 * R * 4, *t2 = table + (size_t)m2 * R * 4;
 #pragma unroll
-    for (int i = 0; i < kAffRowsF; ++i) {
-      const int ry = row + i * 16, gy = ry0 + ry;
-      const bool ok = colok && gy >= 0 && gy < H && ry < RH;
-      const size_t o = ((size_t)(ok ? gy : 0) * W + (ok ? gx : 0)) >> 2;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const f4 t = reinterpret_cast<const f4 *>(db + (size_t)c * P)[o];
-        v[i][c] = ok ? t : f4{0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < DP_MAX_RECTS; ++r) {
+        if (live >> r & 1u) occ |= window_bits4(t1[4 * r], t1[4 * r + 1], t1[4 * r + 2], t1[4 * r + 3], oy, ox);
+        if (live >> (DP_MAX_RECTS + r) & 1u) occ |= window_bits4(t2[4 * r], t2[4 * r + 1], t2[4 * r + 2], t2[4 * r + 3], oy, ox);
       }
     }
-    if (col4 < RW4) {
+    float v[3][4];
 #pragma unroll
-      for (int i = 0; i < kAffRowsF; ++i) {
-        const int ry = row + i * 16;
-        if (ry < RH) {
+    for (int c = 0; c < 3; ++c) {
+      v[c][0] = xv[c].x; v[c][1] = xv[c].y; v[c][2] = xv[c].z; v[c][3] = xv[c].w;
+    }
+    if (F.staged) {   // block-uniform, tested once (inside the pixel loop the compiler kept a branch per pixel)
+      const int RW = F.RW4 << 2;
 #pragma unroll
-          for (int c = 0; c < 3; ++c) *reinterpret_cast<f4 *>(sd + c * kAffCapF + ry * RW + (col4 << 2)) = v[i][c];
+      for (int j = 0; j < 4; ++j) {
+        float sx, sy;
+        affine_src(A, ox + j, oy, sx, sy);
+        const float fx0 = floorf(sx), fy0 = floorf(sy);
+        const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+        // clamped for memory safety only: with the margin a tap never leaves the staged box
+        const int ix = min(max((int)fx0 - F.rx0, 0), RW - 2), iy = min(max((int)fy0 - F.ry0, 0), F.RH - 2);
+        const float *t = sd + iy * RW + ix;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {  // tap order fixed: (y0,x0), (y0,x1), (y1,x0), (y1,x1); zeros stand for out-of-image taps
+          const float *tc = t + c * kAffCapF;
+          v[c][j] += __builtin_fmaf(wy1 * wx1, tc[RW + 1],
+                                    __builtin_fmaf(wy1 * wx0, tc[RW], __builtin_fmaf(wy0 * wx1, tc[1], (wy0 * wx0) * tc[0])));
         }
       }
-    }
-  }
-  __syncthreads();
-
-  if (!mine) return;
-  unsigned occ = 0u;   // tiles no window touches (block-uniform test) skip the per-pixel compares
-  if (windows_touch(w1, ty0, ty0 + kAffT, tx0, tx0 + kAffT)) occ |= occluded4w(w1, oy, ox);
-  if (windows_touch(w2, ty0, ty0 + kAffT, tx0, tx0 + kAffT)) occ |= occluded4w(w2, oy, ox);
-  float v[3][4];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    v[c][0] = xv[c].x; v[c][1] = xv[c].y; v[c][2] = xv[c].z; v[c][3] = xv[c].w;
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float acc[3];
-    if (staged) {
-      float sx, sy;
-      affine_src(A, ox + j, oy, sx, sy);
-      const float fx0 = floorf(sx), fy0 = floorf(sy);
-      const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-      // clamped for memory safety only: with the margin a tap never leaves the staged box
-      const int ix = min(max((int)fx0 - rx0, 0), RW - 2), iy = min(max((int)fy0 - ry0, 0), RH - 2);
-      const float *t = sd + iy * RW + ix;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {  // tap order fixed: (y0,x0), (y0,x1), (y1,x0), (y1,x1); zeros stand for out-of-image taps
-        const float *tc = t + c * kAffCapF;
-        acc[c] = __builtin_fmaf(wy1 * wx1, tc[RW + 1],
-                                __builtin_fmaf(wy1 * wx0, tc[RW], __builtin_fmaf(wy0 * wx1, tc[1], (wy0 * wx0) * tc[0])));
-      }
     } else {
-      affine_taps_global(A, db, P, H, W, ox + j, oy, acc);
-    }
+      for (int j = 0; j < 4; ++j) {
+        float acc[3];
+        affine_taps_global(A, db, P, H, W, ox + j, oy, acc);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) v[c][j] += acc[c];
-  }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    f4 t = f4{v[c][0], v[c][1], v[c][2], v[c][3]};
-    if (nd.enable) {   // reference NormModel: true division; a power-of-two std makes the reciprocal multiply identical
-      if (nd.rstd_exact) t = (t - nd.mean[c]) * nd.rstd[c];
-      else t = (t - nd.mean[c]) / nd.std[c];
+        for (int c = 0; c < 3; ++c) v[c][j] += acc[c];
+      }
     }
-    __builtin_nontemporal_store(select4(occ, t, nd.fill[c]), reinterpret_cast<f4 *>(ob + (size_t)c * P) + g);
+    float *ob = out + ((size_t)b * S + s) * 3 * P;
+    const bool any = live != 0u;   // block-uniform: a tile no window touches stores without the 4 selects per channel
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      f4 t = f4{v[c][0], v[c][1], v[c][2], v[c][3]};
+      if (nd.enable) {   // reference NormModel: true division; a power-of-two std makes the reciprocal multiply identical
+        if (nd.rstd_exact) t = (t - nd.mean[c]) * nd.rstd[c];
+        else t = (t - nd.mean[c]) / nd.std[c];
+      }
+      __builtin_nontemporal_store(any ? select4(occ, t, nd.fill[c]) : t, reinterpret_cast<f4 *>(ob + (size_t)c * P) + g);
+    }
   }
 }
 
@@ -2740,6 +2810,10 @@ int dp_apply_bwd(const float *G, const int32_t *table, int R, const int32_t *idx
   return launch_status();
 }
 
+// samples one forward workgroup walks (software-pipelined footprint loads); tools/kbench overrides it to sweep
+constexpr int kAffSamplesPerBlock = 8;
+static int g_aff_samples_per_block = 0;
+
 static int launch_apply_affine_fwd(const float *x, const float *delta, const float *theta, const int32_t *table, int R,
                                    const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
                                    const dp_norm_t *norm, float *out, dp_stream_t stream, hipEvent_t ev_start,
@@ -2747,11 +2821,20 @@ static int launch_apply_affine_fwd(const float *x, const float *delta, const flo
   DP_REQUIRE(x && delta && theta && out && aligned16(x) && aligned16(out));
   const int rc = check_occlusion_args(table, R, idx, idx_bstride, B, S, H, W, norm);
   if (rc) return rc;
-  DP_REQUIRE(S <= 65535);
   const int tiles_x = cdiv(W, kAffT), tiles_y = cdiv(H, kAffT);
-  hipExtLaunchKernelGGL(k_apply_affine_fwd, dim3(tiles_x * tiles_y, S, B), dim3(kBlock), 0, as_stream(stream), ev_start,
-                        ev_stop, 0, x, delta, theta, table, R, idx, idx2, idx_bstride, S, H, W, tiles_x, make_norm(norm),
-                        out);
+  DP_REQUIRE((long)H * W * 12 < (1l << 31));   // the footprint loads address delta[b] with 32-bit byte offsets
+  int spb = kAffSamplesPerBlock;   // ... unless that leaves fewer than ~4 workgroups per CU slot (small B)
+  while (spb > 1 && (long)tiles_x * tiles_y * B * cdiv(S, spb) < 4096) spb >>= 1;
+  if (g_aff_samples_per_block > 0) spb = g_aff_samples_per_block;
+  if (const char *e = getenv("DORPATCH_AFFINE_SPB")) {   // test knob: small problems would otherwise never walk > 1 sample
+    const int v = atoi(e);
+    if (v >= 1) spb = v;
+  }
+  spb = min(spb, 64);   // one lane of a wave per sample of the chunk
+  DP_REQUIRE(cdiv(S, spb) <= 65535);
+  hipExtLaunchKernelGGL(k_apply_affine_fwd, dim3(tiles_x * tiles_y, cdiv(S, spb), B), dim3(kBlock), 0, as_stream(stream),
+                        ev_start, ev_stop, 0, x, delta, theta, table, R, idx, idx2, idx_bstride, S, H, W, tiles_x, spb,
+                        make_norm(norm), out);
   return launch_status();
 }
 

@@ -280,6 +280,27 @@ inline hipemu_f4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipemu_f
   return d;
 }
 
+// v_readlane_b32 with a wave-uniform lane index
+inline int __builtin_amdgcn_readlane(int v, int lane) { return hipemu::shuffle(v, lane); }
+
+// Raw buffer descriptor + 16-byte load with the hardware's range check: an offset at or past num_records reads zeros.
+struct __amdgpu_buffer_rsrc_t {
+  const char *base;
+  unsigned bytes;
+};
+inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void *p, short stride, int num_records, int flags) {
+  (void)stride; (void)flags;
+  return __amdgpu_buffer_rsrc_t{(const char *)p, (unsigned)num_records};
+}
+typedef unsigned hipemu_u4 __attribute__((ext_vector_type(4)));
+inline hipemu_u4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int aux) {
+  (void)aux;
+  hipemu_u4 v = {0u, 0u, 0u, 0u};
+  const unsigned long o = (unsigned long)(unsigned)voffset;
+  if (o + 16 <= r.bytes) memcpy(&v, r.base + o + (unsigned)soffset, 16);
+  return v;
+}
+
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...)                              \
   do {                                                                                         \
     (void)(stream);                                                                            \

@@ -96,6 +96,24 @@ def test_affine_apply_matches_grid_sample_oracle_and_its_adjoint(B, S, H, affine
     assert abs(lhs - rhs) <= 1e-5 * (abs(lhs) + 1.0), (lhs, rhs)
 
 
+@pytest.mark.parametrize("B,S,H,affine", [(2, 5, 56, (25.0, (0.7, 1.3), 6.0)), (1, 7, 96, (20.0, (0.42, 1.2), 3.0))])
+def test_forward_is_bit_identical_for_any_number_of_samples_per_workgroup(B, S, H, affine, monkeypatch):
+    """The forward walks `samples per workgroup` samples with the next footprint in flight; small problems get 1 from the
+    launcher, so the walk is forced here (DORPATCH_AFFINE_SPB): 2, 3 (ragged last chunk), 8 (> S: one chunk) against 1.
+    The second case mixes staged and slow-path samples (scale 0.42 .. 1.2) inside one chunk."""
+    x, delta, table_np, idx_np, idx2_np, theta = _setup(B, S, H, seed=11, dual=True, affine=affine)
+    table = ops.upload_table(table_np, DEV)
+    idx, idx2 = torch.from_numpy(idx_np).int().to(DEV), torch.from_numpy(idx2_np).int().to(DEV)
+    norm = ops.make_norm(*NORM, 0.5)
+    th = torch.from_numpy(theta).to(DEV)
+    outs = {}
+    for spb in (1, 2, 3, 8):
+        monkeypatch.setenv("DORPATCH_AFFINE_SPB", str(spb))
+        outs[spb] = ops.apply_affine_fwd(x.to(DEV), delta.to(DEV), th, table, idx, idx2, norm).cpu()
+    for spb in (2, 3, 8):
+        assert torch.equal(outs[spb], outs[1]), spb
+
+
 class FixedPlacement(object):
     def __init__(self, theta):
         self.theta = theta

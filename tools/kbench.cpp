@@ -407,6 +407,16 @@ int main(int argc, char **argv) {
     bench("dp_apply_affine_fwd", out_bytes + 2.0 * B * img, iters, st, [&] {
       DP(dp_apply_affine_fwd(x, g_adv, d_th, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, big, st));
     });
+    for (int spb : {1, 2, 4, 8, 16, 32}) {   // samples per forward workgroup (0 = the launcher's own choice, above)
+      if (spb > S) break;
+      g_aff_samples_per_block = spb;
+      char name[64];
+      snprintf(name, sizeof name, "dp_apply_affine_fwd %2d samples/workgroup", spb);
+      bench(name, out_bytes + 2.0 * B * img, iters, st, [&] {
+        DP(dp_apply_affine_fwd(x, g_adv, d_th, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, big, st));
+      });
+    }
+    g_aff_samples_per_block = 0;
     bench("dp_apply_affine_bwd (+dp_sum_slabs)", out_bytes + (double)B * img, iters, st, [&] {
       DP(dp_apply_affine_bwd(big2, d_th, d_thi, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, nslab == 1 ? g_adv : slabs, st));
       if (nslab > 1) DP(dp_sum_slabs(slabs, nslab, (int64_t)B * 3 * P, g_adv, 0, st));
