@@ -413,27 +413,6 @@ __device__ __forceinline__ bool window_live(const int32_t *__restrict__ t, int h
   return r1 > r0 && c1 > c0 && r0 < h1 && r1 > h0 && c0 < x1 && c1 > x0;
 }
 
-// Does any window of table entry t intersect rows [h0, h1) x columns [w0, w1)?  Scalar (block-uniform) code: lets a
-// workgroup whose tile no window touches skip the per-pixel occlusion tests altogether.
-__device__ __forceinline__ bool windows_touch(const int32_t *__restrict__ t, int R, int h0, int h1, int w0, int w1) {
-  bool hit = false;
-  for (int r = 0; r < R; ++r) hit |= (t[4 * r] < h1 && t[4 * r + 1] > h0 && t[4 * r + 2] < w1 && t[4 * r + 3] > w0);
-  return hit;
-}
-
-// occluded4 for a table entry given by pointer
-__device__ __forceinline__ unsigned occluded4t(const int32_t *__restrict__ t, int R, int h, int w) {
-  unsigned occ = 0u;
-  for (int r = 0; r < R; ++r) {
-    const int r0 = t[4 * r + 0], r1 = t[4 * r + 1], c0 = t[4 * r + 2], c1 = t[4 * r + 3];
-    if (h >= r0 && h < r1) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) occ |= (unsigned)((w + j >= c0) & (w + j < c1)) << j;
-    }
-  }
-  return occ;
-}
-
 __device__ __forceinline__ bool occluded1(const int32_t *__restrict__ t, int R, int h, int w) {
   bool occ = false;
   for (int r = 0; r < R; ++r)
@@ -518,11 +497,12 @@ __device__ __forceinline__ void affine_foot_load(const AffFoot &F, __amdgpu_buff
   const int col4 = threadIdx.x & 15, row = threadIdx.x >> 4;
   const int gx = F.rx0 + (col4 << 2);
   const bool colok = col4 < F.RW4 && gx >= 0 && gx < W;     // aligned and W % 4 == 0: a float4 is inside or outside as a whole
+  const int o0 = __mul24(F.ry0 + row, W) + gx;              // 24-bit multiplies: v_mul_lo_u32 is a quarter-rate instruction
 #pragma unroll
   for (int i = 0; i < kAffRowsF; ++i) {
     const int ry = row + i * 16, gy = F.ry0 + ry;
     const bool ok = colok && gy >= 0 && gy < H && ry < F.RH;
-    const unsigned o = ok ? (unsigned)(gy * W + gx) << 2 : kBufOutOfRange;
+    const unsigned o = ok ? (unsigned)(o0 + i * 16 * W) << 2 : kBufOutOfRange;
 #pragma unroll
     for (int c = 0; c < 3; ++c) v[i][c] = buffer_load4(db, o + (unsigned)c * ((unsigned)P << 2));
   }
@@ -531,12 +511,13 @@ __device__ __forceinline__ void affine_foot_load(const AffFoot &F, __amdgpu_buff
 __device__ __forceinline__ void affine_foot_store(const AffFoot &F, const f4 v[kAffRowsF][3], float *__restrict__ sd) {
   const int col4 = threadIdx.x & 15, row = threadIdx.x >> 4;
   if (col4 < F.RW4) {
+    const int e0 = __mul24(row, F.RW4 << 2) + (col4 << 2);
 #pragma unroll
     for (int i = 0; i < kAffRowsF; ++i) {
       const int ry = row + i * 16;
       if (ry < F.RH) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) *reinterpret_cast<f4 *>(sd + c * kAffCapF + ry * (F.RW4 << 2) + (col4 << 2)) = v[i][c];
+        for (int c = 0; c < 3; ++c) *reinterpret_cast<f4 *>(sd + c * kAffCapF + e0 + i * 16 * (F.RW4 << 2)) = v[i][c];
       }
     }
   }
@@ -645,7 +626,7 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_fwd(
         const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
         // clamped for memory safety only: with the margin a tap never leaves the staged box
         const int ix = min(max((int)fx0 - F.rx0, 0), RW - 2), iy = min(max((int)fy0 - F.ry0, 0), F.RH - 2);
-        const float *t = sd + iy * RW + ix;
+        const float *t = sd + __mul24(iy, RW) + ix;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {  // tap order fixed: (y0,x0), (y0,x1), (y1,x0), (y1,x1); zeros stand for out-of-image taps
           const float *tc = t + c * kAffCapF;
@@ -706,9 +687,59 @@ __device__ __forceinline__ void affine_bwd_pixel_global(const Affine &A, const A
     }
 }
 
+// Output region that can touch a 32 x 16 source tile under one sample's map (block-uniform values, computed one sample
+// per lane).  Box = bounding box of the inverse-mapped tile expanded by one pixel (an output contributes iff floor(src)
+// lies in it), + 2 pixels of margin, clipped to the image; the left edge aligned down to whole float4s.
+struct AffRegion {
+  int qx0a, qy0, QW4, QH;   // origin, width in float4s (LDS row pitch = 4 * QW4), height; QH = 0: no output maps near
+  int kxy;                  // kx | ky << 8: half-widths of a source pixel's candidate window; 0: NOT staged (slow path)
+};
+
+__device__ __forceinline__ AffRegion affine_region(const Affine &Ai, int tx0, int ty0, int H, int W) {
+  const float bx0 = (float)(tx0 - 1), bx1 = (float)min(tx0 + kAffT, W), by0 = (float)(ty0 - 1), by1 = (float)min(ty0 + kAffTB, H);
+  const float qxa = Ai.a00 * bx0, qxb = Ai.a00 * bx1, qxc = Ai.a01 * by0, qxd = Ai.a01 * by1;
+  const float qya = Ai.a10 * bx0, qyb = Ai.a10 * bx1, qyc = Ai.a11 * by0, qyd = Ai.a11 * by1;
+  const float qx_lo = (fminf(qxa, qxb) + fminf(qxc, qxd)) + Ai.t0, qx_hi = (fmaxf(qxa, qxb) + fmaxf(qxc, qxd)) + Ai.t0;
+  const float qy_lo = (fminf(qya, qyb) + fminf(qyc, qyd)) + Ai.t1, qy_hi = (fmaxf(qya, qyb) + fmaxf(qyc, qyd)) + Ai.t1;
+  const bool finite = fabsf(qx_lo) < 1e6f && fabsf(qx_hi) < 1e6f && fabsf(qy_lo) < 1e6f && fabsf(qy_hi) < 1e6f;
+  const int qx0 = finite ? max(0, (int)floorf(qx_lo) - 2) : 0, qx1 = finite ? min(W - 1, (int)ceilf(qx_hi) + 2) : W - 1;
+  const int qy0 = finite ? max(0, (int)floorf(qy_lo) - 2) : 0, qy1 = finite ? min(H - 1, (int)ceilf(qy_hi) + 2) : H - 1;
+  const float ex = fabsf(Ai.a00) + fabsf(Ai.a01), ey = fabsf(Ai.a10) + fabsf(Ai.a11);
+  const int kx = (int)ceilf(ex + 0.01f), ky = (int)ceilf(ey + 0.01f);
+  AffRegion Q;
+  Q.qx0a = qx0 & ~3;
+  Q.qy0 = qy0;
+  Q.QW4 = ((qx1 - Q.qx0a) >> 2) + 1;
+  Q.QH = qy1 - qy0 + 1;
+  if (finite && (qx1 < qx0 || qy1 < qy0)) Q.QH = 0;   // empty: the sample contributes nothing to this tile
+  const bool staged = finite && Q.QW4 >= 1 && Q.QW4 <= 16 && Q.QH <= kAffRowsB * 16 && kx <= 4 && ky <= 4;
+  Q.kxy = staged ? (kx | ky << 8) : 0;
+  return Q;
+}
+
+// Lane (row = tid / 16, col4 = tid % 16) requests 4 consecutive outputs of 16 region rows per pass, 3 channels; the
+// aligned region never leaves the image (qx0a >= 0, aligned right edge <= W - 1 since W % 4 == 0).
+__device__ __forceinline__ void affine_region_load(const AffRegion &Q, const float *__restrict__ Gs, int P, int W,
+                                                   f4 gv[kAffRowsB][3]) {
+  const int col4 = threadIdx.x & 15, row = threadIdx.x >> 4;
+  const bool colok = col4 < Q.QW4;
+  const int o0 = __mul24(Q.qy0 + row, W) + Q.qx0a + (col4 << 2);
+#pragma unroll
+  for (int i = 0; i < kAffRowsB; ++i) {
+    const bool ok = colok && row + i * 16 < Q.QH;
+    const int o = (ok ? o0 + i * 16 * W : __mul24(Q.qy0, W) + Q.qx0a) >> 2;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gv[i][c] = reinterpret_cast<const f4 *>(Gs + (size_t)c * P)[o];
+  }
+}
+
 // grid: x = 32 x 16 SOURCE tiles, y = S-slab, z = image.  Thread (ly = tid / 16, lx = 2 * (tid % 16)) owns source pixels
 // (ty0 + ly, tx0 + lx .. + 1) x 3 channels.  theta_inv (B,S,6) is the inverse map supplied by the host; it only
 // positions the staged region and the candidate windows (both carry a margin), never a weight.
+// Like the forward, the workgroup walks its samples with the NEXT sample's region of G in flight while it gathers from the
+// current one, and takes every per-sample block-uniform value (both maps, the region, which occlusion windows touch the
+// region) from a lane that computed it once, up to 64 samples at a time (first tiled version: ~80 vector instructions and
+// three dependent scalar-load round trips at the head of every sample, the loads waited for immediately).
 __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
     const float *__restrict__ G, const float *__restrict__ theta, const float *__restrict__ theta_inv,
     const int32_t *__restrict__ table, int R, const int32_t *__restrict__ idx,
@@ -723,125 +754,155 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
   const int py = ty0 + (threadIdx.x >> 4), px0 = tx0 + ((threadIdx.x & 15) << 1);
   const bool mine = py < H && px0 < W;   // W % 4 == 0: px0 + 1 < W as well
   const int s_begin = z * s_per_slab, s_end = min(S, s_begin + s_per_slab);
+  const int lane = threadIdx.x & 63;
+  const int col4 = threadIdx.x & 15, row = threadIdx.x >> 4;
   float acc[2][3];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int c = 0; c < 3; ++c) acc[j][c] = 0.f;
-  // source box whose taps this workgroup owns, expanded by one pixel: an output contributes iff floor(src) lies in it
-  const float bx0 = (float)(tx0 - 1), bx1 = (float)min(tx0 + kAffT, W), by0 = (float)(ty0 - 1), by1 = (float)min(ty0 + kAffTB, H);
-  for (int s = s_begin; s < s_end; ++s) {
-    const Affine A = load_affine(theta, (size_t)b * S + s);
-    const Affine Ai = load_affine(theta_inv, (size_t)b * S + s);
-    const int32_t *t1 = table + (size_t)idx[(size_t)b * idx_bstride + s] * R * 4;
-    const int32_t *t2 = idx2 ? table + (size_t)idx2[(size_t)b * idx_bstride + s] * R * 4 : nullptr;
-    const float *Gs = G + ((size_t)b * S + s) * 3 * P;
-    // output region = bounding box of the inverse-mapped source box (+ 2 pixels of margin), clipped to the image
-    const float qxa = Ai.a00 * bx0, qxb = Ai.a00 * bx1, qxc = Ai.a01 * by0, qxd = Ai.a01 * by1;
-    const float qya = Ai.a10 * bx0, qyb = Ai.a10 * bx1, qyc = Ai.a11 * by0, qyd = Ai.a11 * by1;
-    const float qx_lo = (fminf(qxa, qxb) + fminf(qxc, qxd)) + Ai.t0, qx_hi = (fmaxf(qxa, qxb) + fmaxf(qxc, qxd)) + Ai.t0;
-    const float qy_lo = (fminf(qya, qyb) + fminf(qyc, qyd)) + Ai.t1, qy_hi = (fmaxf(qya, qyb) + fmaxf(qyc, qyd)) + Ai.t1;
-    const bool finite = fabsf(qx_lo) < 1e6f && fabsf(qx_hi) < 1e6f && fabsf(qy_lo) < 1e6f && fabsf(qy_hi) < 1e6f;
-    const int qx0 = finite ? max(0, (int)floorf(qx_lo) - 2) : 0, qx1 = finite ? min(W - 1, (int)ceilf(qx_hi) + 2) : W - 1;
-    const int qy0 = finite ? max(0, (int)floorf(qy_lo) - 2) : 0, qy1 = finite ? min(H - 1, (int)ceilf(qy_hi) + 2) : H - 1;
-    const int QW = qx1 - qx0 + 1, QH = qy1 - qy0 + 1;
-    if (finite && (QW <= 0 || QH <= 0)) continue;       // no output maps near this tile (block-uniform)
-    const float ex = fabsf(Ai.a00) + fabsf(Ai.a01), ey = fabsf(Ai.a10) + fabsf(Ai.a11);
-    const int kx = (int)ceilf(ex + 0.01f), ky = (int)ceilf(ey + 0.01f);
-    const int qx0a = qx0 & ~3, QW4 = ((qx1 - qx0a) >> 2) + 1, QWp = QW4 << 2;   // left edge aligned to whole float4s
-    const bool staged = finite && QW4 <= 16 && QH <= kAffRowsB * 16 && kx <= 4 && ky <= 4;
-    if (!staged) {   // slow path: per-pixel walk over global memory
-      if (mine) {
+
+  for (int c_begin = s_begin; c_begin < s_end; c_begin += 64) {   // chunks of <= 64 samples: one lane per sample
+    const int c_end = min(s_end, c_begin + 64);
+    const int sl = min(c_begin + lane, c_end - 1);
+    const float *tp = theta + ((size_t)b * S + sl) * 6, *tip = theta_inv + ((size_t)b * S + sl) * 6;
+    const Affine Al = Affine{tp[0], tp[1], tp[2], tp[3], tp[4], tp[5]};
+    const Affine Ail = Affine{tip[0], tip[1], tip[2], tip[3], tip[4], tip[5]};
+    const AffRegion Ql = affine_region(Ail, tx0, ty0, H, W);
+    const int m1l = idx[(size_t)b * idx_bstride + sl], m2l = idx2 ? idx2[(size_t)b * idx_bstride + sl] : 0;
+    unsigned livel = 0u;   // bit r: window r of idx touches the staged region; bit DP_MAX_RECTS + r: of idx2
+    for (int r = 0; r < R; ++r) {
+      livel |= (unsigned)window_live(table + ((size_t)m1l * R + r) * 4, Ql.qy0, Ql.qy0 + Ql.QH, Ql.qx0a, Ql.qx0a + (Ql.QW4 << 2)) << r;
+      if (idx2)
+        livel |= (unsigned)window_live(table + ((size_t)m2l * R + r) * 4, Ql.qy0, Ql.qy0 + Ql.QH, Ql.qx0a, Ql.qx0a + (Ql.QW4 << 2))
+                 << (DP_MAX_RECTS + r);
+    }
+    auto region_of = [&](int k) {
+      AffRegion Q;
+      Q.qx0a = lane_bcast(Ql.qx0a, k);
+      Q.qy0 = lane_bcast(Ql.qy0, k);
+      Q.QW4 = lane_bcast(Ql.QW4, k);
+      Q.QH = lane_bcast(Ql.QH, k);
+      Q.kxy = lane_bcast(Ql.kxy, k);
+      return Q;
+    };
+
+    AffRegion Qn = region_of(0);
+    f4 gv[kAffRowsB][3];
+    if (Qn.kxy && Qn.QH) affine_region_load(Qn, G + ((size_t)b * S + c_begin) * 3 * P, P, W, gv);
+
+    for (int s = c_begin; s < c_end; ++s) {
+      const int k = s - c_begin;
+      const AffRegion Q = Qn;
+      const Affine A = Affine{lane_bcast(Al.a00, k), lane_bcast(Al.a01, k), lane_bcast(Al.t0, k),
+                              lane_bcast(Al.a10, k), lane_bcast(Al.a11, k), lane_bcast(Al.t1, k)};
+      const Affine Ai = Affine{lane_bcast(Ail.a00, k), lane_bcast(Ail.a01, k), lane_bcast(Ail.t0, k),
+                               lane_bcast(Ail.a10, k), lane_bcast(Ail.a11, k), lane_bcast(Ail.t1, k)};
+      const unsigned live = (unsigned)lane_bcast((int)livel, k);
+      const int m1 = lane_bcast(m1l, k), m2 = lane_bcast(m2l, k);
+      const int32_t *t1 = table + (size_t)m1 * R * 4, *t2 = idx2 ? table + (size_t)m2 * R * 4 : nullptr;
+      const float *Gs = G + ((size_t)b * S + s) * 3 * P;
+      const bool staged = Q.kxy != 0, empty = Q.QH == 0;
+      const int QWp = Q.QW4 << 2;
+
+      __syncthreads();   // the previous sample's gather is done with the staging buffers
+      if (staged && !empty) {
+        // tap records of the region's outputs, computed ONCE per output by the forward's own expression
+        const int ox = Q.qx0a + (col4 << 2);
+        const int e0 = __mul24(row, QWp) + (col4 << 2);
+#pragma unroll
+        for (int i = 0; i < kAffRowsB; ++i) {
+          const int qy = row + i * 16;
+          if (!(col4 < Q.QW4 && qy < Q.QH)) continue;
+          const int oy = Q.qy0 + qy;
+          unsigned occ = 0u;
+          if (live) {   // block-uniform; a window that misses the region costs nothing
+#pragma unroll
+            for (int r = 0; r < DP_MAX_RECTS; ++r) {
+              if (live >> r & 1u) occ |= window_bits4(t1[4 * r], t1[4 * r + 1], t1[4 * r + 2], t1[4 * r + 3], oy, ox);
+              if (live >> (DP_MAX_RECTS + r) & 1u)
+                occ |= window_bits4(t2[4 * r], t2[4 * r + 1], t2[4 * r + 2], t2[4 * r + 3], oy, ox);
+            }
+          }
+          float fxs[4], fys[4];
+          int tap[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float sx, sy;
+            affine_src(A, ox + j, oy, sx, sy);   // the forward's own expression: identical weights
+            const float fx0 = floorf(sx), fy0 = floorf(sy);
+            // tap record: floor(src) relative to (tile origin - 2), 0 = not a neighbour of this tile
+            const float rx = fx0 - (float)(tx0 - 2), ry = fy0 - (float)(ty0 - 2);
+            const bool near = rx >= 0.f && rx < (float)(kAffT + 4) && ry >= 0.f && ry < (float)(kAffTB + 4);
+            tap[j] = near ? (1 + (int)rx + ((int)ry << 8)) : 0;
+            fxs[j] = sx - fx0;
+            fys[j] = sy - fy0;
+          }
+          const int e = e0 + i * 16 * QWp;
+          *reinterpret_cast<i4 *>(stap + e) = i4{tap[0], tap[1], tap[2], tap[3]};
+          *reinterpret_cast<f4 *>(swx + e) = f4{fxs[0], fxs[1], fxs[2], fxs[3]};
+          *reinterpret_cast<f4 *>(swy + e) = f4{fys[0], fys[1], fys[2], fys[3]};
+#pragma unroll
+          for (int c = 0; c < 3; ++c) *reinterpret_cast<f4 *>(sg + c * kAffCapB + e) = select4(occ, gv[i][c], 0.f);
+        }
+      }
+      __syncthreads();
+      if (s + 1 < c_end) {   // next sample's region of G: in flight during this sample's gather
+        Qn = region_of(k + 1);
+        if (Qn.kxy && Qn.QH) affine_region_load(Qn, Gs + (size_t)3 * P, P, W, gv);
+      }
+      if (!mine || empty) continue;
+      if (!staged) {   // slow path: per-pixel walk over global memory
 #pragma unroll
         for (int j = 0; j < 2; ++j) affine_bwd_pixel_global(A, Ai, Gs, t1, t2, R, P, H, W, px0 + j, py, acc[j]);
+        continue;
       }
-      continue;
-    }
-    {
-      // stage the region: lane (row = tid / 16, col4 = tid % 16) takes 4 consecutive outputs of 16 rows per pass; all
-      // 3 * kAffRowsB float4 loads are in flight before the barrier that retires the previous sample's gather
-      const int col4 = threadIdx.x & 15, row = threadIdx.x >> 4;
-      const int ox = qx0a + (col4 << 2);
-      const bool colok = col4 < QW4;       // qx0a >= 0 and the aligned right edge <= W - 1 (W % 4 == 0): always inside the image
-      f4 gv[kAffRowsB][3];
-#pragma unroll
-      for (int i = 0; i < kAffRowsB; ++i) {
-        const int qy = row + i * 16;
-        const bool ok = colok && qy < QH;
-        const size_t o = ((size_t)(ok ? qy0 + qy : qy0) * W + (ok ? ox : qx0a)) >> 2;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) gv[i][c] = reinterpret_cast<const f4 *>(Gs + (size_t)c * P)[o];
-      }
-      // (window coordinates through the scalar cache here: holding both masks' windows in SGPRs across the sample loop
-      // measured 22 % slower — 1.90 vs 1.55 ms, profiles/r03f_kbench_affine.txt vs r03e — the kernel already uses 106 SGPRs)
-      const bool touch1 = windows_touch(t1, R, qy0, qy0 + QH, qx0a, qx0a + QWp);
-      const bool touch2 = t2 && windows_touch(t2, R, qy0, qy0 + QH, qx0a, qx0a + QWp);
-      __syncthreads();   // the previous sample's gather is done with the staging buffers
-#pragma unroll
-      for (int i = 0; i < kAffRowsB; ++i) {
-        const int qy = row + i * 16;
-        if (!(colok && qy < QH)) continue;
-        const int oy = qy0 + qy;
-        unsigned occ = 0u;
-        if (touch1) occ |= occluded4t(t1, R, oy, ox);
-        if (touch2) occ |= occluded4t(t2, R, oy, ox);
-        float fxs[4], fys[4];
-        int tap[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float sx, sy;
-          affine_src(A, ox + j, oy, sx, sy);   // the forward's own expression: identical weights
-          const float fx0 = floorf(sx), fy0 = floorf(sy);
-          // tap record: floor(src) relative to (tile origin - 2), 0 = not a neighbour of this tile
-          const float rx = fx0 - (float)(tx0 - 2), ry = fy0 - (float)(ty0 - 2);
-          const bool near = rx >= 0.f && rx < (float)(kAffT + 4) && ry >= 0.f && ry < (float)(kAffTB + 4);
-          tap[j] = near ? (1 + (int)rx + ((int)ry << 8)) : 0;
-          fxs[j] = sx - fx0;
-          fys[j] = sy - fy0;
-        }
-        const int e = qy * QWp + (col4 << 2);
-        *reinterpret_cast<i4 *>(stap + e) = i4{tap[0], tap[1], tap[2], tap[3]};
-        *reinterpret_cast<f4 *>(swx + e) = f4{fxs[0], fxs[1], fxs[2], fxs[3]};
-        *reinterpret_cast<f4 *>(swy + e) = f4{fys[0], fys[1], fys[2], fys[3]};
-#pragma unroll
-        for (int c = 0; c < 3; ++c) *reinterpret_cast<f4 *>(sg + c * kAffCapB + e) = select4(occ, gv[i][c], 0.f);
-      }
-    }
-    __syncthreads();
-    if (mine) {
       // the thread's two pixels share one candidate window (their inverse images are one output step apart): every
       // staged record is read once and tested against both.  o - floor(c) lies in [1 - k, k] for either pixel.
+      const int kx = Q.kxy & 0xff, ky = Q.kxy >> 8;
       float c0x, c0y, c1x, c1y;
       affine_src(Ai, px0, py, c0x, c0y);
       affine_src(Ai, px0 + 1, py, c1x, c1y);
       const int fx_a = (int)floorf(fminf(c0x, c1x)), fx_b = (int)floorf(fmaxf(c0x, c1x));
       const int fy_a = (int)floorf(fminf(c0y, c1y)), fy_b = (int)floorf(fmaxf(c0y, c1y));
-      const int cqx0 = max(fx_a + 1 - kx - qx0a, 0), cqx1 = min(fx_b + kx - qx0a, QWp - 1);
-      const int cqy0 = max(fy_a + 1 - ky - qy0, 0), cqy1 = min(fy_b + ky - qy0, QH - 1);
+      const int cqx0 = max(fx_a + 1 - kx - Q.qx0a, 0), cqx1 = min(fx_b + kx - Q.qx0a, QWp - 1);
+      const int cqy0 = max(fy_a + 1 - ky - Q.qy0, 0), cqy1 = min(fy_b + ky - Q.qy0, Q.QH - 1);
       const int want0 = 1 + (px0 - (tx0 - 2)) + ((py - (ty0 - 2)) << 8);   // record of an output whose floor(src) == (px0, py)
-      for (int qy = cqy0; qy <= cqy1; ++qy) {
-        for (int e = qy * QWp + cqx0; e <= qy * QWp + cqx1; ++e) {
-          const int d0 = want0 - stap[e];   // (px - x0) + 256 * (py - y0): 0, 1, 256 or 257 for the four taps
-          const int d1 = d0 + 1;
-          const bool hit0 = ((unsigned)d0 & ~0x101u) == 0u, hit1 = ((unsigned)d1 & ~0x101u) == 0u;
-          if (!(hit0 || hit1)) continue;
-          const float fx = swx[e], fy = swy[e];
-          const float g0 = sg[e], g1 = sg[kAffCapB + e], g2 = sg[2 * kAffCapB + e];
-          if (hit0) {
-            float wgt = (d0 & 1) ? fx : 1.f - fx;
-            wgt = ((d0 >> 8) ? fy : 1.f - fy) * wgt;
-            acc[0][0] += wgt * g0;
-            acc[0][1] += wgt * g1;
-            acc[0][2] += wgt * g2;
-          }
-          if (hit1) {
-            float wgt = (d1 & 1) ? fx : 1.f - fx;
-            wgt = ((d1 >> 8) ? fy : 1.f - fy) * wgt;
-            acc[1][0] += wgt * g0;
-            acc[1][1] += wgt * g1;
-            acc[1][2] += wgt * g2;
-          }
+      // one candidate: d = (px - x0) + 256 * (py - y0) is 0, 1, 256 or 257 for the four taps of an output
+      auto candidate = [&](int e, int rec) {
+        const int d0 = want0 - rec, d1 = d0 + 1;
+        const bool hit0 = ((unsigned)d0 & ~0x101u) == 0u, hit1 = ((unsigned)d1 & ~0x101u) == 0u;
+        if (!(hit0 || hit1)) return;
+        const float fx = swx[e], fy = swy[e];
+        const float g0 = sg[e], g1 = sg[kAffCapB + e], g2 = sg[2 * kAffCapB + e];
+        if (hit0) {
+          float wgt = (d0 & 1) ? fx : 1.f - fx;
+          wgt = ((d0 >> 8) ? fy : 1.f - fy) * wgt;
+          acc[0][0] += wgt * g0;
+          acc[0][1] += wgt * g1;
+          acc[0][2] += wgt * g2;
         }
+        if (hit1) {
+          float wgt = (d1 & 1) ? fx : 1.f - fx;
+          wgt = ((d1 >> 8) ? fy : 1.f - fy) * wgt;
+          acc[1][0] += wgt * g0;
+          acc[1][1] += wgt * g1;
+          acc[1][2] += wgt * g2;
+        }
+      };
+      // A row of the window is <= 2 kx + 2 records (6 for the default placement range): its first 6 records are read
+      // back to back before any is tested (one LDS round trip per row instead of one per candidate — the gather spent
+      // its time waiting on them); order of accumulation unchanged: rows ascending, records ascending.
+      constexpr int kRowAhead = 6;
+      for (int qy = cqy0; qy <= (cqx0 <= cqx1 ? cqy1 : cqy0 - 1); ++qy) {   // (an empty column range: no rows)
+        const int er = __mul24(qy, QWp), e0 = er + cqx0, e1 = er + cqx1;
+        int rec[kRowAhead];
+#pragma unroll
+        for (int u = 0; u < kRowAhead; ++u) rec[u] = stap[min(e0 + u, e1)];
+#pragma unroll
+        for (int u = 0; u < kRowAhead; ++u)
+          if (e0 + u <= e1) candidate(e0 + u, rec[u]);
+        for (int e = e0 + kRowAhead; e <= e1; ++e) candidate(e, stap[e]);
       }
     }
   }
@@ -2822,7 +2883,7 @@ static int launch_apply_affine_fwd(const float *x, const float *delta, const flo
   const int rc = check_occlusion_args(table, R, idx, idx_bstride, B, S, H, W, norm);
   if (rc) return rc;
   const int tiles_x = cdiv(W, kAffT), tiles_y = cdiv(H, kAffT);
-  DP_REQUIRE((long)H * W * 12 < (1l << 31));   // the footprint loads address delta[b] with 32-bit byte offsets
+  DP_REQUIRE((long)H * W * 12 < (1l << 31) && H < (1 << 22) && W < (1 << 22));   // 32-bit byte offsets, 24-bit multiplies
   int spb = kAffSamplesPerBlock;   // ... unless that leaves fewer than ~4 workgroups per CU slot (small B)
   while (spb > 1 && (long)tiles_x * tiles_y * B * cdiv(S, spb) < 4096) spb >>= 1;
   if (g_aff_samples_per_block > 0) spb = g_aff_samples_per_block;
@@ -2859,6 +2920,7 @@ int dp_apply_affine_bwd(const float *G, const float *theta, const float *theta_i
   DP_REQUIRE(G && theta && theta_inv && slabs);
   const int rc = check_occlusion_args(table, R, idx, idx_bstride, B, S, H, W, norm);
   if (rc) return rc;
+  DP_REQUIRE(H < (1 << 22) && W < (1 << 22));   // 24-bit multiplies in the region addressing
   const int P = H * W;
   const int s_per_slab = bwd_s_per_slab(B, S, P);
   const int nslab = cdiv(S, s_per_slab);

@@ -2,7 +2,7 @@
 # SQ counters of the apply kernels (one rocprofv3 --pmc pass, kernel-trace only): where do the waves' cycles go?
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r03j; mkdir -p $O
+O=$R/gpurun_out/${PMC_OUT:-r03j}; mkdir -p $O
 cd /tmp
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/pmc -o kb -- $R/tools/kbench 64 32 224 2 "affine" > $O/kbench_under_pmc.txt 2> $O/pmc.err
 python - $O <<'PY'

@@ -114,6 +114,25 @@ def test_forward_is_bit_identical_for_any_number_of_samples_per_workgroup(B, S, 
         assert torch.equal(outs[spb], outs[1]), spb
 
 
+def test_backward_slab_of_more_than_64_samples():
+    """dp_apply_affine_bwd takes its per-sample uniforms from one lane per sample, 64 samples at a time; a slab holds more
+    than 64 samples only when tiles x B >= 4096 and S > 128 (one slab).  84 images x 132 samples at 224^2, identity
+    placement: bit-identical to dp_apply_bwd (GPU only: 6.7 GB of gradients)."""
+    if DEV == "cpu":
+        pytest.skip("6.7 GB problem: GPU only")
+    B, S, H = 84, 132, 224
+    assert ops._lib.load().dp_apply_bwd_nslab(B, S, H * H) == 1
+    table_np = masks.universe_rects(H, 2)
+    rng = np.random.RandomState(5)
+    idx = torch.from_numpy(np.stack([rng.choice(len(table_np), S, replace=False) for _ in range(B)])).int().to(DEV)
+    table = ops.upload_table(table_np, DEV)
+    theta = torch.from_numpy(np.stack([PL.identity(S)] * B)).to(DEV)
+    norm = ops.make_norm(*NORM, 0.5)
+    G = torch.randn(B * S, 3, H, H, generator=torch.Generator(device=DEV).manual_seed(1), device=DEV)
+    got = ops.apply_affine_bwd(G, theta, theta.clone(), table, idx, None, norm, B=B)
+    assert torch.equal(got, ops.apply_bwd(G, table, idx, None, norm, B=B))
+
+
 class FixedPlacement(object):
     def __init__(self, theta):
         self.theta = theta
