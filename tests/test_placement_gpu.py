@@ -114,6 +114,38 @@ def test_forward_is_bit_identical_for_any_number_of_samples_per_workgroup(B, S, 
         assert torch.equal(outs[spb], outs[1]), spb
 
 
+def test_full_size_launch_adjoint_and_walk_invariance():
+    """The benchmark's own launch — 64 images x 32 samples at 224^2, default placement range, PatchCleanser double masks:
+    the launcher's choice (8 samples per forward workgroup) is bit-identical to a walk of 1; <A d, G> == <d, A^T G> in
+    fp64 over all 2048 samples (size-independent property: no CPU oracle at this size); a second pass of either kernel
+    gives the same bits.  GPU only (2.5 GB of samples)."""
+    if DEV == "cpu":
+        pytest.skip("2048 x 3 x 224 x 224 samples: GPU only")
+    import os
+    B, S, H = 64, 32, 224
+    x, delta, table_np, idx_np, idx2_np, theta = _setup(B, S, H, seed=21, dual=True, affine=(10.0, (0.9, 1.1), 8.0))
+    table = ops.upload_table(table_np, DEV)
+    idx, idx2 = torch.from_numpy(idx_np).int().to(DEV), torch.from_numpy(idx2_np).int().to(DEV)
+    th, thi = torch.from_numpy(theta).to(DEV), torch.from_numpy(PL.invert(theta)).to(DEV)
+    raw = ops.make_norm(None, None, 0.0)
+    zero_x, dd = torch.zeros_like(x).to(DEV), delta.to(DEV)
+    assert "DORPATCH_AFFINE_SPB" not in os.environ
+    Ad = ops.apply_affine_fwd(zero_x, dd, th, table, idx, idx2, raw)
+    assert torch.equal(Ad, ops.apply_affine_fwd(zero_x, dd, th, table, idx, idx2, raw))
+    os.environ["DORPATCH_AFFINE_SPB"] = "1"
+    try:
+        assert torch.equal(Ad, ops.apply_affine_fwd(zero_x, dd, th, table, idx, idx2, raw))
+    finally:
+        del os.environ["DORPATCH_AFFINE_SPB"]
+    G = torch.randn(B * S, 3, H, H, generator=torch.Generator(device=DEV).manual_seed(7), device=DEV)
+    AtG = ops.apply_affine_bwd(G, th, thi, table, idx, idx2, ops.RAW_NORM, B=B)
+    assert torch.equal(AtG, ops.apply_affine_bwd(G, th, thi, table, idx, idx2, ops.RAW_NORM, B=B))
+    lhs = float((Ad.double().view(-1) * G.double().view(-1)).sum())
+    rhs = float((dd.double().view(-1) * AtG.double().view(-1)).sum())
+    print("full-size adjoint: <A d, G> = %.9e, <d, A^T G> = %.9e" % (lhs, rhs))
+    assert abs(lhs - rhs) <= 1e-5 * (abs(lhs) + 1.0), (lhs, rhs)
+
+
 def test_backward_slab_of_more_than_64_samples():
     """dp_apply_affine_bwd takes its per-sample uniforms from one lane per sample, 64 samples at a time; a slab holds more
     than 64 samples only when tiles x B >= 4096 and S > 128 (one slab).  84 images x 132 samples at 224^2, identity
