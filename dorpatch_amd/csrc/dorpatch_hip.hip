@@ -396,8 +396,10 @@ constexpr int kAffT = 32;            // tile side (forward: 32 x 32 outputs; bac
 constexpr int kAffTB = 16;
 constexpr int kAffRowsF = 3;         // forward: footprint of at most 64 x 48 source pixels, staged 16 rows x 16 float4 per pass
 constexpr int kAffCapF = 64 * 16 * kAffRowsF;  // ... per channel: 36 KiB of LDS for the 3 channels
-constexpr int kAffRowsB = 2;         // backward: staged output region of at most 64 x 32 pixels
-constexpr int kAffCapB = 64 * 16 * kAffRowsB;  // 6 dwords each: 48 KiB
+constexpr int kAffRowsB = 2;         // backward: staged output region of at most 64 x 32 pixels in 2 passes of 16 rows ...
+constexpr int kAffCapB = 1664;       // ... and at most this many pixels, 6 dwords each: 39 KiB = 4 workgroups per CU (the
+                                     // default placement range needs <= 52 x 32; 2048 = 48 KiB = 3 per CU is the kbench variant:
+                                     // 1.42 vs 1.17 ms, profiles/r03v_kbench_affine.txt)
 
 // Bits [c0 - x, c1 - x) clamped to the 4 pixels (h, x .. x + 3) of a lane, if row h lies in [r0, r1): a bit-field mask
 // instead of 4 x 2 compares per window (c1 > c0 and r1 > r0 required: callers test liveness first).
@@ -695,7 +697,7 @@ struct AffRegion {
   int kxy;                  // kx | ky << 8: half-widths of a source pixel's candidate window; 0: NOT staged (slow path)
 };
 
-__device__ __forceinline__ AffRegion affine_region(const Affine &Ai, int tx0, int ty0, int H, int W) {
+__device__ __forceinline__ AffRegion affine_region(const Affine &Ai, int tx0, int ty0, int H, int W, int cap) {
   const float bx0 = (float)(tx0 - 1), bx1 = (float)min(tx0 + kAffT, W), by0 = (float)(ty0 - 1), by1 = (float)min(ty0 + kAffTB, H);
   const float qxa = Ai.a00 * bx0, qxb = Ai.a00 * bx1, qxc = Ai.a01 * by0, qxd = Ai.a01 * by1;
   const float qya = Ai.a10 * bx0, qyb = Ai.a10 * bx1, qyc = Ai.a11 * by0, qyd = Ai.a11 * by1;
@@ -712,7 +714,7 @@ __device__ __forceinline__ AffRegion affine_region(const Affine &Ai, int tx0, in
   Q.QW4 = ((qx1 - Q.qx0a) >> 2) + 1;
   Q.QH = qy1 - qy0 + 1;
   if (finite && (qx1 < qx0 || qy1 < qy0)) Q.QH = 0;   // empty: the sample contributes nothing to this tile
-  const bool staged = finite && Q.QW4 >= 1 && Q.QW4 <= 16 && Q.QH <= kAffRowsB * 16 && kx <= 4 && ky <= 4;
+  const bool staged = finite && Q.QW4 >= 1 && Q.QW4 <= 16 && Q.QH <= kAffRowsB * 16 && (Q.QW4 << 2) * Q.QH <= cap && kx <= 4 && ky <= 4;
   Q.kxy = staged ? (kx | ky << 8) : 0;
   return Q;
 }
@@ -740,14 +742,15 @@ __device__ __forceinline__ void affine_region_load(const AffRegion &Q, const flo
 // current one, and takes every per-sample block-uniform value (both maps, the region, which occlusion windows touch the
 // region) from a lane that computed it once, up to 64 samples at a time (first tiled version: ~80 vector instructions and
 // three dependent scalar-load round trips at the head of every sample, the loads waited for immediately).
+template <int CAP>
 __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
     const float *__restrict__ G, const float *__restrict__ theta, const float *__restrict__ theta_inv,
     const int32_t *__restrict__ table, int R, const int32_t *__restrict__ idx,
     const int32_t *__restrict__ idx2, int idx_bstride, int B, int S, int H, int W, int tiles_x, int s_per_slab,
     NormDev nd, float *__restrict__ slabs) {
-  __shared__ __attribute__((aligned(16))) float sg[3 * kAffCapB];
-  __shared__ __attribute__((aligned(16))) float swx[kAffCapB], swy[kAffCapB];
-  __shared__ __attribute__((aligned(16))) int stap[kAffCapB];
+  __shared__ __attribute__((aligned(16))) float sg[3 * CAP];
+  __shared__ __attribute__((aligned(16))) float swx[CAP], swy[CAP];
+  __shared__ __attribute__((aligned(16))) int stap[CAP];
   const int P = H * W;
   const int b = blockIdx.z, z = blockIdx.y;
   const int tx0 = (blockIdx.x % tiles_x) * kAffT, ty0 = (blockIdx.x / tiles_x) * kAffTB;
@@ -768,7 +771,7 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
     const float *tp = theta + ((size_t)b * S + sl) * 6, *tip = theta_inv + ((size_t)b * S + sl) * 6;
     const Affine Al = Affine{tp[0], tp[1], tp[2], tp[3], tp[4], tp[5]};
     const Affine Ail = Affine{tip[0], tip[1], tip[2], tip[3], tip[4], tip[5]};
-    const AffRegion Ql = affine_region(Ail, tx0, ty0, H, W);
+    const AffRegion Ql = affine_region(Ail, tx0, ty0, H, W, CAP);
     const int m1l = idx[(size_t)b * idx_bstride + sl], m2l = idx2 ? idx2[(size_t)b * idx_bstride + sl] : 0;
     unsigned livel = 0u;   // bit r: window r of idx touches the staged region; bit DP_MAX_RECTS + r: of idx2
     for (int r = 0; r < R; ++r) {
@@ -843,7 +846,7 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
           *reinterpret_cast<f4 *>(swx + e) = f4{fxs[0], fxs[1], fxs[2], fxs[3]};
           *reinterpret_cast<f4 *>(swy + e) = f4{fys[0], fys[1], fys[2], fys[3]};
 #pragma unroll
-          for (int c = 0; c < 3; ++c) *reinterpret_cast<f4 *>(sg + c * kAffCapB + e) = select4(occ, gv[i][c], 0.f);
+          for (int c = 0; c < 3; ++c) *reinterpret_cast<f4 *>(sg + c * CAP + e) = select4(occ, gv[i][c], 0.f);
         }
       }
       __syncthreads();
@@ -874,7 +877,7 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
         const bool hit0 = ((unsigned)d0 & ~0x101u) == 0u, hit1 = ((unsigned)d1 & ~0x101u) == 0u;
         if (!(hit0 || hit1)) return;
         const float fx = swx[e], fy = swy[e];
-        const float g0 = sg[e], g1 = sg[kAffCapB + e], g2 = sg[2 * kAffCapB + e];
+        const float g0 = sg[e], g1 = sg[CAP + e], g2 = sg[2 * CAP + e];
         if (hit0) {
           float wgt = (d0 & 1) ? fx : 1.f - fx;
           wgt = ((d0 >> 8) ? fy : 1.f - fy) * wgt;
@@ -2914,6 +2917,8 @@ int dp_apply_affine_fwd_timed(const float *x, const float *delta, const float *t
                                  (hipEvent_t)start, (hipEvent_t)stop);
 }
 
+static int g_aff_bwd_cap = 0;   // tools/kbench: 2048 selects the 48 KiB variant
+
 int dp_apply_affine_bwd(const float *G, const float *theta, const float *theta_inv, const int32_t *table, int R,
                         const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
                         const dp_norm_t *norm, float *slabs, dp_stream_t stream) {
@@ -2926,9 +2931,14 @@ int dp_apply_affine_bwd(const float *G, const float *theta, const float *theta_i
   const int nslab = cdiv(S, s_per_slab);
   DP_REQUIRE(nslab <= 65535);
   const int tiles_x = cdiv(W, kAffT), tiles_y = cdiv(H, kAffTB);
-  hipLaunchKernelGGL(k_apply_affine_bwd, dim3(tiles_x * tiles_y, nslab, B), dim3(kBlock), 0, as_stream(stream), G,
-                     theta, theta_inv, table, R, idx, idx2, idx_bstride, B, S, H, W, tiles_x, s_per_slab,
-                     make_norm(norm), slabs);
+  if (g_aff_bwd_cap == 2048)
+    hipLaunchKernelGGL(k_apply_affine_bwd<2048>, dim3(tiles_x * tiles_y, nslab, B), dim3(kBlock), 0, as_stream(stream), G,
+                       theta, theta_inv, table, R, idx, idx2, idx_bstride, B, S, H, W, tiles_x, s_per_slab,
+                       make_norm(norm), slabs);
+  else
+    hipLaunchKernelGGL(k_apply_affine_bwd<kAffCapB>, dim3(tiles_x * tiles_y, nslab, B), dim3(kBlock), 0, as_stream(stream),
+                       G, theta, theta_inv, table, R, idx, idx2, idx_bstride, B, S, H, W, tiles_x, s_per_slab,
+                       make_norm(norm), slabs);
   return launch_status();
 }
 

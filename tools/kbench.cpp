@@ -421,6 +421,12 @@ int main(int argc, char **argv) {
       DP(dp_apply_affine_bwd(big2, d_th, d_thi, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, nslab == 1 ? g_adv : slabs, st));
       if (nslab > 1) DP(dp_sum_slabs(slabs, nslab, (int64_t)B * 3 * P, g_adv, 0, st));
     });
+    g_aff_bwd_cap = 2048;
+    bench("dp_apply_affine_bwd, 48 KiB region (3 workgroups per CU)", out_bytes + (double)B * img, iters, st, [&] {
+      DP(dp_apply_affine_bwd(big2, d_th, d_thi, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, nslab == 1 ? g_adv : slabs, st));
+      if (nslab > 1) DP(dp_sum_slabs(slabs, nslab, (int64_t)B * 3 * P, g_adv, 0, st));
+    });
+    g_aff_bwd_cap = 0;
     {  // the shape HotLoop uses per micro-batch: 8 images x 32 masks
       const int Bm = std::min(B, 8), ns = dp_apply_bwd_nslab(Bm, S, P);
       float *sl = (float *)dmalloc((size_t)ns * Bm * img);
