@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round 3, GPU calls 9 / 17: validation of the round's final tree — full GPU suite with -rs (every skip named) on the
+# Round 3, GPU calls 9 / 17 / 25: validation of the round's final tree — full GPU suite with -rs (every skip named) on the
 # regenerated fixtures, smoke(), short bench, 2 gloo ranks on one device.
 export TMPDIR=/tmp
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
-O=gpurun_out/r03r; mkdir -p $O
+O=gpurun_out/r03z; mkdir -p $O
 ( time timeout 1800 python -m pytest tests -m gpu -q -rs -s --durations=8 -p no:cacheprovider 2>&1 | grep -v "mask size" ) > $O/pytest_gpu.log 2>&1; echo "pytest rc=${PIPESTATUS[0]}" | tee -a $O/rc.txt
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/rc.txt
 ( timeout 300 python bench.py --no-cpu-baseline --no-pmc --no-sweep --steps 10 --warmup 3 ) > $O/bench_short.json 2> $O/bench_short.err; echo "bench rc=$?" | tee -a $O/rc.txt
