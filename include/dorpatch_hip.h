@@ -110,7 +110,8 @@ int dp_apply_bwd(const float *G, const int32_t *table, int R,
  *   dp_apply_affine_bwd  slabs[z,b] = (1/std) sum_{s in slab z} warp^T(keep(s) * G[b,s])      exact adjoint, gather
  *                        form (fixed summation order, no atomics); theta_inv (B,S,2,3) = the inverse maps, used
  *                        only to position the search window; nslab = dp_apply_bwd_nslab(B, S, H*W), then dp_sum_slabs.
- * Identity theta reproduces dp_apply_fwd / dp_apply_bwd bit for bit. */
+ * Identity theta reproduces dp_apply_fwd / dp_apply_bwd bit for bit.  Limits (hipErrorInvalidValue beyond them):
+ * 12 * H * W < 2^31 (32-bit byte offsets into one image's delta), H, W < 2^22. */
 int dp_apply_affine_fwd(const float *x, const float *delta, const float *theta, const int32_t *table, int R,
                         const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
                         const dp_norm_t *norm, float *out, dp_stream_t stream);
