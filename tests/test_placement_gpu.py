@@ -146,6 +146,28 @@ def test_full_size_launch_adjoint_and_walk_invariance():
     assert abs(lhs - rhs) <= 1e-5 * (abs(lhs) + 1.0), (lhs, rhs)
 
 
+def test_size_limits_are_rejected_before_any_launch():
+    """include/dorpatch_hip.h: 12 * H * W < 2^31 and H, W < 2^22 for the placement entry points (32-bit byte offsets,
+    24-bit multiplies in the kernels' addressing).  The calls claim such sizes over tiny buffers: they must return
+    hipErrorInvalidValue (1) without launching."""
+    import ctypes
+    lib = ops._lib.load()
+    buf = torch.zeros(256, device=DEV)
+    theta = torch.from_numpy(PL.identity(1)).to(DEV)
+    table = ops.upload_table(np.zeros((1, 1, 4), dtype=np.int32), DEV)
+    idx = torch.zeros(1, dtype=torch.int32, device=DEV)
+    norm = ops.make_norm(None, None, 0.5)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    fwd = lambda H, W: lib.dp_apply_affine_fwd(p(buf), p(buf), p(theta), p(table), 1, p(idx), None, 1, 1, 1, H, W,
+                                               ctypes.byref(norm), p(buf), None)
+    bwd = lambda H, W: lib.dp_apply_affine_bwd(p(buf), p(theta), p(theta), p(table), 1, p(idx), None, 1, 1, 1, H, W,
+                                               ctypes.byref(norm), p(buf), None)
+    assert fwd(4, 4) == 0 and bwd(4, 4) == 0                      # the same call at a legal size goes through
+    torch.cuda.synchronize() if DEV != "cpu" else None
+    assert fwd(16384, 16384) == 1                                 # 12 * H * W = 3.2e9
+    assert fwd(4, 1 << 22) == 1 and bwd(4, 1 << 22) == 1 and bwd(1 << 22, 4) == 1
+
+
 def test_backward_slab_of_more_than_64_samples():
     """dp_apply_affine_bwd takes its per-sample uniforms from one lane per sample, 64 samples at a time; a slab holds more
     than 64 samples only when tiles x B >= 4096 and S > 128 (one slab).  84 images x 132 samples at 224^2, identity
