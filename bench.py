@@ -2,8 +2,10 @@
 """bench.py — EOT-samples/sec of the DorPatch hot loop on MI355X.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps K --warmup W          # no launcher: spawns its own N ranks (rank r <-> GPU r)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --config 3 --scaling strong --gpus 8   # BASELINE configs[3]: 512 EOT samples of one image, 64 per GPU
     python bench.py --config {0,2,3}            # the other single-GPU BASELINE configs (parity-test cases, also timed)
     DORPATCH_TRACE=1: roctx ranges around the step's phases (for `rocprofv3 --marker-trace --kernel-trace`).
     A/B switches: --deterministic {auto,on,off}, --conv1x1 {table,auto,gemm,miopen}, DORPATCH_TUNABLEOP=0, --stem-split, --skip-satisfied {on,off},
@@ -17,7 +19,13 @@ S-reduction of the input gradients (dp_apply_bwd) -> structural / density / grou
 bookkeeping -> signed update (dp_project_update).  Workload = BASELINE.json configs[1]:
 64 images x 32 sampled double-masks = 2048 EOT samples per step per GPU at 224x224.  With N > 1
 ranks the per-GPU work is fixed (weak scaling: S = 32*N masks per image, 32 per rank) and the ranks
-exchange one all-reduce of the (64,3,224,224) patch gradient per step (RCCL).
+exchange one all-reduce of the (64,3,224,224) patch gradient per step (RCCL).  `--scaling strong` fixes the
+TOTAL instead: --samples is then the number of masks per image over all ranks (each rank takes 1/N of them).
+Launch: under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process is one rank; started
+plainly with --gpus N > 1 it is the launcher — it checks that N GPUs are visible (exit code 2 with a message
+otherwise), starts N copies of itself with RANK = LOCAL_RANK = r on 127.0.0.1, passes rank 0's JSON line
+through, and exits non-zero if any rank fails (the others are terminated).  The reference's mechanism for
+more than one GPU is nn.DataParallel inside one process (main.py:53).
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
   "roofline":     dp_apply_fwd, algorithmic bytes (602 112 B/sample @224) / HIP-event time, vs 8 TB/s;
@@ -51,7 +59,10 @@ PRESETS = {0: (8, 4, 224, 0.0204),          # configs[0]: the reference's own CP
            3: (1, 64, 224, 0.0204)}         # configs[3]: per-GPU share (64 of 512 samples of one image)
 
 
-def parse():
+CONFIG3_TOTAL_SAMPLES = 512              # configs[3]: "512 EOT samples sharded 64/GPU" on 8 GPUs
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--config", type=int, default=None, choices=sorted(PRESETS),
@@ -105,15 +116,35 @@ def parse():
                          "of the multi-rank path — init_process_group(nccl, device_id), broadcast, broadcast_object_list, "
                          "the SUM all-reduce of the step's _comm buffer, the int32 MAX-reduce of the failure bitmap — "
                          "executes on RCCL on a 1-GPU box (they are not short-circuited when world == 1)")
+    ap.add_argument("--whole-attack", action="store_true",
+                    help="NOT the headline metric: time a WHOLE attack the way main.py runs it (reference main.py:82-153) — "
+                         "`main.py --synthetic --targeted --max_iterations K -b B --sampling_size 128`, one batch: stage 0 + "
+                         "stage 1 + the collect_failure sweeps + PatchCleanser at 4 ratios — once with finished images "
+                         "leaving the batch (default) and once with --no_retire; prints seconds per image and the split")
+    ap.add_argument("--attack-iterations", type=int, default=1000, help="--whole-attack: max_iterations per stage")
+    ap.add_argument("--attack-batch", type=int, default=4, help="--whole-attack: images in the batch")
+    ap.add_argument("--attack-modes", default="retire,no_retire", help="--whole-attack: which variants to run")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --samples masks per image PER GPU, the job grows with --gpus; strong: --samples "
+                         "masks per image IN TOTAL, each of the N ranks takes 1/N of them (with --config 3: 512 in total = "
+                         "BASELINE configs[3], 64 per GPU at N = 8)")
     ap.add_argument("--same-device", action="store_true",
                     help="all ranks use cuda:0 (functional test of the multi-rank path on a 1-GPU box; gloo only)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.skip_satisfied is None:          # the what-if only makes sense with the selected-sample backward
         args.skip_satisfied = "on" if args.satisfied is not None else "off"
     if args.config is not None:
         args.batch, args.samples, args.size, args.patch_budget = PRESETS[args.config]
+        if args.config == 3 and args.scaling == "strong":
+            args.samples = CONFIG3_TOTAL_SAMPLES
+    if args.scaling == "strong" and args.samples % max(1, args.gpus):
+        ap.error("--scaling strong: --samples (%d, the total per image) must be divisible by --gpus (%d)"
+                 % (args.samples, args.gpus))
     args.config_label = next(("BASELINE configs[%d]" % k for k, v in PRESETS.items()
                               if v == (args.batch, args.samples, args.size, args.patch_budget)), "custom")
+    if args.config == 3 and args.scaling == "strong":
+        args.config_label = "BASELINE configs[3] (strong scaling: %d EOT samples of one image in total, %d per GPU)" % (
+            args.samples, args.samples // max(1, args.gpus))
     return args
 
 
@@ -245,30 +276,166 @@ def note(msg):
 T_START = time.perf_counter()
 
 
-def main():
-    args = parse()
+def whole_attack(args, dev, model=None, n_classes=None, extra_argv=()):
+    """`--whole-attack`: dorpatch_amd.driver.run (= the reference's main(args), main.py:47-184) on one synthetic batch,
+    per variant.  -> the JSON object.  Seconds are wall clock with the device drained at the boundaries; `stage{0,1}_s`
+    include that stage's failure sweeps (`stage{0,1}_sweeps_s`), `patchcleanser_s` is the 4-ratio certification of the
+    batch, `other_s` what is left of the driver call (model construction, clean forward, file writes)."""
+    import shutil
+    import tempfile
+    from dorpatch_amd import driver
+    B, K, S = args.attack_batch, args.attack_iterations, 128
+    res = {}
+    for mode in [m for m in args.attack_modes.split(",") if m]:
+        tmp = tempfile.mkdtemp(prefix="dp_whole_", dir="/tmp")
+        cwd = os.getcwd()
+        os.chdir(tmp)                       # the reference's result paths are relative (attack.py:103)
+        try:
+            argv = ["--synthetic", "--targeted", "-b", str(B), "--num_images", "1", "--max_iterations", str(K),
+                    "--sampling_size", str(S), "--img_size", str(args.size), "--micro_batch", str(args.micro_batch),
+                    "--quiet"] + (["--no_retire"] if mode == "no_retire" else []) + list(extra_argv)
+            dargs = driver.build_parser().parse_args(argv)
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = driver.run(dargs, device=dev, model=model, n_classes=n_classes)   # model: tests only (a toy net)
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            total = time.perf_counter() - t0
+        finally:
+            os.chdir(cwd)
+            shutil.rmtree(tmp, ignore_errors=True)
+        bd = out["attack_breakdown"][0]
+        n = max(1, bd["images"])
+        res[mode] = {
+            "seconds_per_image": round(total / n, 3), "total_s": round(total, 3), "images": n,
+            "stage0_s": round(bd.get("stage0_s", 0.0), 3), "stage1_s": round(bd.get("stage1_s", 0.0), 3),
+            "stage0_sweeps_s": round(bd.get("stage0_sweeps_s", 0.0), 3), "stage1_sweeps_s": round(bd.get("stage1_sweeps_s", 0.0), 3),
+            "sweeps": bd["sweeps"], "swept_images": bd["swept_images"],
+            "patchcleanser_s": round(out["defense_seconds"], 3),
+            "other_s": round(total - out["attack_seconds"] - out["defense_seconds"], 3),
+            "stage0_steps": bd.get("stage0_steps"), "stage1_steps": bd.get("stage1_steps"),
+            "stage0_image_steps": bd.get("stage0_image_steps"), "stage1_image_steps": bd.get("stage1_image_steps"),
+            "samples_forward": bd["samples_forward"], "samples_back_propagated": bd["samples_back_propagated"],
+            "certified_asr_PC": out["certified_asr_PC"], "acc_robust": out["acc_robust"]}
+        note("whole attack (%s): %.1f s for %d images" % (mode, total, n))
+    first = next(iter(res.values()))
+    line = {"metric": "whole-attack seconds per image", "value": first["seconds_per_image"], "unit": "s/image",
+            "n_gpus": 1, "higher_is_better": False, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "NOT the headline: main.py --synthetic --targeted --max_iterations %d -b %d --sampling_size %d "
+                                   "@%dx%d (reference defaults otherwise: patch_budget 0.12, dropout 2, eps 4), ResNetV2-50x1-BiT "
+                                   "seeded random weights: stage 0 + stage 1 + collect_failure sweeps + PatchCleanser x4 ratios "
+                                   "(reference main.py:82-153)" % (K, B, S, args.size, args.size)},
+            "variants": res}
+    if "retire" in res and "no_retire" in res:
+        line["straggler_saving"] = {
+            "seconds_per_image": round(res["no_retire"]["seconds_per_image"] - res["retire"]["seconds_per_image"], 3),
+            "fraction": round(1.0 - res["retire"]["total_s"] / res["no_retire"]["total_s"], 4),
+            "samples_forward_ratio": round(res["retire"]["samples_forward"] / max(1, res["no_retire"]["samples_forward"]), 4)}
+    return line
+
+
+RANK_HOOK_ENV = "DORPATCH_BENCH_RANK_HOOK"     # TEST HOOK: a Python file exec'd in every rank process before main()
+                                               # (tests/bench_emu_hook.py routes the kernels through the CPU emulation)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this file (RANK = LOCAL_RANK = r,
+    WORLD_SIZE = N, rendezvous on 127.0.0.1:<free port>), rank r bound to GPU r by main().  Rank 0 inherits this
+    process's stdout (its ONE JSON line is the launcher's), every rank inherits stderr.  Returns the exit code: 0 only
+    if every rank exited 0; the first failure terminates the others (a dead rank would leave them in a collective)."""
+    import subprocess
+    n = args.gpus
+    if os.environ.get(RANK_HOOK_ENV) is None and not args.same_device:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            print("bench.py: --gpus %d needs %d visible GPUs, this host shows %d (HIP_VISIBLE_DEVICES=%r); nothing was run"
+                  % (n, n, have, os.environ.get("HIP_VISIBLE_DEVICES")), file=sys.stderr, flush=True)
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    note("launcher: %d ranks started (pids %s), rendezvous 127.0.0.1:%d" % (n, [p.pid for p in procs], port))
+    rc = 0
+    try:
+        live = set(range(n))
+        while live:
+            for r in sorted(live):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print("bench.py: rank %d exited with code %d; terminating the other ranks" % (r, code),
+                          file=sys.stderr, flush=True)
+                    for q in live:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args.size, threads=args.cpu_threads or None)))
-        return
+        return 0
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:       # started without a launcher: be the launcher
+        return launch_ranks(args, argv)
+    hook = os.environ.get(RANK_HOOK_ENV)
+    if hook:                                                    # test infrastructure only, see RANK_HOOK_ENV
+        with open(hook) as f:
+            exec(compile(f.read(), hook, "exec"), {"__name__": "bench_rank_hook", "__file__": hook, "bench": sys.modules[__name__]})
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    if world != args.gpus:
+        print("bench.py: --gpus %d but the launcher's WORLD_SIZE is %d (torch.distributed.run --nproc-per-node must equal "
+              "--gpus)" % (args.gpus, world), file=sys.stderr, flush=True)
+        return 2
     if DEVICE_OVERRIDE is None:
         assert torch.cuda.is_available(), "bench.py needs a ROCm GPU (no CPU fallback for the product path)"
         if args.same_device:
             local_rank = 0
+        if local_rank >= torch.cuda.device_count():
+            print("bench.py: rank %d wants GPU %d, only %d visible" % (rank, local_rank, torch.cuda.device_count()),
+                  file=sys.stderr, flush=True)
+            return 2
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     else:
         dev = torch.device(DEVICE_OVERRIDE)
+    if args.whole_attack:
+        if world != 1:
+            print("bench.py: --whole-attack is a single-GPU measurement", file=sys.stderr, flush=True)
+            return 2
+        print(json.dumps(whole_attack(args, dev)))
+        return 0
     pg = None
     json_fd = None
     if world > 1 or args.force_pg:
-        # RCCL prints a version banner ("RCCL version : ...", 5 lines) on the C stdout of rank 0; stdout must carry exactly
-        # one JSON line, so file descriptor 1 is pointed at stderr for the rest of the run and the JSON line goes to a
-        # duplicate of the original descriptor
-        if args.backend == "nccl":
+        # RCCL prints a version banner ("RCCL version : ...", 5 lines) on the C stdout of rank 0 (gloo: "[Gloo] Rank 0 is
+        # connected to ..."); stdout must carry exactly one JSON line, so file descriptor 1 is pointed at stderr for the
+        # rest of the run and the JSON line goes to a duplicate of the original descriptor (not under the in-process tests,
+        # whose stdout is a Python-level capture)
+        if DEVICE_OVERRIDE is None or os.environ.get(RANK_HOOK_ENV):
             sys.stdout.flush()
             json_fd = os.dup(1)
             os.dup2(2, 1)
@@ -289,8 +456,12 @@ def main():
         GroupNormAct.fused = False
     from dorpatch_amd import conv1x1
     conv1x1.MODE = args.conv1x1
-    B, S_local, H = args.batch, args.samples, args.size
-    S = S_local * world                          # weak scaling: fixed per-GPU work
+    B, H = args.batch, args.size
+    if args.scaling == "strong":                 # fixed total: --samples masks per image over all ranks
+        S, S_local = args.samples, args.samples // world
+    else:                                        # weak scaling: fixed per-GPU work
+        S_local = args.samples
+        S = S_local * world
     torch.manual_seed(1234)
     np.random.seed(1234)
     model = build_model(dev)
@@ -390,7 +561,7 @@ def main():
             "metric": "EOT-samples/sec", "value": round(value, 2), "unit": "EOT-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d images x %d sampled PatchCleanser double-masks per "
                                    "image per GPU = %d EOT samples/step/GPU, %dx%d, ResNetV2-50x1-BiT "
                                    "(seeded random weights, frozen, fp32), stage-%d step of DorPatch.generate, "
@@ -428,7 +599,8 @@ def main():
     if pg is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -111,6 +111,7 @@ class _ImageState(object):
         self.not_decay = 0
         self.num_failure = np.inf
         self.active = True
+        self.steps_in_stage = 0
 
     def n_from_failure(self, i, sampling_size, start):
         """attack.py:193."""
@@ -118,6 +119,7 @@ class _ImageState(object):
 
     def step(self, i, stage, loss_adv, loss_target, sampling_idxs, n_form_failure):
         """Consume this step's losses; returns (save_best, stop).  attack.py:255-316."""
+        self.steps_in_stage += 1
         attack_success = loss_adv < SUCCESS_THRESHOLD            # :255
         mask_success = attack_success                           # :257 (.all(0) over one image)
         new_successes = sampling_idxs[:n_form_failure][mask_success[:n_form_failure]]
@@ -263,6 +265,10 @@ class DorPatch(object):
         skippable; below it every sample is back-propagated in place),
         ``trace`` (default: the environment's ``DORPATCH_TRACE``; ``1`` = roctx ranges
         around the step's phases, ``"log"`` = phase names collected in ``last_run.phases.log`` — see ``_Phases``),
+        ``retire`` (True: an image that has early-stopped in the current stage — the reference ``break``s there,
+        ``attack.py:311-316`` — leaves the batch: only the images still running are occluded, forwarded, back-propagated
+        and swept by ``collect_failure``, so a batch costs the SUM of its images' iterations instead of B x the slowest
+        image's; False: the round-3 behaviour, finished images keep riding along with lr = 0),
         ``tape_tabs`` (micro-batches whose activations one backward may draw from, default: what fits in half of the free
         HBM, at most 8), ``backward_ladder`` (batch sizes the selected-sample backward may use), ``placement``
         (EXTENSION, not in the reference: e.g. ``dorpatch_amd.placement.RandomAffine()`` — every EOT sample sees the
@@ -346,6 +352,22 @@ class DorPatch(object):
 # implementation
 # ======================================================================================
 
+def _every_conv_under_policy(net):
+    """True iff every library convolution of ``net`` goes through ``libconv`` / ``conv1x1`` (per-problem determinism):
+    dorpatch_amd's own ResNetV2 with every StdConv2d folded and frozen, and no other convolution module except the
+    head (which ``ResNetV2.forward`` routes through libconv itself when frozen)."""
+    from . import resnetv2
+    if not isinstance(net, resnetv2.ResNetV2):
+        return False
+    for m in net.modules():
+        if isinstance(m, resnetv2.StdConv2d):
+            if not m.folded or m.weight.requires_grad:
+                return False
+        elif isinstance(m, torch.nn.Conv2d) and m is not net.head.fc:
+            return False
+    return not net.head.fc.weight.requires_grad
+
+
 def tape_z_channels(net):
     return net.stem.conv.out_channels
 
@@ -401,9 +423,24 @@ class HotLoop(object):
     drives it through both stages; ``bench.py`` drives ``step`` directly, so the
     benchmark times exactly the code path ``generate`` executes."""
 
-    def __init__(self, owner, model, x, patch_budget, n_classes, save_dir, batch_id, y, targeted, lr,
-                 confidence, clip_min, clip_max, max_iterations, basic_unit, selection, dropout,
-                 sampling_size, density, structured, eps, dual, extras):
+    def __init__(self, *args):
+        """Process-wide settings changed for the run (frozen parameters, TunableOp scope, libconv.MODE,
+        cudnn.deterministic) are undone by close(); if construction itself raises, close() runs before the exception
+        leaves, so a failed generate() leaves the caller's process as it found it."""
+        from . import libconv
+        self._frozen = []
+        self._tuned_scope = False
+        self._cudnn_det = torch.backends.cudnn.deterministic
+        self._libconv_mode = libconv.MODE
+        try:
+            self._init(*args)
+        except BaseException:
+            self.close()
+            raise
+
+    def _init(self, owner, model, x, patch_budget, n_classes, save_dir, batch_id, y, targeted, lr,
+              confidence, clip_min, clip_max, max_iterations, basic_unit, selection, dropout,
+              sampling_size, density, structured, eps, dual, extras):
         ops.require_gpu(x, "DorPatch.generate (`x`)")
         if dropout not in (1, 2):
             raise ValueError("dropout must be 1 or 2 (reference attack.py:25-31 builds no mask set otherwise)")
@@ -425,6 +462,7 @@ class HotLoop(object):
         self.failure_start = extras.get("failure_sampling_start", 1000)  # attack.py:193
         self.log_every = extras.get("log_every", 20)                  # attack.py:318
         self.step_hook = extras.get("step_hook", None)
+        self.retire = bool(extras.get("retire", True))
         # EXTENSION (dorpatch_amd/placement.py; absent from the reference, which places the patch at identity):
         # an object with .draw(rng, S, H, W) -> (S,2,3) output->source pixel maps, one draw per image per step
         self.placement = extras.get("placement", None)
@@ -437,15 +475,12 @@ class HotLoop(object):
         # Tuned GEMM solutions for the table-routed 1x1 convolutions of dorpatch_amd's own ResNetV2: one verdict per
         # process (rank 0's numeric self-test, agreed by all ranks), in effect only between here and close().
         from . import conv1x1, resnetv2
-        self._tuned_scope = False
         if any(isinstance(m, resnetv2.StdConv2d) for m in self.net.modules()):
             self._tuned_scope = conv1x1.activate(owner.pg, self.dev.type == "cuda")
         self.gemm_solutions = conv1x1.report_tuned()
         # Run-to-run bit reproducibility of the library convolutions (class docstring): True = the global flag for the
         # whole run; "auto" = per (direction, batch, shape) problem, probed at first use (dorpatch_amd/libconv.py).
         from . import libconv
-        self._cudnn_det = torch.backends.cudnn.deterministic
-        self._libconv_mode = libconv.MODE
         if owner.deterministic is True:
             torch.backends.cudnn.deterministic = True
         elif owner.deterministic == "auto" and not torch.backends.cudnn.deterministic:
@@ -454,8 +489,10 @@ class HotLoop(object):
         # The per-problem policy only reaches the library calls of dorpatch_amd's own ResNetV2.  Any other classifier is
         # checked as a whole, as in round 2: the first micro-batch of each row count runs twice, and if the two input
         # gradients differ in any bit the global flag is switched on for the rest of the run (restored by close()).
+        # The policy reaches a convolution only through a FOLDED, frozen StdConv2d (resnetv2.py:49-57): an un-folded
+        # ResNetV2 handed straight to generate() runs plain F.conv2d and is checked as a whole like any other net.
         self._det_whole_net = (owner.deterministic == "auto" and not torch.backends.cudnn.deterministic
-                               and not isinstance(self.net, resnetv2.ResNetV2))
+                               and not _every_conv_under_policy(self.net))
         self._det_rows_checked = set()
 
         owner.criterion = CW_loss(n_classes, targeted, confidence)     # attack.py:57
@@ -531,6 +568,8 @@ class HotLoop(object):
         self.adv_x = torch.empty_like(self.x)
         self.stage = 0
         self.samples_done = 0
+        self.swept_images = 0                 # images x sweeps of collect_failure so far
+        self.timing = {"sweeps_s": 0.0, "sweeps": 0}      # filled by run(): stage{0,1}_s, stage{0,1}_steps, per-image steps
         self.kernel_events = None
         self._conv_shared = False
         # Optional (extras stem_split=True), dorpatch_amd's own ResNetV2 with a frozen stem only: the backward stops at
@@ -639,6 +678,7 @@ class HotLoop(object):
                 self.best_pattern = torch.load(os.path.join(dir_0, "adv_pattern_%d.pt" % self.batch_id),
                                                map_location=self.dev).float().contiguous()
                 continue
+            t0 = self._clock()
             if stage == 1:
                 self._enter_stage1()
             last_i = -1
@@ -647,7 +687,17 @@ class HotLoop(object):
                 if not self.step(i):
                     break
             self._finish_stage(stage, last_i, dir_0)
+            self.timing["stage%d_s" % stage] = self._clock() - t0       # includes this stage's sweeps
+            self.timing["stage%d_steps" % stage] = last_i + 1
+            self.timing["stage%d_image_steps" % stage] = [st.steps_in_stage for st in self.img]
         return self.best_mask.clone(), self.best_pattern.clone()        # attack.py:361
+
+    def _clock(self):
+        """Wall clock with the device drained (stage / sweep accounting only: a handful of calls per run)."""
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+        import time
+        return time.perf_counter()
 
     def _enter_stage1(self):
         """attack.py:143-165."""
@@ -695,13 +745,32 @@ class HotLoop(object):
     def _refresh_failures(self):
         # masks per forward chosen so that B * chunk ~ the training micro-batch: same conv shapes as the
         # hot loop (no extra MIOpen solver searches), bounded activation memory
-        chunk = max(1, self.o.micro_batch // self.B)
-        lists = _collect_failure(self.net, self.norm, self.adv_x, self.y, self.table,
-                                 self._flags("flag_targeted"), chunk, pg=self.o.pg)
-        for st, l in zip(self.img, lists):
-            if st.active:
-                st.failed_idxs = l
+        act = self._running()
+        if not act:
+            return
+        t0 = self._clock()
+        adv_x, y, flags = self.adv_x, self.y, self._flags("flag_targeted")
+        if len(act) < self.B:          # finished images are not swept (their failure lists are never read again)
+            sel = torch.as_tensor(act, dtype=torch.int64, device=self.dev)
+            adv_x, y, flags = adv_x.index_select(0, sel), y.index_select(0, sel), flags[act]
+        chunk = max(1, self.o.micro_batch // len(act))
+        lists = _collect_failure(self.net, self.norm, adv_x, y, self.table, flags, chunk, pg=self.o.pg)
+        for b, l in zip(act, lists):
+            if self.img[b].active:
+                self.img[b].failed_idxs = l
+        self.swept_images += len(act)
+        dt = self._clock() - t0
+        self.timing["sweeps_s"] += dt
+        self.timing["sweeps"] += 1
+        key = "stage%d_sweeps_s" % self.stage
+        self.timing[key] = self.timing.get(key, 0.0) + dt
         self.o._log(">> %d failures collected!" % sum(len(l) for l in lists))
+
+    def _running(self):
+        """Images the EOT pass and the failure sweep cover: all of them, or (``retire``) those still active."""
+        if not self.retire:
+            return list(range(self.B))
+        return [b for b, st in enumerate(self.img) if st.active]
 
     def _draw(self, i):
         for b, st in enumerate(self.img):
@@ -870,8 +939,27 @@ class HotLoop(object):
         """Occlude (dp_apply_fwd), run the frozen backbone forward + input-gradient backward,
         CW loss (dp_cw_loss) and reduce the input gradients over the samples (dp_apply_bwd).
         Micro-batched over whole images (or over S when one image's samples exceed the
-        micro-batch) so activation memory stays bounded; the reduction order is fixed."""
-        B, Sl, S = self.B, self.S_local, self.S
+        micro-batch) so activation memory stays bounded; the reduction order is fixed.
+        With ``retire`` only the images still running take part (attack.py:311-316: the reference stops its one
+        image there): their rows of adv_x / idx / y are gathered into a dense batch, the results scattered back; the
+        patch-gradient rows of finished images are zero (their lr is 0: nothing reads them)."""
+        Sl, S, dev = self.S_local, self.S, self.dev
+        act = self._running()
+        B = len(act)
+        compact = B < self.B
+        adv_x, x, y = self.adv_x, self.x, self.y
+        g_out, loss_flat, pred = self.g_adv, self._own_loss, self.pred    # this rank's slab of the all-reduce buffer
+        if compact:
+            sel = torch.as_tensor(act, dtype=torch.int64, device=dev)
+            adv_x, x, y = adv_x.index_select(0, sel), x.index_select(0, sel), y.index_select(0, sel)
+            idx = idx.index_select(0, sel)
+            idx2 = None if idx2 is None else idx2.index_select(0, sel)
+            crit_flags = crit_flags.index_select(0, sel)
+            g_out = torch.empty((B, 3, self.H, self.W), dtype=torch.float32, device=dev)
+            loss_flat = torch.empty((B * Sl,), dtype=torch.float32, device=dev)
+            pred = torch.empty((B * Sl,), dtype=torch.int32, device=dev)
+        self._run_y, self._run_g, self._run_pred = y, g_out, pred
+        self._run_on = np.asarray([self.img[b].active for b in act], dtype=bool)
         upstream = 1.0 / float(S)                  # loss_adv.mean(1) then .sum().backward()
         mb = max(1, self.o.micro_batch)
         timer = None
@@ -881,15 +969,16 @@ class HotLoop(object):
         theta = theta_inv = delta = None
         if self.placement is not None:     # extension: sample (b, s) sees x + warp(delta, theta[b, s])
             from . import placement as dp_placement
-            th = np.ascontiguousarray(self.theta_np[:, self.s_lo:self.s_hi])
-            theta = torch.as_tensor(th, device=self.dev)
-            theta_inv = torch.as_tensor(dp_placement.invert(th), device=self.dev)
+            th = np.ascontiguousarray(self.theta_np[act][:, self.s_lo:self.s_hi])
+            theta = torch.as_tensor(th, device=dev)
+            theta_inv = torch.as_tensor(dp_placement.invert(th), device=dev)
             delta = ops.blend(self.adv_mask, self.adv_pattern, self.x, self.eps, add_x=False)[0]
-            inp_all = ops.apply_affine_fwd(self.x, delta, theta, self.table, idx, idx2, self.dn, timer=timer)
+            if compact:
+                delta = delta.index_select(0, sel)
+            inp_all = ops.apply_affine_fwd(x, delta, theta, self.table, idx, idx2, self.dn, timer=timer)
         else:
-            inp_all = ops.apply_fwd(self.adv_x, self.table, idx, idx2, self.dn, timer=timer)   # (B*Sl,3,H,W)
+            inp_all = ops.apply_fwd(adv_x, self.table, idx, idx2, self.dn, timer=timer)   # (B*Sl,3,H,W)
         self._placement_ctx = (theta, theta_inv)
-        loss_flat = self._own_loss                 # this rank's (B, S_local) slab of the step's all-reduce buffer
         # micro-batches: (first sample, end sample, first image, end image, first local mask, end local mask, accumulate)
         chunks = []
         if Sl <= mb:
@@ -913,22 +1002,28 @@ class HotLoop(object):
         if not self._taped:
             for c in chunks:
                 n0, n1, b0, b1, s0, s1, _ = c
-                G = self._fb_chunk(inp_all[n0:n1], self.y[b0:b1], crit_flags[b0:b1], s1 - s0,
-                                   upstream, loss_flat[n0:n1], self.pred[n0:n1])
+                G = self._fb_chunk(inp_all[n0:n1], y[b0:b1], crit_flags[b0:b1], s1 - s0,
+                                   upstream, loss_flat[n0:n1], pred[n0:n1])
                 self._reduce_chunk(G, c, idx, idx2)
             self.n_active += B * Sl
             self.n_backward += B * Sl
+        if compact:                                # scatter the dense batch's results to the images' own rows
+            self.g_adv.zero_()
+            self.g_adv.index_copy_(0, sel, g_out)
+            self._own_loss.view(self.B, Sl).index_copy_(0, sel, loss_flat.view(B, Sl))
+            self.pred.view(self.B, Sl).index_copy_(0, sel, pred.view(B, Sl))    # finished images keep their last row
+        self._run_y = self._run_g = self._run_pred = None
         self._own_pred.copy_(self.pred)            # int32 -> fp32 (class ids are exact), rides in the same buffer
 
     def _reduce_chunk(self, G, c, idx, idx2):
         n0, n1, b0, b1, s0, s1, accumulate = c
         if s1 - s0 == self.S_local:                # whole images
             self._reduce_over_samples(G, idx[b0:b1], None if idx2 is None else idx2[b0:b1], b1 - b0,
-                                      self.g_adv[b0:b1], accumulate, (b0, b1, s0, s1))
+                                      self._run_g[b0:b1], accumulate, (b0, b1, s0, s1))
         else:                                      # a slice of one image's samples
             self._reduce_over_samples(G, idx[b0:b1, s0:s1].contiguous(),
                                       None if idx2 is None else idx2[b0:b1, s0:s1].contiguous(), 1,
-                                      self.g_adv[b0:b1], accumulate, (b0, b1, s0, s1))
+                                      self._run_g[b0:b1], accumulate, (b0, b1, s0, s1))
 
     # ---------------------------------------------------------------- backward over the samples that carry gradient
     def _fb_taped(self, inp_all, chunks, idx, idx2, crit_flags, upstream, loss_flat):
@@ -967,17 +1062,17 @@ class HotLoop(object):
                 with torch.no_grad():
                     z = libconv.conv_fwd(inp, conv.weight, conv.stride, conv.padding)
             logits = taped.forward(net, inp, tape, z=z)
-            _, dlogits, pred = ops.cw_loss(logits.float().contiguous(), self.y[b0:b1].contiguous(),
+            _, dlogits, pred = ops.cw_loss(logits.float().contiguous(), self._run_y[b0:b1].contiguous(),
                                            crit_flags[b0:b1].contiguous(), s1 - s0, self.confidence, upstream,
                                            loss_out=loss_flat[n0:n1])
-            self.pred[n0:n1].copy_(pred)
+            self._run_pred[n0:n1].copy_(pred)
             dls.append(dlogits)
         if self._tape_tabs is None:               # size the tapes of the rest of the run
             self._tape_tabs = self._tabs_that_fit(tape.nbytes())
         n_group = tape.n_samples
         dl = dls[0] if len(dls) == 1 else torch.cat(dls)
         act = (dl != 0).any(dim=1).cpu().numpy()   # host sync: the forward of this group is complete
-        img_on = np.asarray([st.active for st in self.img])
+        img_on = self._run_on
         if not img_on.all():                       # early-stopped images: lr = 0, their gradient is never used
             act &= np.concatenate([np.repeat(img_on[b0:b1], s1 - s0) for _, _, b0, b1, s0, s1, _ in group])
         nz = np.flatnonzero(act)

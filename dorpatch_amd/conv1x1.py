@@ -155,36 +155,63 @@ def _selftest_tuned():
     return ok
 
 
-def _decide(pg):
-    """The once-per-process verdict; collective when ``pg`` is a process group (every rank must call it)."""
+def _load_file():
+    """TunableOp reads (and validates) the solution file in this process; its enabled / tuning state is left as found."""
+    try:
+        import torch.cuda.tunable as tun
+        was = (tun.is_enabled(), tun.tuning_is_enabled())
+        tun.enable(True)
+        tun.tuning_enable(False)
+        tun.record_untuned_enable(False)
+        ok = bool(tun.read_file(TUNABLEOP_FILE))
+        tun.enable(was[0])
+        tun.tuning_enable(was[1])
+        return ok
+    except Exception:            # noqa: BLE001 - any refusal simply leaves the default solutions in place
+        return False
+
+
+def _local_verdict(selftest):
+    """This process's own answer, no collective: the file exists, (``selftest``) its solutions pass the numeric self-test
+    in a child process, and TunableOp accepts it here."""
+    if not (TUNABLEOP and os.path.exists(TUNABLEOP_FILE)):
+        return False
+    if selftest and not _selftest_tuned():
+        return False
+    return _load_file()
+
+
+def _agree(pg):
+    """The ranks of ``pg`` settle on ONE verdict — always the same two collectives (a broadcast of rank 0's answer, an
+    all-gather of every rank's), whatever each rank has cached: a rank that already decided locally (e.g. it ran
+    PatchCleanser before its first generate()) and a rank that has not must not enter different collectives.
+    Rank 0's answer includes the numeric self-test; one rank's refusal is every rank's."""
+    global _tuned_verdict
     from . import dist as dp_dist
     _, rank = dp_dist.world_rank(pg)
-    ok = False
-    if TUNABLEOP and os.path.exists(TUNABLEOP_FILE):
-        ok = _selftest_tuned() if rank == 0 else True
-    ok = bool(dp_dist.broadcast_object(ok, pg))             # rank 0's verdict
-    if ok:
-        try:
-            import torch.cuda.tunable as tun
-            was = (tun.is_enabled(), tun.tuning_is_enabled())
-            tun.enable(True)
-            tun.tuning_enable(False)
-            tun.record_untuned_enable(False)
-            ok = bool(tun.read_file(TUNABLEOP_FILE))
-            tun.enable(was[0])
-            tun.tuning_enable(was[1])
-        except Exception:            # noqa: BLE001 - any refusal simply leaves the default solutions in place
-            ok = False
-    return dp_dist.all_true(ok, pg)                          # one rank's refusal is every rank's
+    mine = _tuned_verdict
+    if mine is None:
+        mine = _local_verdict(selftest=(rank == 0))
+    lead = bool(dp_dist.broadcast_object(bool(mine), pg))
+    _tuned_verdict = dp_dist.all_true(bool(mine) and lead, pg)
+    _agreed.add(id(pg))
+
+
+_agreed = set()          # ids of the process groups whose ranks have agreed on the verdict
 
 
 def activate(pg=None, device_is_cuda=True):
-    """Enter a tuned-solution scope (see the life-cycle note above); -> whether the tuned solutions are in effect."""
+    """Enter a tuned-solution scope (see the life-cycle note above); -> whether the tuned solutions are in effect.
+    With a process group the first call per group is collective (``_agree``); without one the verdict is this process's
+    own and is cached — a later activate(pg) still runs the agreement."""
     global _tuned_verdict, _tuned_scope, _tuned_prev
     if not device_is_cuda:
         return False
-    if _tuned_verdict is None:
-        _tuned_verdict = _decide(pg)
+    if pg is not None:
+        if id(pg) not in _agreed:
+            _agree(pg)
+    elif _tuned_verdict is None:
+        _tuned_verdict = _local_verdict(selftest=True)
     if not _tuned_verdict:
         return False
     import torch.cuda.tunable as tun

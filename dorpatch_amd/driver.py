@@ -24,7 +24,8 @@ recomputed, ``main.py:100-118, 144-153``).  What changes is the machinery:
 * extra flags (never part of the result path, so directories stay interchangeable with the
   reference's): ``--num_images`` (the reference hard-codes 10, ``main.py:85``), ``--max_iterations``,
   ``--sampling_size``, ``--img_size``, ``--miopen_find``, ``--synthetic`` (seeded-random weights + ``torch.rand`` images:
-  neither ImageNet nor the checkpoint can be fetched offline), ``--shard``, ``--micro_batch``, ``--skip_satisfied``.
+  neither ImageNet nor the checkpoint can be fetched offline), ``--shard``, ``--micro_batch``, ``--skip_satisfied``,
+  ``--no_retire``.
 """
 import argparse
 import os
@@ -87,6 +88,9 @@ def build_parser():
     extra.add_argument('--skip_satisfied', action='store_true',
                        help='back-propagate only the EOT samples whose CW hinge is still active (DorPatch(skip_satisfied=True); '
                             'off = the reference: every sample)')
+    extra.add_argument('--no_retire', action='store_true',
+                       help='keep early-stopped images of a batch in the EOT pass and the failure sweep until the last image '
+                            'stops (the round-3 behaviour; default: they leave the batch, generate(retire=True))')
     extra.add_argument('--quiet', action='store_true', help='no per-iteration progress lines')
     return parser
 
@@ -182,6 +186,7 @@ def run(args, model=None, dataloader=None, device=None, process_group=None, n_cl
         return bool(dp_dist.broadcast_object(found, process_group)) if shard_samples else found
 
     per_batch = {}                                    # i -> dict of numpy results (gathered over ranks at the end)
+    breakdown = []                                    # this rank's generate() calls: where the seconds went
     t_attack = t_defense = 0.0
     with torch.no_grad():
         for i, (x, y) in enumerate(dataloader):
@@ -222,10 +227,15 @@ def run(args, model=None, dataloader=None, device=None, process_group=None, n_cl
                         y=target if args.targeted else None, lr=args.lr, num_patch=args.num_patch,
                         dropout=args.dropout, density=args.density, structured=args.structured,
                         save_dir=result_dir, batch_id=i, eps=args.epsilon,
-                        max_iterations=args.max_iterations, sampling_size=args.sampling_size)
+                        max_iterations=args.max_iterations, sampling_size=args.sampling_size,
+                        retire=not args.no_retire)
                 if device.type == "cuda":
                     torch.cuda.synchronize()
                 t_attack += time.perf_counter() - t0
+                run_stats = attack.last_run
+                breakdown.append(dict(batch=i, images=int(x.shape[0]), seconds=time.perf_counter() - t0,
+                                      samples_forward=run_stats.n_forward, samples_back_propagated=run_stats.n_backward,
+                                      swept_images=run_stats.swept_images, **run_stats.timing))
                 if owns_files:                                                 # main.py:135-138
                     _atomic_write(ppath, lambda f: torch.save(adv_pattern, f))
                     _atomic_write(mpath, lambda f: torch.save(adv_mask, f))    # the mask last: its presence means "done"
@@ -260,7 +270,8 @@ def run(args, model=None, dataloader=None, device=None, process_group=None, n_cl
     records = [r for i in order for r in per_batch[i]["records"]]
 
     out = summarize(defense, records, preds_list, y_list, preds_adv_list, target_list)     # main.py:161-184
-    out.update(result_dir=result_dir, n_images=int(len(y_list)), attack_seconds=t_attack, defense_seconds=t_defense)
+    out.update(result_dir=result_dir, n_images=int(len(y_list)), attack_seconds=t_attack, defense_seconds=t_defense,
+               attack_breakdown=breakdown)
     if rank == 0:
         print("clean accuracy: {:.2f}%, robust accuracy:{:.2f}%, acc@PC:{:s}%, certified_ACC@PC:{:s}%, "
               "certified_ASR@PC:{:s}%".format(out["acc_clean"], out["acc_robust"],

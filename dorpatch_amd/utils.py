@@ -100,12 +100,29 @@ def get_model(dataset_name, model_name, model_dir='pretrained_models'):
 
 
 def get_dataset(dataset_name, data_dir='/home/data', train=False, batch_size=128, shuffle=True):
-    """Name kept because the reference's ``main.py:1`` star-imports it (``utils.py:81-102``).  Dataset acquisition is
-    outside the accelerated path (OUT OF SCOPE) and is not restated here: build the loader with the
-    reference's own ``utils.get_dataset`` (torchvision) and hand ``DorPatch.generate`` its (B,3,H,W) batches, or run the
-    driver with ``--synthetic``."""
-    raise NotImplementedError("dorpatch_amd does not restate dataset loading (reference utils.py:81-102, out of scope): "
-                              "use the reference's get_dataset / your own DataLoader, or `main.py --synthetic`")
+    """reference ``utils.py:81-102``: a shuffled ``DataLoader`` over the named torchvision dataset (``cifar10`` /
+    ``cifar100`` / ``imagenet`` under ``<data_dir>/<name>``), every image resized to 256 on its short side, centre-cropped to
+    224 x 224 and converted to a float tensor in [0,1].  Dataset acquisition is outside the accelerated path
+    but the driver's default (non ``--synthetic``) route needs it, so the loader is built here on torchvision, imported
+    lazily; without torchvision the ImportError says what to do."""
+    try:
+        from torchvision import datasets, transforms
+    except ImportError as e:
+        raise ImportError("get_dataset(%r) needs torchvision (not installed here): install it, pass your own DataLoader "
+                          "to dorpatch_amd.driver.run(args, dataloader=...), or use `main.py --synthetic`" % dataset_name) from e
+    size = 224
+    pipeline = transforms.Compose([transforms.Resize(int(size / 0.875)), transforms.CenterCrop((size, size)),
+                                   transforms.ToTensor()])
+    root = os.path.join(data_dir, dataset_name)
+    if dataset_name == 'imagenet':
+        dataset = datasets.ImageNet(root=root, split='train' if train else 'val', transform=pipeline)
+    elif dataset_name in ('cifar10', 'cifar100'):
+        cls = datasets.CIFAR10 if dataset_name == 'cifar10' else datasets.CIFAR100
+        dataset = cls(root=root, train=train, download=True, transform=pipeline)
+    else:
+        raise KeyError(dataset_name)
+    print('Dataset has {} instances'.format(len(dataset)))
+    return torch.utils.data.DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, num_workers=1, pin_memory=True)
 
 
 def clip(mask, pattern, x, eps):

@@ -38,6 +38,8 @@ Fixtures
                    iteration 500 of stage 0 (attack.py:169-182), with the reference's ``targeted`` flag, label and the
                    masked copies' predictions per step.
 ``geometry.npz``   MaskWindow geometry for 56/224/384 and mask-universe checksums.
+``end_metric_bit_224.npz``  the end metric at 224 x 224 through ResNetV2-50x1-BiT with a 10-class head: 2 images x
+                   (1 + 3) runs of the unmodified reference (S = 32, 100 iterations per stage), see bit224_problem.
 ``end_metric_56.npz``  8 images x full two-stage reference runs (300 iterations per stage, S = 8, toy nets whose
                    gain sweeps the range where the attack goes from certifiably succeeding to failing): the
                    returned mask / pattern, the failure count over the 2520-mask universe and the reference
@@ -474,7 +476,7 @@ def _pack_null(path, results, n_images, meta):
     return out
 
 
-NULL_RUNS_OF = {"toy": NULL_RUNS, "bit": 3}
+NULL_RUNS_OF = {"toy": NULL_RUNS, "bit": 3, "bit224": 3}
 
 
 def make_end_metric_null_fixture(path, n_images=32, H=56, S=8, max_iterations=300, eps=4.0, procs=4):
@@ -521,8 +523,61 @@ def make_end_metric_bit_fixture(path, n_images=8, H=56, S=8, max_iterations=300,
                                                     patch_budget=0.12, n_classes=1000))
 
 
+# --- and at the size the metric is quoted on: 224 x 224 through ResNetV2-50x1-BiT with a 10-class head
+# (with 1000 near-tied random classes PatchCleanser never certifies anything, see the 56 x 56 fixture), well-conditioned
+# seeded weights, S = 32, 100 iterations per stage, 2 images x (1 + 3) runs of the unmodified reference.  The seeded
+# network is nearly input-insensitive (its logits move by ~0.05 between unrelated random images), so the clean margin
+# between the top class and the runner-up (the target) is what decides whether a patch of L2 <= 4 can win: image 0 keeps
+# the natural margin (~0.46, which a 40-iteration probe showed stage 1 does not close), image 1 gets the target's head
+# bias raised so that the margin is 0.15 (closable) — one problem from each side of the tipping point.
+BIT224_MARGINS = (None, 0.15)
+
+
+def bit224_problem(k, H=224, n_classes=10):
+    from dorpatch_amd.resnetv2 import WELL_CONDITIONED_GN_BIAS, resnetv2_50x1_bit, seeded_init_
+    from dorpatch_amd.utils import NormModel, get_normalize
+    net = seeded_init_(resnetv2_50x1_bit(n_classes), seed=1234, gn_bias=WELL_CONDITIONED_GN_BIAS).fold_weight_standardization().freeze()
+    model = NormModel(net, get_normalize("imagenet", "resnetv2")).eval()
+    x = torch.rand(1, 3, H, H, generator=torch.Generator().manual_seed(400 + k))
+    shift = 0.0
+    with torch.no_grad():
+        top = model(x).topk(2)
+        y = top[1][:, 1].clone()
+        if BIT224_MARGINS[k] is not None:
+            shift = float(top[0][0, 0] - top[0][0, 1]) - BIT224_MARGINS[k]
+            net.head.fc.bias[int(y)] += shift
+    return model, x, y, shift
+
+
+def _bit224_job(job):
+    k, run, H, S, n_it, eps, threads = job
+    torch.set_num_threads(threads)
+    from . import restatement as R
+    ref = ref_shim.load_reference()
+    model, x, y, shift = bit224_problem(k, H)
+    noise = None if run == 0 else (10_000 * run + k, NULL_NOISE_REL)
+    cap, mask, pattern, _ = run_reference(model, x, y, sampling_size=S, max_iterations=n_it, eps=eps, n_classes=10,
+                                          keep=lambda s, i: False, seed=1234 + k, grad_noise=noise)
+    return k, run, _score(ref, R, model, x, y, mask, pattern, H, eps, 10) + (x.numpy()[0], shift)
+
+
+def make_end_metric_bit224_fixture(path, n_images=2, H=224, S=32, max_iterations=100, eps=4.0, procs=2, threads=3):
+    """``end_metric_bit_224.npz``: main.py:168-184's inputs at 224 x 224 through ResNetV2-50x1-BiT, 2 images x (1 + 3)
+    runs of the unmodified reference (~80 minutes on 6 cores).  ``gains`` holds the head-bias shift of each image's
+    target class (0 = none)."""
+    jobs = [(k, run, H, S, max_iterations, eps, threads) for k in range(n_images) for run in range(NULL_RUNS_OF["bit224"] + 1)]
+    results = list(_pool_map(_bit224_job, jobs, procs))
+    return _pack_null(path, results, n_images, dict(name="bit224", H=H, S=S, max_iterations=max_iterations, eps=eps,
+                                                    patch_budget=0.12, n_classes=10,
+                                                    margins=np.array([np.nan if m is None else m for m in BIT224_MARGINS])))
+
+
 def main():
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    if "--only-end-metric-bit224" in sys.argv:
+        o = make_end_metric_bit224_fixture(os.path.join(GOLDEN_DIR, "end_metric_bit_224.npz"))
+        print({k: o[k].tolist() for k in ("n_fail", "pc_pred", "pc_cert", "adv_pred", "target", "clean", "gains")})
+        return
     if "--only-end-metric-null" in sys.argv:
         o = make_end_metric_null_fixture(os.path.join(GOLDEN_DIR, "end_metric_null_56.npz"))
         print({k: o[k].tolist() for k in ("n_fail",)})

@@ -338,6 +338,103 @@ def test_micro_batching_does_not_change_the_step(mb):
     np.testing.assert_allclose(outs[0]["g_adv"].numpy(), outs[1]["g_adv"].numpy(), rtol=1e-4, atol=1e-5 * scale)
 
 
+def _retire_run(retire, *, mb, dropout=1, S=6, B=4, H=56, steps=6, stop_at=(2, 3), dual=False, stage=0):
+    """`steps` steps of a B-image loop; image 1 is marked finished after step stop_at[0]-1, image 3 after stop_at[1]-1
+    (what `_ImageState.step` does at attack.py:311-316).  The failure sweep runs at steps 0, 2, 4."""
+    n_mask = 144 if dropout == 1 else 2520
+    model = _toy(2.0)
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(B, 3, H, H, generator=g)
+    m0, p0 = torch.rand(B, 1, H, H, generator=g), torch.rand(B, 3, H, H, generator=g)
+    y = torch.tensor([1, 4, 7, 2][:B])
+    per_step = 2 if dual else 1
+    rows = [[np.random.RandomState(100 * b + k).choice(n_mask, S, replace=False) for k in range(steps * per_step)]
+            for b in range(B)]
+    seen = []
+    hook = lambda d: seen.append(dict(loss_adv=d["loss_adv"].copy(), g_adv=d["g_adv"].detach().cpu().clone(),
+                                      lr=d["lr"].copy()))
+    loop = HotLoop(DorPatch(micro_batch=mb, verbose=False), model, x.to(DEV), 0.12, 10, "t/cfg/sub", 0, y.to(DEV), True,
+                   1e-2, 1e-1, 0, 1, 10 ** 6, 7, 'topk', dropout, S, 1e-3, 1e-3, 4.0, dual,
+                   dict(init_mask=m0, init_pattern=p0, rngs=[FixedDraw(rows[b]) for b in range(B)], step_hook=hook,
+                        failure_refresh=2, retire=retire))
+    loop.stage = stage
+    preds, fails, n_fwd = [], [], []
+    for i in range(steps):
+        if i == stop_at[0]:
+            loop.img[1].active = False
+        if i == stop_at[1]:
+            loop.img[3].active = False
+        loop.step(i)
+        preds.append(loop.pred_host.copy())
+        fails.append([list(st.failed_idxs) for st in loop.img])
+        n_fwd.append(loop.n_forward)
+    out = dict(seen=seen, preds=preds, fails=fails, n_fwd=n_fwd, swept=loop.swept_images,
+               pattern=loop.adv_pattern.cpu().clone(), mask=loop.adv_mask.cpu().clone(),
+               best_pattern=loop.best_pattern.cpu().clone())
+    loop.close()
+    return out
+
+
+@pytest.mark.parametrize("mb,dual,stage", [(10 ** 6, False, 0), (12, False, 0), (4, False, 1), (12, True, 0)])
+def test_finished_images_leave_the_batch(mb, dual, stage):
+    """the reference stops its single image at attack.py:311-316; in a batch the finished images used
+    to ride along (forwarded, back-propagated, swept, with lr = 0).  With `retire` (default) only the running images
+    are gathered into the EOT pass and the failure sweep.  For the images still running nothing may change: the kernels
+    treat every sample independently, so against `retire=False` their losses, gradients, predictions, failure lists and
+    parameters agree to the last bit whenever the classifier's library kernels are batch-size invariant (the toy nets
+    on the CPU emulation and on the GPU: asserted bit-exact here), and a finished image's rows stay frozen."""
+    on, off = _retire_run(True, mb=mb, dual=dual, stage=stage), _retire_run(False, mb=mb, dual=dual, stage=stage)
+    S, B = 6, 4
+    assert off["n_fwd"] == [B * S * (k + 1) for k in range(6)]                     # everything rides along
+    assert on["n_fwd"] == [24, 48, 48 + 18, 48 + 18 + 12, 48 + 18 + 24, 48 + 18 + 36]
+    assert (off["swept"], on["swept"]) == (12, 4 + 3 + 2)                          # sweeps at steps 0, 2, 4
+    for k in range(6):
+        live = [b for b in range(B) if not ((b == 1 and k >= 2) or (b == 3 and k >= 3))]
+        a, w = on["seen"][k], off["seen"][k]
+        assert np.array_equal(a["lr"], w["lr"]) and all(a["lr"][b] == 0 for b in range(B) if b not in live)
+        assert np.array_equal(a["loss_adv"][live], w["loss_adv"][live])
+        assert torch.equal(a["g_adv"][live], w["g_adv"][live])
+        dead = [b for b in range(B) if b not in live]
+        assert not a["g_adv"][dead].any()                                          # nothing computed for them
+        assert np.array_equal(on["preds"][k], off["preds"][k])                     # finished rows keep their last value
+        for b in live:
+            assert on["fails"][k][b] == off["fails"][k][b]
+    for name in ("pattern", "mask", "best_pattern"):
+        assert torch.equal(on[name], off[name]), name
+
+
+def test_retired_batch_equals_the_batch_of_the_running_images():
+    """The dense batch the running images are gathered into is, bit for bit, the batch a loop over only those images
+    would build: same rows in the same order, same micro-batch boundaries — whatever the library kernels do with a
+    batch size, they do the same in both.  (2 of 4 images finished from the start.)"""
+    H, S, B = 56, 6, 4
+    model = _toy(2.0)
+    g = torch.Generator().manual_seed(22)
+    x = torch.rand(B, 3, H, H, generator=g)
+    m0, p0 = torch.rand(B, 1, H, H, generator=g), torch.rand(B, 3, H, H, generator=g)
+    y = torch.tensor([1, 4, 7, 2])
+    rows = [[np.random.RandomState(100 * b + k).choice(2520, S, replace=False) for k in range(3)] for b in range(B)]
+    keep = [0, 2]
+
+    def run(sel, finished):
+        seen = []
+        loop = _loop(model, x[sel].to(DEV), y[sel].to(DEV), S,
+                     dict(init_mask=m0[sel], init_pattern=p0[sel], rngs=[FixedDraw(rows[b]) for b in sel],
+                          step_hook=lambda d: seen.append((d["loss_adv"].copy(), d["g_adv"].detach().cpu().clone()))), mb=8)
+        for j in finished:
+            loop.img[j].active = False
+        for i in range(1, 4):
+            loop.step(i)
+        out = seen, loop.adv_pattern.cpu().clone(), loop.adv_mask.cpu().clone()
+        loop.close()
+        return out
+
+    full, sub = run([0, 1, 2, 3], [1, 3]), run(keep, [])
+    for (la, ga), (lb, gb) in zip(full[0], sub[0]):
+        assert np.array_equal(la[keep], lb) and torch.equal(ga[keep], gb)
+    assert torch.equal(full[1][keep], sub[1]) and torch.equal(full[2][keep], sub[2])
+
+
 def test_oversampling_and_single_window_universe():
     """attack.py:92-94: a sampling_size larger than the universe is cut to the universe (dropout = 1: the
     4 x 36 = 144 single-window masks), so every mask is drawn exactly once per step; losses match the oracle.

@@ -76,3 +76,100 @@ def test_cpu_baseline_leg_is_bounded_and_labelled():
     assert "oracle/restatement.eot_step" in out["sample"] and "64x64" in out["sample"]
     # both the reference's real behaviour (weights trainable) and the frozen variant, median of timed steps
     assert out["value_frozen"] > 0 and out["detail"]["as_is"]["timed_steps"] == 2 and out["detail"]["frozen"]["timed_steps"] == 2
+
+
+# ---------------------------------------------------------------- the plain command, N > 1
+TINY = ["--batch", "1", "--size", "32", "--steps", "1", "--warmup", "0", "--no-sweep", "--no-cpu-baseline",
+        "--deterministic", "off", "--backend", "gloo"]
+
+
+def _plain(argv, hook=True, timeout=600):
+    """`python bench.py <argv>` as a child process with NO launcher environment — what the driver runs."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    if hook:
+        env["DORPATCH_BENCH_RANK_HOOK"] = hook if isinstance(hook, str) else os.path.join(root, "tests", "bench_emu_hook.py")
+    else:
+        env.pop("DORPATCH_BENCH_RANK_HOOK", None)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, capture_output=True, text=True,
+                          timeout=timeout, cwd=root)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_plain_command_spawns_its_own_ranks(world):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment starts N ranks itself, and the launcher's stdout
+    carries exactly rank 0's JSON line for the whole job (weak scaling: 2 masks per image per rank)."""
+    res = _plain(["--gpus", str(world), "--samples", "2", "--micro-batch", "2"] + TINY)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["scaling"] == "weak"
+    assert out["config"]["masks_per_image_per_gpu"] == 2 and out["config"]["masks_per_image_total"] == 2 * world
+    assert "process group backend gloo" in out["config"]["parallelism"]
+
+
+def test_plain_command_strong_scaling_mode():
+    """--scaling strong: --samples is the total per image; each of the N ranks takes 1/N.  (BASELINE configs[3] is
+    `--config 3 --scaling strong --gpus 8`: 512 in total, 64 per GPU — the preset arithmetic is checked below without
+    running it.)"""
+    res = _plain(["--gpus", "4", "--samples", "8", "--scaling", "strong", "--micro-batch", "2"] + TINY)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 4 and out["scaling"] == "strong"
+    assert out["config"]["masks_per_image_per_gpu"] == 2 and out["config"]["masks_per_image_total"] == 8
+    assert abs(out["value"] - 1 * 8 / (out["ms_per_step"] / 1e3)) <= 0.006 + 1e-3 * out["value"]
+    import bench
+    a = bench.parse(["--config", "3", "--scaling", "strong", "--gpus", "8"])
+    assert (a.batch, a.samples, a.size) == (1, 512, 224) and a.config_label.startswith("BASELINE configs[3]")
+    a = bench.parse(["--config", "3", "--gpus", "8"])                 # weak: 64 per GPU -> the same 512 at N = 8
+    assert (a.batch, a.samples) == (1, 64) and a.config_label == "BASELINE configs[3]"
+    with pytest.raises(SystemExit):
+        bench.parse(["--samples", "10", "--scaling", "strong", "--gpus", "4"])
+
+
+def test_plain_command_without_enough_gpus_fails_loudly():
+    """No GPU in the build container: the launcher must say so and exit non-zero BEFORE starting any rank."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("this host really has >= 2 GPUs")
+    res = _plain(["--gpus", "2"] + TINY, hook=False, timeout=120)
+    assert res.returncode == 2 and res.stdout.strip() == ""
+    assert "needs 2 visible GPUs" in res.stderr
+
+
+def test_a_failing_rank_fails_the_launcher(tmp_path):
+    """A rank that dies must surface as a non-zero exit code of the plain command, with no JSON line, and must not leave
+    the other ranks waiting in a collective (they are terminated: the command returns promptly)."""
+    import os
+    bad = tmp_path / "hook.py"
+    bad.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(7)\ntime.sleep(600)\n")
+    res = _plain(["--gpus", "2", "--samples", "2"] + TINY, hook=str(bad), timeout=120)
+    assert res.returncode == 7
+    assert "rank 1 exited with code 7" in res.stderr and res.stdout.strip() == ""
+
+
+def test_whole_attack_mode_reports_the_split():
+    """bench.py --whole-attack: the driver (= main.py) on one synthetic batch, with and without retiring finished images;
+    here 2 images x 3 iterations per stage @56x56 on a toy classifier through the emulation — the control flow and the
+    JSON object, not the speed."""
+    import torch
+    import bench
+    from oracle import toy_models
+    args = bench.parse(["--whole-attack", "--attack-iterations", "3", "--attack-batch", "2", "--size", "56",
+                        "--micro-batch", "16"])
+    model = toy_models.NormModel(toy_models.make_toy(n_classes=100, gain=2.0), toy_models.Normalize())   # 100 classes: the
+    with emu_patch.emulated_ops():       # random target (main.py:122) must differ from the label, as the reference asserts
+        out = bench.whole_attack(args, torch.device("cpu"), model=model, n_classes=100,
+                                 extra_argv=["--sampling_size", "8", "--dropout", "1"])
+    assert out["metric"] == "whole-attack seconds per image" and out["higher_is_better"] is False
+    for mode in ("retire", "no_retire"):
+        v = out["variants"][mode]
+        assert v["images"] == 2 and v["stage0_steps"] == 3 and v["stage1_steps"] == 3 and v["sweeps"] == 2
+        assert v["stage0_image_steps"] == [3, 3] and v["samples_forward"] == 2 * 8 * 6
+        assert v["seconds_per_image"] > 0 and v["stage0_s"] >= v["stage0_sweeps_s"] > 0 and v["patchcleanser_s"] > 0
+        assert len(v["certified_asr_PC"]) == 4
+    assert "straggler_saving" in out and json.dumps(out)

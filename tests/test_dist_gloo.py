@@ -89,10 +89,16 @@ def _worker(rank, world, port, out_dir):
         libconv.merge_across(pg)
         policy = dict(libconv.POLICY)
         # the tuned-GEMM verdict is rank 0's self-test, broadcast, AND-ed with every rank's own load of the file: here
-        # no GPU, so _decide() must come out False everywhere without running anything
+        # no GPU, so the agreement must come out False everywhere.  The LAST rank enters with a verdict it already cached
+        # locally (as if it had run PatchCleanser before its first generate()): the agreement runs the same two
+        # collectives on every rank whatever is cached, so nobody hangs, and the cached True does not survive
         ran = []
         conv1x1._selftest_tuned = lambda: ran.append(rank) or True
-        verdict = conv1x1._decide(pg)
+        if rank == world - 1:
+            conv1x1._tuned_verdict = True
+        assert conv1x1.activate(pg, True) is False
+        verdict = conv1x1._tuned_verdict
+        assert id(pg) in conv1x1._agreed and conv1x1.activate(pg, True) is False          # no second agreement round
         torch.save(dict(g=g, loss=loss, bitmap=bitmap, agree=agree, policy=policy, verdict=verdict, ran=ran),
                    os.path.join(out_dir, "rank%d.pt" % rank))
     finally:
