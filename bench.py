@@ -268,6 +268,51 @@ def pmc_traffic_live(B, S, H, timeout_s=150):
                    "(tools/kbench replay of the same launch)" % (kib["WRITE_SIZE"], kib["FETCH_SIZE"]))
 
 
+def project_update_roofline(dev, H, stage, images=256, iters=10):
+    """Second roofline entry: dp_project_update (chain rule through utils.clip + structural / density / group-lasso
+    gradients + signed update, reference attack.py:247, 333-342 — the other kernel `north_star` names) on a working set
+    past the 256 MiB Infinity Cache: `images` = 256 images @224 = 0.9 GB per launch (the step's own 64 images = 231 MB
+    would sit in the cache and flatter it).  Algorithmic bytes per pixel: reads x 12 + adv_x 12 + lv_x 4 +
+    g_adv 12 + pattern 12 + mask 4, writes pattern 12 (+ mask 4 in stage 0) = 72 / 68 B.  Timed with events on the
+    stream the kernel is launched on (torch's current stream), average of `iters` launches after 3 warm-ups."""
+    from dorpatch_amd import ops
+    emu = dev.type != "cuda"
+    B2 = 1 if emu else images
+    g = torch.Generator().manual_seed(5)
+    r = lambda *shape: torch.rand(*shape, generator=g).to(dev)
+    x, adv, pat, gadv = r(1, 3, H, H).expand(B2, 3, H, H).contiguous(), r(1, 3, H, H).expand(B2, 3, H, H).contiguous(), \
+        r(1, 3, H, H).expand(B2, 3, H, H).contiguous(), (r(1, 3, H, H) - 0.5).expand(B2, 3, H, H).contiguous()
+    mask, lv = r(1, 1, H, H).expand(B2, 1, H, H).contiguous(), r(1, H, H).expand(B2, H, H).contiguous()
+    unit, win = 7, H // 8
+    cell, wsum, _, _ = ops.mask_stats(mask, unit, win)
+    ones = torch.ones(B2, device=dev)
+    kw = dict(stage=stage, lr=ones * 1e-2, coeff_gl=ones * 1e-5, cell_sumsq=cell, win_sum=wsum, unit=unit, win=win,
+              density=1e-3, do_update=True)
+    run = lambda: ops.project_update(x, adv, lv, gadv, ones, ones * 1e-3, pat, mask, **kw)
+    for _ in range(3):
+        run()
+    if emu:
+        t0 = time.perf_counter()
+        run()
+        ms = (time.perf_counter() - t0) * 1e3
+    else:
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        start.record()
+        for _ in range(iters):
+            run()
+        stop.record()
+        stop.synchronize()
+        ms = start.elapsed_time(stop) / iters
+    bpp = 72 if stage == 0 else 68
+    algo = B2 * H * H * bpp
+    achieved = algo / (ms * 1e-3) / 1e9
+    return {"kernel": "k_project_update_v4 (dp_project_update), stage %d" % stage, "bound": "hbm", "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": algo, "avg_launch_ms": round(ms, 4),
+            "working_set": "%d images x %dx%d (%.0f MB per launch: past the 256 MiB Infinity Cache)" % (B2, H, H, algo / 1e6)}
+
+
 def note(msg):
     """Progress on stderr (stdout carries exactly one JSON line)."""
     print("[bench %7.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
@@ -538,6 +583,10 @@ def main(argv=None):
         barrier()
         dt_sweep = time.perf_counter() - t1
         note("collect_failure sweep done: %.3f s" % dt_sweep)
+    roof2 = None
+    if rank == 0 and H % 8 == 0 and H >= 56:
+        roof2 = project_update_roofline(dev, H, args.stage)
+        note("dp_project_update roofline pass done: %.4f ms" % roof2["avg_launch_ms"])
     det_report = loop.deterministic_in_effect          # read before close() restores the caller's settings
     from dorpatch_amd import libconv
     det_forced = libconv.summary()["forced_list"]
@@ -587,6 +636,8 @@ def main(argv=None):
                          "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(apply_ms, 4)},
         }
+        if roof2 is not None:
+            out["roofline_project_update"] = roof2
         if dt_sweep is not None:
             out["collect_failure_sweep_ms"] = round(dt_sweep * 1e3, 1)
             out["value_with_sweep_amortised"] = round(B * S * 100 / (100 * dt / args.steps + dt_sweep), 2)

@@ -14,8 +14,9 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
-DP_ABI_VERSION = 7
+DP_ABI_VERSION = 8
 DP_MAX_RECTS = 4
+DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK, DP_DEBUG_UPDATE_VARIANT, DP_DEBUG_APPLY_ORDER = 1, 2, 3     # dp_debug_set knobs (tests / A-B)
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 c_int_p = ctypes.c_void_p
@@ -43,6 +44,7 @@ _I, _F, _P, _L = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_int64
 PROTOTYPES = {
     "dp_abi_version": (_I, []),
     "dp_error_string": (ctypes.c_char_p, [_I]),
+    "dp_debug_set": (_I, [_I, _I]),
     "dp_sumsq_nchunk": (_I, [_I]),
     "dp_sumsq_partials": (_I, [_P, _P, _P, _I, _I, _P, _P]),
     "dp_blend": (_I, [_P, _P, _P, _P, _F, _I, _I, _I, _P, _P, _P, _P]),

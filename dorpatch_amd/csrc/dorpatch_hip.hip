@@ -30,6 +30,11 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBlock = 256;  // threads per workgroup: 4 waves of 64
 
+// dp_debug_set knobs (include/dorpatch_hip.h): launch-geometry overrides for tests / A-B runs, 0 = the product's choice
+int g_aff_samples_per_block = 0;   // DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK (tools/kbench sweeps it too)
+int g_update_variant = 0;          // DP_DEBUG_UPDATE_VARIANT
+int g_apply_order = 0;             // DP_DEBUG_APPLY_ORDER
+
 // Register-allocation hint: the compiler must forget what it knows about a lane-private value (so that it re-derives
 // addresses / predicates from it instead of keeping dozens of them alive).  No semantics; empty in the host emulation.
 #ifdef HIPEMU_HOST
@@ -46,6 +51,7 @@ constexpr int kBlock = 256;  // threads per workgroup: 4 waves of 64
 inline int launch_status() { return (int)hipGetLastError(); }
 inline hipStream_t as_stream(dp_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+__device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ----------------------------------------------------------------------------
@@ -205,11 +211,25 @@ template <int G, bool NT>
 __global__ __launch_bounds__(kBlock) void k_apply_fwd(
     const float *__restrict__ adv_x, const int32_t *__restrict__ table, int R,
     const int32_t *__restrict__ idx, const int32_t *__restrict__ idx2, int idx_bstride,
-    int S, int H, int W, int s_per_block, NormDev nd, float *__restrict__ out) {
+    int S, int H, int W, int s_per_block, NormDev nd, float *__restrict__ out, int xcd_units) {
   const int P = H * W, P4 = P >> 2;
-  const int g0 = blockIdx.x * (kBlock * G) + threadIdx.x;
-  const int b = blockIdx.z;
-  const int s_begin = blockIdx.y * s_per_block;
+  int tile = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
+  if (xcd_units > 0) {
+    // 1-D launch, XCD-aware walk.  Workgroup L runs on XCD L % 8 (round-robin dispatch, MI355X_MICROARCH.md): the
+    // S-chunks of one (image, tile) unit are consecutive workgroups OF ONE XCD, so the unit's 12 KiB of source pixels
+    // come from HBM once and from that XCD's L2 for the other chunks.  With the 3-D grid (chunk on the slow axis) every
+    // XCD re-read every image once per chunk wave: 1.156 x the algorithmic traffic at 64 x 32 x 224^2 (rocprofv3 PMC).
+    const int tiles = cdiv_dev(P4, kBlock * G), nchunk = cdiv_dev(S, s_per_block);
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int ju = j / nchunk;
+    const int u = ju * 8 + xcd;
+    if (u >= xcd_units) return;
+    chunk = j - ju * nchunk;
+    b = u / tiles;
+    tile = u - b * tiles;
+  }
+  const int g0 = tile * (kBlock * G) + threadIdx.x;
+  const int s_begin = chunk * s_per_block;
   const int s_end = min(S, s_begin + s_per_block);
 
   const f4 *src = reinterpret_cast<const f4 *>(adv_x + (size_t)b * 3 * P);
@@ -1309,6 +1329,179 @@ __global__ __launch_bounds__(kBlock) void k_project_update(UpdateArgs A) {
     float mm = m - lr * sgn(gm);
     mm = fminf(fmaxf(mm, A.clip_min), A.clip_max);
     A.mask[(size_t)b * P + pix] = mm;
+  }
+}
+
+// The same step with 16-byte lanes (W % 4 == 0, 16-byte aligned tensors: every shape the backbone takes).  A workgroup
+// owns a 32 x 32 pixel tile; one lane = 4 consecutive pixels of a row x 3 channels, so g_adv, pattern, x, mask, lv_x and
+// the best-so-far copies move as float4 (the scalar kernel above issues 4-byte requests: ~40 % of the HBM roofline).
+// adv_x (1-pixel halo all round) and lv_x (halo up / left) are staged in LDS with float4 interior loads; the arithmetic
+// per pixel is the scalar kernel's, expression for expression (bit-identical results: tests compare the two).
+constexpr int UW = 32, UH = 32;      // tile; 256 lanes = 32 rows x 8 float4 columns (224 = 7 tiles, 384 = 12)
+constexpr int URS = UW + 8;          // LDS row stride: pixel (., w0 + lx) at [4 + lx]; left halo [3], right halo [4 + UW]
+
+struct TileU {
+  float v[3][UH + 2][URS];           // [ly] <-> row h0 + ly - 1
+};
+
+__global__ __launch_bounds__(kBlock) void k_project_update_v4(UpdateArgs A) {
+  __shared__ __attribute__((aligned(16))) TileU t;
+  __shared__ __attribute__((aligned(16))) float s_lv[UH + 1][URS];   // [ly] <-> row h0 + ly - 1; same column layout
+  __shared__ float s_wmean;
+  const int H = A.H, W = A.W, P = H * W;
+  const int b = blockIdx.z;
+  const int h0 = blockIdx.y * UH, w0 = blockIdx.x * UW;
+  const float *img = A.adv_x + (size_t)b * 3 * P;
+  const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < 3 * (UH + 2) * (UW / 4); i += kBlock) {
+    const int c = i / ((UH + 2) * (UW / 4));
+    const int r = i - c * ((UH + 2) * (UW / 4));
+    const int ly = r / (UW / 4), q = r - ly * (UW / 4);
+    const int h = h0 + ly - 1, w = w0 + 4 * q;
+    f4 val = zero4;
+    if (h >= 0 && h < H && w < W) val = *reinterpret_cast<const f4 *>(img + ((size_t)c * H + h) * W + w);
+    *reinterpret_cast<f4 *>(&t.v[c][ly][4 + 4 * q]) = val;
+  }
+  for (int i = threadIdx.x; i < 3 * (UH + 2) * 2; i += kBlock) {      // the two halo columns
+    const int c = i / ((UH + 2) * 2);
+    const int r = i - c * ((UH + 2) * 2);
+    const int ly = r >> 1, side = r & 1;
+    const int h = h0 + ly - 1, w = side ? (w0 + UW) : (w0 - 1);
+    float val = 0.f;
+    if (h >= 0 && h < H && w >= 0 && w < W) val = img[((size_t)c * H + h) * W + w];
+    t.v[c][ly][side ? (4 + UW) : 3] = val;
+  }
+  const float *lvp = A.lv_x + (size_t)b * P;
+  for (int i = threadIdx.x; i < (UH + 1) * (UW / 4); i += kBlock) {
+    const int ly = i / (UW / 4), q = i - ly * (UW / 4);
+    const int h = h0 + ly - 1, w = w0 + 4 * q;
+    f4 val = zero4;
+    if (h >= 0 && h < H && w < W) val = *reinterpret_cast<const f4 *>(lvp + (size_t)h * W + w);
+    *reinterpret_cast<f4 *>(&s_lv[ly][4 + 4 * q]) = val;
+  }
+  if (threadIdx.x < UH + 1) {
+    const int ly = threadIdx.x, h = h0 + ly - 1, w = w0 - 1;
+    s_lv[ly][3] = (h >= 0 && h < H && w >= 0) ? lvp[(size_t)h * W + w] : 0.f;
+  }
+  const int nwindow = A.nwy * A.nwx;
+  if (A.stage == 0 && threadIdx.x == 64) {
+    float mean = 0.f;
+    for (int k = 0; k < nwindow; ++k) mean += A.win_sum[(size_t)b * nwindow + k];
+    s_wmean = mean / (float)nwindow;
+  }
+  __syncthreads();
+
+  const int q = threadIdx.x & (UW / 4 - 1), ty = threadIdx.x / (UW / 4);
+  const int h = h0 + ty, wq = w0 + 4 * q;
+  if (h >= H || wq >= W) return;
+  const int ly = ty + 1;
+  const size_t pix = (size_t)h * W + wq;
+
+  const float s = A.scale[b];
+  const float coef = A.structured[b];
+  const float base = coef / (float)P;
+  const f4 m4 = *reinterpret_cast<const f4 *>(A.mask + (size_t)b * P + pix);
+  f4 gm4 = zero4;
+  f4 gp4[3], pv4[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const size_t off = ((size_t)b * 3 + c) * P + pix;
+    const f4 g4 = *reinterpret_cast<const f4 *>(A.g_adv + off);
+    const f4 p4 = *reinterpret_cast<const f4 *>(A.pattern + off);
+    const f4 x4 = *reinterpret_cast<const f4 *>(A.x + off);
+    pv4[c] = p4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int w = wq + k, lx = 4 + 4 * q + k;
+      float g = g4[k];
+      if (coef != 0.f) {
+        const float up_left = (w >= 1) ? (base / (s_lv[ly][lx - 1] + 1e-5f)) / 3.f : 0.f;
+        const float up_up = (h >= 1) ? (base / (s_lv[ly - 1][lx] + 1e-5f)) / 3.f : 0.f;
+        const float xc = t.v[c][ly][lx];
+        float gs = 0.f;
+        if (w >= 1) {          // L at (h, w - 1): a = |v - right| (right = this pixel), b = |v - down|
+          const float v = t.v[c][ly][lx - 1];
+          const float a = fabsf(v - xc);                                          // w - 1 < W - 1 always
+          const float bb = (h < H - 1) ? fabsf(v - t.v[c][ly + 1][lx - 1]) : v;
+          const float mn = (a > bb) ? bb : a;
+          const float dLda = mn + ((a > bb) ? 0.f : (a + bb));
+          gs -= up_left * dLda * sgn(v - xc);
+        }
+        if (h >= 1) {          // L at (h - 1, w): a = |v - right|, b = |v - down| (down = this pixel)
+          const float v = t.v[c][ly - 1][lx];
+          const float a = (w < W - 1) ? fabsf(v - t.v[c][ly - 1][lx + 1]) : v;
+          const float bb = fabsf(v - xc);                                         // h - 1 < H - 1 always
+          const float mn = (a > bb) ? bb : a;
+          const float dLdb = mn + ((a > bb) ? (a + bb) : 0.f);
+          gs -= up_up * dLdb * sgn(v - xc);
+        }
+        g += gs;
+      }
+      const float gd = g * s;
+      gp4[c][k] = gd * m4[k];
+      gm4[k] += gd * (p4[k] - x4[k]);
+    }
+  }
+
+  if (A.stage == 0) {
+    if (A.density != 0.f) {
+      const int ky = h / A.win;
+      int kx = wq / A.win, rx = wq - kx * A.win;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (ky < A.nwy && kx < A.nwx) {
+          const float ck = A.win_sum[(size_t)b * nwindow + ky * A.nwx + kx];
+          gm4[k] += (2.f / (float)(nwindow - 1)) * A.density * (ck - s_wmean);
+        }
+        if (++rx == A.win) { rx = 0; ++kx; }
+      }
+    }
+    const int cy = h / A.unit;
+    int cx = wq / A.unit, rx = wq - cx * A.unit;
+    const float cgl = A.coeff_gl[b];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (cy < A.ncy && cx < A.ncx) {
+        const float cs = A.cell_sumsq[(size_t)b * A.ncy * A.ncx + cy * A.ncx + cx];
+        const float gsq = (cgl * (float)A.unit) / (2.f * sqrtf(cs));       // 0 * inf = NaN: frozen cell (see above)
+        gm4[k] += gsq * (2.f * m4[k]);
+      }
+      if (++rx == A.unit) { rx = 0; ++cx; }
+    }
+  }
+
+  if (A.g_pattern_out) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) *reinterpret_cast<f4 *>(A.g_pattern_out + ((size_t)b * 3 + c) * P + pix) = gp4[c];
+  }
+  if (A.g_mask_out) *reinterpret_cast<f4 *>(A.g_mask_out + (size_t)b * P + pix) = (A.stage == 0) ? gm4 : zero4;
+
+  const bool save = A.save_best && A.save_best[b] != 0;
+  if (save) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) *reinterpret_cast<f4 *>(A.best_pattern + ((size_t)b * 3 + c) * P + pix) = pv4[c];
+    if (A.stage == 0) *reinterpret_cast<f4 *>(A.best_mask + (size_t)b * P + pix) = m4;
+  }
+  if (!A.do_update) return;
+  const float lr = A.lr[b];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    f4 pn;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float p = pv4[c][k] - lr * sgn(gp4[c][k]);
+      pn[k] = fminf(fmaxf(p, A.clip_min), A.clip_max);
+    }
+    *reinterpret_cast<f4 *>(A.pattern + ((size_t)b * 3 + c) * P + pix) = pn;
+  }
+  if (A.stage == 0) {
+    f4 mn4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float mm = m4[k] - lr * sgn(gm4[k]);
+      mn4[k] = fminf(fmaxf(mm, A.clip_min), A.clip_max);
+    }
+    *reinterpret_cast<f4 *>(A.mask + (size_t)b * P + pix) = mn4;
   }
 }
 
@@ -2753,14 +2946,19 @@ int launch_apply_fwd(int variant, const float *adv_x, const int32_t *table, int 
   const int s_per_block = cdiv(S, nchunk);
   nchunk = cdiv(S, s_per_block);
   DP_REQUIRE(nchunk <= 65535);
-  const dim3 grid(tiles, nchunk, B), block(kBlock);
+  // launch order: a unit's chunks adjacent on one XCD (default) or the ABI-7 3-D grid (DP_DEBUG_APPLY_ORDER = 1)
+  const long units = (long)tiles * B;
+  const long linear = ((units + 7) / 8) * 8 * nchunk;
+  const bool xcd_walk = g_apply_order == 0 && nchunk > 1 && linear <= 0x7fffffffL;
+  const dim3 grid = xcd_walk ? dim3((unsigned)linear, 1, 1) : dim3(tiles, nchunk, B), block(kBlock);
+  const int xcd_units = xcd_walk ? (int)units : 0;
   const NormDev nd = make_norm(norm);
   hipStream_t st = as_stream(stream);
   // hipExtLaunchKernelGGL stamps the events with the kernel's own begin / end (what rocprofv3 reports),
   // not with the position of a marker packet in the queue
 #define DP_LAUNCH_FWD(G_, NT_)                                                                    \
   hipExtLaunchKernelGGL((k_apply_fwd<G_, NT_>), grid, block, 0, st, ev_start, ev_stop, 0, adv_x,   \
-                        table, R, idx, idx2, idx_bstride, S, H, W, s_per_block, nd, out)
+                        table, R, idx, idx2, idx_bstride, S, H, W, s_per_block, nd, out, xcd_units)
   if (G == 1 && nt) DP_LAUNCH_FWD(1, true);
   else if (G == 1) DP_LAUNCH_FWD(1, false);
   else if (G == 2 && nt) DP_LAUNCH_FWD(2, true);
@@ -2797,6 +2995,25 @@ extern "C" {
 int dp_abi_version(void) { return DP_ABI_VERSION; }
 
 const char *dp_error_string(int err) { return hipGetErrorString((hipError_t)err); }
+
+int dp_debug_set(int knob, int value) {
+  switch (knob) {
+    case DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK:
+      DP_REQUIRE(value >= 0 && value <= 64);
+      g_aff_samples_per_block = value;
+      return 0;
+    case DP_DEBUG_UPDATE_VARIANT:
+      DP_REQUIRE(value == 0 || value == 1);
+      g_update_variant = value;
+      return 0;
+    case DP_DEBUG_APPLY_ORDER:
+      DP_REQUIRE(value == 0 || value == 1);
+      g_apply_order = value;
+      return 0;
+    default:
+      return (int)hipErrorInvalidValue;
+  }
+}
 
 int dp_sumsq_nchunk(int P) { return P > 0 ? cdiv(P, kSumsqPixPerBlock) : 0; }
 
@@ -2881,7 +3098,6 @@ int dp_apply_bwd(const float *G, const int32_t *table, int R, const int32_t *idx
 
 // samples one forward workgroup walks (software-pipelined footprint loads); tools/kbench overrides it to sweep
 constexpr int kAffSamplesPerBlock = 8;
-static int g_aff_samples_per_block = 0;
 
 static int launch_apply_affine_fwd(const float *x, const float *delta, const float *theta, const int32_t *table, int R,
                                    const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
@@ -2894,11 +3110,7 @@ static int launch_apply_affine_fwd(const float *x, const float *delta, const flo
   DP_REQUIRE((long)H * W * 12 < (1l << 31) && H < (1 << 22) && W < (1 << 22));   // 32-bit byte offsets, 24-bit multiplies
   int spb = kAffSamplesPerBlock;   // ... unless that leaves fewer than ~4 workgroups per CU slot (small B)
   while (spb > 1 && (long)tiles_x * tiles_y * B * cdiv(S, spb) < 4096) spb >>= 1;
-  if (g_aff_samples_per_block > 0) spb = g_aff_samples_per_block;
-  if (const char *e = getenv("DORPATCH_AFFINE_SPB")) {   // test knob: small problems would otherwise never walk > 1 sample
-    const int v = atoi(e);
-    if (v >= 1) spb = v;
-  }
+  if (g_aff_samples_per_block > 0) spb = g_aff_samples_per_block;   // dp_debug_set / tools/kbench
   spb = min(spb, 64);   // one lane of a wave per sample of the chunk
   DP_REQUIRE(cdiv(S, spb) <= 65535);
   hipExtLaunchKernelGGL(k_apply_affine_fwd, dim3(tiles_x * tiles_y, cdiv(S, spb), B), dim3(kBlock), 0, as_stream(stream),
@@ -3042,8 +3254,16 @@ int dp_project_update(const dp_update_cfg_t *cfg, const float *x, const float *a
     A.nwx = (cfg->W - cfg->win) / cfg->win + 1;
     DP_REQUIRE(A.nwy * A.nwx >= 2);
   }
-  hipLaunchKernelGGL(k_project_update, dim3(cdiv(cfg->W, TW), cdiv(cfg->H, TH), cfg->B),
-                     dim3(kBlock), 0, as_stream(stream), A);
+  const bool wide = (cfg->W & 3) == 0 && g_update_variant != 1 && aligned16(x) && aligned16(adv_x) && aligned16(lv_x) &&
+                    aligned16(g_adv) && aligned16(pattern) && aligned16(mask) &&
+                    (!best_pattern || aligned16(best_pattern)) && (!best_mask || aligned16(best_mask)) &&
+                    (!g_pattern_out || aligned16(g_pattern_out)) && (!g_mask_out || aligned16(g_mask_out));
+  if (wide)
+    hipLaunchKernelGGL(k_project_update_v4, dim3(cdiv(cfg->W, UW), cdiv(cfg->H, UH), cfg->B),
+                       dim3(kBlock), 0, as_stream(stream), A);
+  else
+    hipLaunchKernelGGL(k_project_update, dim3(cdiv(cfg->W, TW), cdiv(cfg->H, TH), cfg->B),
+                       dim3(kBlock), 0, as_stream(stream), A);
   return launch_status();
 }
 

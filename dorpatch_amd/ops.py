@@ -64,6 +64,12 @@ def make_norm(mean=None, std=None, fill=0.5):
 RAW_NORM = make_norm(None, None, 0.5)
 
 
+def debug_set(knob, value):
+    """dp_debug_set: launch-geometry overrides for tests / A-B measurements (``_lib.DP_DEBUG_*``); 0 = product default.
+    Never called by the product path."""
+    _lib.check(_lib.load().dp_debug_set(int(knob), int(value)), "dp_debug_set")
+
+
 def upload_table(table, device):
     """(n, R, 4) numpy int32 rectangle table -> device int32 tensor."""
     t = np.ascontiguousarray(table, dtype=np.int32)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DP_ABI_VERSION 7
+#define DP_ABI_VERSION 8
 #define DP_MAX_RECTS 4 /* occlusion windows per mask-table entry */
 
 typedef void *dp_stream_t; /* hipStream_t */
@@ -46,6 +46,20 @@ typedef struct {
 
 int dp_abi_version(void);
 const char *dp_error_string(int err);
+
+/* Launch-geometry overrides for tests and A/B measurements — NOT part of the product path (nothing in
+ * dorpatch_amd/attack.py calls it).  Every knob is process-wide, defaults to 0 = the product's own choice, changes
+ * only how a result is computed, never the result (the tests that use it assert exactly that).  Replaces the
+ * DORPATCH_AFFINE_SPB environment variable of ABI 7.  Returns 1 (hipErrorInvalidValue) for an unknown knob / value.
+ *   DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK  samples one dp_apply_affine_fwd workgroup walks (1..64; 0: sized from the grid)
+ *   DP_DEBUG_UPDATE_VARIANT            dp_project_update: 1 = the 4-byte-lane kernel even where the 16-byte-lane
+ *                                      kernel applies (0: 16-byte lanes whenever W % 4 == 0 and pointers are aligned)
+ *   DP_DEBUG_APPLY_ORDER               dp_apply_fwd grid walk: 1 = the ABI-7 order (samples on the slow grid axis);
+ *                                      0: a tile's samples adjacent in launch order */
+#define DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK 1
+#define DP_DEBUG_UPDATE_VARIANT 2
+#define DP_DEBUG_APPLY_ORDER 3
+int dp_debug_set(int knob, int value);
 
 /* ---- a-2  utils.clip (utils.py:105-110) + adv_x = delta + x (attack.py:184-185) ---- */
 

@@ -173,3 +173,16 @@ def test_whole_attack_mode_reports_the_split():
         assert v["seconds_per_image"] > 0 and v["stage0_s"] >= v["stage0_sweeps_s"] > 0 and v["patchcleanser_s"] > 0
         assert len(v["certified_asr_PC"]) == 4
     assert "straggler_saving" in out and json.dumps(out)
+
+
+@pytest.mark.parametrize("stage", [0, 1])
+def test_project_update_roofline_entry(stage):
+    """The second roofline object of the bench line (dp_project_update past the Infinity Cache): the byte arithmetic and
+    the object's shape, through the emulation on one image."""
+    import torch
+    import bench
+    with emu_patch.emulated_ops():
+        r = bench.project_update_roofline(torch.device("cpu"), 56, stage)
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["traffic"] is None
+    assert r["algorithmic_bytes_per_launch"] == 56 * 56 * (72 if stage == 0 else 68) and r["avg_launch_ms"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "k_project_update_v4" in r["kernel"]

@@ -277,6 +277,83 @@ def test_project_update_grads_and_update(stage, B, H):
     assert p.min() >= 0 and p.max() <= 1
 
 
+@pytest.mark.parametrize("stage", [0, 1])
+@pytest.mark.parametrize("B,H,W", [(2, 56, 56), (1, 224, 224), (1, 384, 384), (3, 40, 36), (2, 33, 100), (1, 7, 8)])
+def test_project_update_wide_lanes_equal_the_scalar_kernel(stage, B, H, W):
+    """dp_project_update's 16-byte-lane kernel (one lane = 4 pixels x 3 channels, 32 x 32 tiles) against the 4-byte-lane
+    kernel (DP_DEBUG_UPDATE_VARIANT = 1) it replaces: gradients incl. the NaN cells, best-so-far copies and updated
+    parameters bit for bit, on tile-aligned sizes (224 = 7 tiles), ragged ones (36, 100, 40 rows) and a single cell."""
+    from dorpatch_amd._lib import DP_DEBUG_UPDATE_VARIANT as KNOB
+    g = torch.Generator().manual_seed(100 * stage + H + W)
+    r = lambda *shape: torch.rand(*shape, generator=g).to(DEV)
+    x, adv, p, m = r(B, 3, H, W), r(B, 3, H, W), r(B, 3, H, W), r(B, 1, H, W)
+    adv[0, :, : H // 2] = adv[0, :, : H // 2].round()          # ties a == b and zero differences: the sign / min branches
+    if stage == 0:
+        m[0, 0, 0:7, 0:7] = 0.0                                 # frozen cell -> NaN
+    g_adv = (torch.randn(B, 3, H, W, generator=g) * 1e-3).to(DEV)
+    g_adv[:, :, ::3, ::5] = 0.0                                 # sign(0) = 0 pixels
+    lv = r(B, H, W) * 0.5
+    f32 = lambda v: torch.tensor(v, dtype=torch.float32, device=DEV)
+    unit, win = 7, max(1, W // 8)
+    ncy, ncx, nwy, nwx = (H - unit) // unit + 1, (W - unit) // unit + 1, (H - win) // win + 1, (W - win) // win + 1
+    cell, wsum = r(B, ncy, ncx) + 0.1, r(B, nwy, nwx) * win * win
+    if stage == 0:
+        cell[0, 0, 0] = 0.0
+    kw = dict(stage=stage, coeff_gl=f32([1e-5 * (b + 2) for b in range(B)]), cell_sumsq=cell.contiguous(),
+              win_sum=wsum.contiguous(), unit=unit, win=win, density=1e-3)
+    scale, structured = f32([0.5 + 0.1 * b for b in range(B)]), f32([1e-3 * (b + 1) for b in range(B)])
+    lr = f32([0.01 * (b + 1) for b in range(B)])
+    save = torch.tensor([1] + [0] * (B - 1), dtype=torch.int32, device=DEV)
+    outs = []
+    try:
+        for variant in (1, 0):
+            ops.debug_set(KNOB, variant)
+            pp, mm = p.clone(), m.clone()
+            bp, bm = torch.full_like(p, -1.0), torch.full_like(m, -1.0)
+            gp, gm = ops.project_update(x, adv, lv, g_adv, scale, structured, pp, mm, do_update=False, want_grads=True, **kw)
+            assert torch.equal(pp, p) and torch.equal(mm, m)
+            ops.project_update(x, adv, lv, g_adv, scale, structured, pp, mm, lr=lr, save_best=save, best_pattern=bp,
+                               best_mask=bm, do_update=True, **kw)
+            outs.append([t.cpu() for t in (gp, gm, pp, mm, bp, bm)])
+    finally:
+        ops.debug_set(KNOB, 0)
+    names = ("grad_pattern", "grad_mask", "pattern", "mask", "best_pattern", "best_mask")
+    for name, a, b in zip(names, outs[0], outs[1]):
+        assert torch.equal(torch.isnan(a), torch.isnan(b)), name
+        assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)), (name, (a - b).abs().max())
+    if stage == 0 and H >= 7 and W >= 8:
+        assert torch.isnan(outs[0][1]).any()
+    assert not torch.equal(outs[0][2], p.cpu())                 # the update did move the pattern
+
+
+@pytest.mark.parametrize("B,S,H", [(3, 5, 56), (2, 4, 224), (9, 3, 40)])
+def test_apply_fwd_launch_orders_are_equivalent(B, S, H):
+    """dp_apply_fwd walks its workgroups XCD by XCD (a unit's samples adjacent on one XCD, the source tile fetched from
+    HBM once); DP_DEBUG_APPLY_ORDER = 1 is the ABI-7 3-D grid.  Same bytes either way, also when the number of
+    (image, tile) units is not a multiple of 8 (the padded workgroups of the 1-D launch exit)."""
+    from dorpatch_amd._lib import DP_DEBUG_APPLY_ORDER as KNOB
+    x = _rand(B, 3, H, H, seed=3).to(DEV)
+    table = ops.upload_table(masks.universe_rects(H, 2), DEV)
+    idx = torch.from_numpy(np.random.RandomState(1).randint(0, 2520, size=(B, S))).int().to(DEV)
+    idx2 = torch.from_numpy(np.random.RandomState(2).randint(0, 2520, size=(B, S))).int().to(DEV)
+    norm = ops.make_norm([0.5] * 3, [0.5] * 3, 0.5)
+    outs = []
+    try:
+        for order in (1, 0):
+            ops.debug_set(KNOB, order)
+            outs.append((ops.apply_fwd(x, table, idx, None, norm).cpu(), ops.apply_fwd(x, table, idx, idx2, ops.RAW_NORM).cpu()))
+    finally:
+        ops.debug_set(KNOB, 0)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_debug_knobs_reject_unknown_values():
+    with pytest.raises(RuntimeError):
+        ops.debug_set(99, 0)
+    with pytest.raises(RuntimeError):
+        ops.debug_set(2, 5)
+
+
 # ---------------------------------------------------------------- fused GroupNorm + ReLU (backbone, a-8)
 GN_SHAPES = [  # (N, C, H, W): every (V, T) register variant, the HW = 49 per-lane channel path, streaming
     (3, 64, 56, 56),      # L4 = 1568  -> <4,512>

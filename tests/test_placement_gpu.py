@@ -99,7 +99,7 @@ def test_affine_apply_matches_grid_sample_oracle_and_its_adjoint(B, S, H, affine
 @pytest.mark.parametrize("B,S,H,affine", [(2, 5, 56, (25.0, (0.7, 1.3), 6.0)), (1, 7, 96, (20.0, (0.42, 1.2), 3.0))])
 def test_forward_is_bit_identical_for_any_number_of_samples_per_workgroup(B, S, H, affine, monkeypatch):
     """The forward walks `samples per workgroup` samples with the next footprint in flight; small problems get 1 from the
-    launcher, so the walk is forced here (DORPATCH_AFFINE_SPB): 2, 3 (ragged last chunk), 8 (> S: one chunk) against 1.
+    launcher, so the walk is forced here (dp_debug_set): 2, 3 (ragged last chunk), 8 (> S: one chunk) against 1.
     The second case mixes staged and slow-path samples (scale 0.42 .. 1.2) inside one chunk."""
     x, delta, table_np, idx_np, idx2_np, theta = _setup(B, S, H, seed=11, dual=True, affine=affine)
     table = ops.upload_table(table_np, DEV)
@@ -107,9 +107,13 @@ def test_forward_is_bit_identical_for_any_number_of_samples_per_workgroup(B, S, 
     norm = ops.make_norm(*NORM, 0.5)
     th = torch.from_numpy(theta).to(DEV)
     outs = {}
-    for spb in (1, 2, 3, 8):
-        monkeypatch.setenv("DORPATCH_AFFINE_SPB", str(spb))
-        outs[spb] = ops.apply_affine_fwd(x.to(DEV), delta.to(DEV), th, table, idx, idx2, norm).cpu()
+    from dorpatch_amd._lib import DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK as KNOB
+    try:
+        for spb in (1, 2, 3, 8):
+            ops.debug_set(KNOB, spb)
+            outs[spb] = ops.apply_affine_fwd(x.to(DEV), delta.to(DEV), th, table, idx, idx2, norm).cpu()
+    finally:
+        ops.debug_set(KNOB, 0)
     for spb in (2, 3, 8):
         assert torch.equal(outs[spb], outs[1]), spb
 
@@ -121,7 +125,7 @@ def test_full_size_launch_adjoint_and_walk_invariance():
     gives the same bits.  GPU only (2.5 GB of samples)."""
     if DEV == "cpu":
         pytest.skip("2048 x 3 x 224 x 224 samples: GPU only")
-    import os
+    from dorpatch_amd._lib import DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK as KNOB
     B, S, H = 64, 32, 224
     x, delta, table_np, idx_np, idx2_np, theta = _setup(B, S, H, seed=21, dual=True, affine=(10.0, (0.9, 1.1), 8.0))
     table = ops.upload_table(table_np, DEV)
@@ -129,14 +133,13 @@ def test_full_size_launch_adjoint_and_walk_invariance():
     th, thi = torch.from_numpy(theta).to(DEV), torch.from_numpy(PL.invert(theta)).to(DEV)
     raw = ops.make_norm(None, None, 0.0)
     zero_x, dd = torch.zeros_like(x).to(DEV), delta.to(DEV)
-    assert "DORPATCH_AFFINE_SPB" not in os.environ
     Ad = ops.apply_affine_fwd(zero_x, dd, th, table, idx, idx2, raw)
     assert torch.equal(Ad, ops.apply_affine_fwd(zero_x, dd, th, table, idx, idx2, raw))
-    os.environ["DORPATCH_AFFINE_SPB"] = "1"
+    ops.debug_set(KNOB, 1)
     try:
         assert torch.equal(Ad, ops.apply_affine_fwd(zero_x, dd, th, table, idx, idx2, raw))
     finally:
-        del os.environ["DORPATCH_AFFINE_SPB"]
+        ops.debug_set(KNOB, 0)
     G = torch.randn(B * S, 3, H, H, generator=torch.Generator(device=DEV).manual_seed(7), device=DEV)
     AtG = ops.apply_affine_bwd(G, th, thi, table, idx, idx2, ops.RAW_NORM, B=B)
     assert torch.equal(AtG, ops.apply_affine_bwd(G, th, thi, table, idx, idx2, ops.RAW_NORM, B=B))

@@ -346,6 +346,10 @@ int main(int argc, char **argv) {
   // ---- a-4 forward / backward
   bench("dp_apply_fwd (default variant)", out_bytes + (double)B * img, iters, st,
         [&] { DP(dp_apply_fwd(adv, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, big, st)); });
+  g_apply_order = 1;
+  bench("dp_apply_fwd (ABI-7 3-D grid order)", out_bytes + (double)B * img, iters, st,
+        [&] { DP(dp_apply_fwd(adv, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, big, st)); });
+  g_apply_order = 0;
   for (int variant : {1, 2, 4, 9, 10, 12, 16 + 4, 16 + 7, 16 + 8 + 4, 16 + 8 + 7, 32 + 9, 32 + 10, 32 + 1, 64 + 9, 64 + 10}) {
     char name[64];
     snprintf(name, sizeof name, "  k_apply_fwd%s<G=%d,NT=%d>%s", (variant & 16) ? "_ch" : "", variant & 7, (variant >> 3) & 1,
@@ -457,6 +461,13 @@ int main(int argc, char **argv) {
             DP(dp_project_update(&cfg, x, adv, lv, g_adv, scale, structured, coeff, lr, cell, wsum, nullptr,
                                  pattern, mask, best_p, best_m, nullptr, nullptr, st));
           });
+    g_update_variant = 1;
+    bench(stage == 0 ? "dp_project_update stage 0, 4-byte lanes (ABI 7)" : "dp_project_update stage 1, 4-byte lanes (ABI 7)",
+          (double)B * P * bpp, iters, st, [&] {
+            DP(dp_project_update(&cfg, x, adv, lv, g_adv, scale, structured, coeff, lr, cell, wsum, nullptr,
+                                 pattern, mask, best_p, best_m, nullptr, nullptr, st));
+          });
+    g_update_variant = 0;
   }
   // ---- a-8: backbone element-wise kernels at the training micro-batch (256 samples)
   if (H == 224 && (!g_filter || strstr(g_filter, "gn_relu") || strstr(g_filter, "maxpool") || strstr(g_filter, "stem") || strstr(g_filter, "pool"))) {
