@@ -62,6 +62,7 @@ PROTOTYPES = {
     "dp_mask_stats": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "dp_project_update": (_I, [ctypes.POINTER(DpUpdateCfg)] + [_P] * 18),
     "dp_argmax": (_I, [_P, _I, _I, _P, _P]),
+    "dp_conv3x3_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "dp_gn_relu_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P]),
     "dp_gn_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "dp_gn_relu_bwd_gather": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),

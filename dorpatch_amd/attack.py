@@ -376,11 +376,29 @@ def _dp_norm(norm):
     return ops.RAW_NORM if norm is None else ops.make_norm(norm[0], norm[1], 0.5)
 
 
+def sweep_plan(B, rows):
+    """How the failure sweep cuts B images x n masks into forwards of ``rows`` samples: groups of g images (g a power of
+    two) x rows // g masks.  The row count of a forward is then the same whatever B is — when images retire from a batch
+    the sweep keeps presenting the library convolutions the shapes they have already seen (a new batch size costs MIOpen
+    a kernel lookup per layer and, under deterministic="auto", three probe runs per convolution problem: measured 2.4x on
+    the sweeps of a 4-image attack whose batch shrank to 3, 2, 1 images, profiles/r04a_bench_whole_attack.json)."""
+    plan, b = [], 0
+    rows = max(1, int(rows))
+    while b < B:
+        g = 1
+        while g * 2 <= min(B - b, rows):
+            g *= 2
+        plan.append((b, b + g, max(1, rows // g)))
+        b += g
+    return plan
+
+
 @torch.no_grad()
-def _collect_failure(net, norm, adv_x, y_img, table, targeted_flags, batch_size, pg=None):
+def _collect_failure(net, norm, adv_x, y_img, table, targeted_flags, batch_size, pg=None, plan=None):
     """Per-image failed-mask lists (attack.py:384-406).  ``y_img`` (B,) int64 device tensor,
     ``targeted_flags`` bool or (B,) bool array.  Ranks of ``pg`` each sweep a slice of the
-    universe and exchange a (B, n_mask) failure bitmap."""
+    universe and exchange a (B, n_mask) failure bitmap.  ``plan``: [(first image, end image, masks per forward)]
+    (default: all images together, ``batch_size`` masks per forward — the reference's loop)."""
     B, _, H, W = adv_x.shape
     n_mask = table.shape[0]
     dev = adv_x.device
@@ -389,16 +407,19 @@ def _collect_failure(net, norm, adv_x, y_img, table, targeted_flags, batch_size,
     lo, hi = dp_dist.mask_bounds(n_mask, world, rank)
     fail = torch.zeros((B, n_mask), dtype=torch.int32, device=dev)
     tflag = torch.as_tensor(np.broadcast_to(np.asarray(targeted_flags, dtype=bool), (B,)).copy(), device=dev)
-    # chunk so that B * chunk masked images go through the backbone at once
-    chunk = max(1, int(batch_size))
-    for j0 in range(lo, hi, chunk):
-        j1 = min(hi, j0 + chunk)
-        idx = torch.arange(j0, j1, dtype=torch.int32, device=dev)
-        inp = ops.apply_fwd(adv_x, table, idx, None, dn)
-        pred = ops.argmax(net(inp).float().contiguous()).view(B, j1 - j0)
-        same = pred == y_img.view(B, 1).to(torch.int32)
-        # untargeted: still classified as y => failure; targeted: not (yet) the target => failure
-        fail[:, j0:j1] = torch.where(tflag.view(B, 1), ~same, same).to(torch.int32)
+    if plan is None:
+        plan = [(0, B, max(1, int(batch_size)))]
+    for b0, b1, chunk in plan:
+        g = b1 - b0
+        xg, yg, tg = adv_x[b0:b1], y_img[b0:b1].view(g, 1).to(torch.int32), tflag[b0:b1].view(g, 1)
+        for j0 in range(lo, hi, chunk):
+            j1 = min(hi, j0 + chunk)
+            idx = torch.arange(j0, j1, dtype=torch.int32, device=dev)
+            inp = ops.apply_fwd(xg, table, idx, None, dn)
+            pred = ops.argmax(net(inp).float().contiguous()).view(g, j1 - j0)
+            same = pred == yg
+            # untargeted: still classified as y => failure; targeted: not (yet) the target => failure
+            fail[b0:b1, j0:j1] = torch.where(tg, ~same, same).to(torch.int32)
     dp_dist.allreduce_max_(fail, pg)
     fail_np = fail.cpu().numpy().astype(bool)
     return [np.nonzero(fail_np[b])[0].tolist() for b in range(B)]
@@ -743,8 +764,8 @@ class HotLoop(object):
 
     # ---------------------------------------------------------------- one optimisation step
     def _refresh_failures(self):
-        # masks per forward chosen so that B * chunk ~ the training micro-batch: same conv shapes as the
-        # hot loop (no extra MIOpen solver searches), bounded activation memory
+        # forwards of micro_batch rows (sweep_plan): same conv shapes as the hot loop (no extra MIOpen solver
+        # searches), bounded activation memory, and the same shapes whatever the number of images still running
         act = self._running()
         if not act:
             return
@@ -753,8 +774,8 @@ class HotLoop(object):
         if len(act) < self.B:          # finished images are not swept (their failure lists are never read again)
             sel = torch.as_tensor(act, dtype=torch.int64, device=self.dev)
             adv_x, y, flags = adv_x.index_select(0, sel), y.index_select(0, sel), flags[act]
-        chunk = max(1, self.o.micro_batch // len(act))
-        lists = _collect_failure(self.net, self.norm, adv_x, y, self.table, flags, chunk, pg=self.o.pg)
+        lists = _collect_failure(self.net, self.norm, adv_x.contiguous(), y, self.table, flags, None, pg=self.o.pg,
+                                 plan=sweep_plan(len(act), self.o.micro_batch))
         for b, l in zip(act, lists):
             if self.img[b].active:
                 self.img[b].failed_idxs = l
@@ -982,10 +1003,10 @@ class HotLoop(object):
         # micro-batches: (first sample, end sample, first image, end image, first local mask, end local mask, accumulate)
         chunks = []
         if Sl <= mb:
-            ipm = max(1, mb // Sl)                 # whole images per micro-batch
-            for b0 in range(0, B, ipm):
-                b1 = min(B, b0 + ipm)
-                chunks.append((b0 * Sl, b1 * Sl, b0, b1, 0, Sl, False))
+            b0 = 0
+            for k in self._image_groups(B, Sl, mb):    # whole images per micro-batch
+                chunks.append((b0 * Sl, (b0 + k) * Sl, b0, b0 + k, 0, Sl, False))
+                b0 += k
         else:
             for b in range(B):
                 for k, s0 in enumerate(range(0, Sl, mb)):
@@ -1014,6 +1035,26 @@ class HotLoop(object):
             self.pred.view(self.B, Sl).index_copy_(0, sel, pred.view(B, Sl))    # finished images keep their last row
         self._run_y = self._run_g = self._run_pred = None
         self._own_pred.copy_(self.pred)            # int32 -> fp32 (class ids are exact), rides in the same buffer
+
+    @staticmethod
+    def _image_groups(B, Sl, mb):
+        """Whole images per micro-batch for B images of Sl samples: mb // Sl each, and for what is left over (a batch not
+        divisible by it, or one that shrank because images retired) the largest group whose ROW COUNT the committed
+        library routes were measured for (conv1x1.TUNED: 512 / 128 / 64 / 32 rows) — 3 running images x 128 samples run as
+        3 micro-batches of 128 rows, not as one of 384 (a batch size with no tuned GEMM solutions and no route column:
+        measured 1.3x slower per sample, profiles/r04a_bench_whole_attack.json)."""
+        from . import conv1x1
+        ipm = max(1, mb // Sl)
+        allowed = sorted({L // Sl for L in conv1x1.TUNED if L % Sl == 0 and 1 <= L // Sl < ipm}, reverse=True)
+        groups, left = [], B
+        while left > 0:
+            if left >= ipm:
+                k = ipm
+            else:
+                k = next((a for a in allowed if a <= left), left)
+            groups.append(k)
+            left -= k
+        return groups
 
     def _reduce_chunk(self, G, c, idx, idx2):
         n0, n1, b0, b1, s0, s1, accumulate = c

@@ -215,10 +215,9 @@ __global__ __launch_bounds__(kBlock) void k_apply_fwd(
   const int P = H * W, P4 = P >> 2;
   int tile = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
   if (xcd_units > 0) {
-    // 1-D launch, XCD-aware walk.  Workgroup L runs on XCD L % 8 (round-robin dispatch, MI355X_MICROARCH.md): the
-    // S-chunks of one (image, tile) unit are consecutive workgroups OF ONE XCD, so the unit's 12 KiB of source pixels
-    // come from HBM once and from that XCD's L2 for the other chunks.  With the 3-D grid (chunk on the slow axis) every
-    // XCD re-read every image once per chunk wave: 1.156 x the algorithmic traffic at 64 x 32 x 224^2 (rocprofv3 PMC).
+    // 1-D launch, XCD-aware walk (A/B variant, not the default: see launch_apply_fwd).  Workgroup L runs on XCD L % 8
+    // (round-robin dispatch, MI355X_MICROARCH.md): the S-chunks of one (image, tile) unit are consecutive workgroups OF
+    // ONE XCD, so the unit's 12 KiB of source pixels come from HBM once and from that XCD's L2 for the other chunks.
     const int tiles = cdiv_dev(P4, kBlock * G), nchunk = cdiv_dev(S, s_per_block);
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int ju = j / nchunk;
@@ -1353,6 +1352,21 @@ __global__ __launch_bounds__(kBlock) void k_project_update_v4(UpdateArgs A) {
   const int h0 = blockIdx.y * UH, w0 = blockIdx.x * UW;
   const float *img = A.adv_x + (size_t)b * 3 * P;
   const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // the lane's own streaming operands first: 10 independent 16-byte loads in flight while the tile is staged (issued
+  // after the barrier they would wait behind it: 0.214 -> see KERNELS.md)
+  const int q = threadIdx.x & (UW / 4 - 1), ty = threadIdx.x / (UW / 4);
+  const int h = h0 + ty, wq = w0 + 4 * q;
+  const bool mine = h < H && wq < W;
+  const size_t pix = mine ? (size_t)h * W + wq : 0;
+  const f4 m4 = *reinterpret_cast<const f4 *>(A.mask + (size_t)b * P + pix);
+  f4 g4[3], pv4[3], x4[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const size_t off = ((size_t)b * 3 + c) * P + pix;
+    g4[c] = *reinterpret_cast<const f4 *>(A.g_adv + off);
+    pv4[c] = *reinterpret_cast<const f4 *>(A.pattern + off);
+    x4[c] = *reinterpret_cast<const f4 *>(A.x + off);
+  }
   for (int i = threadIdx.x; i < 3 * (UH + 2) * (UW / 4); i += kBlock) {
     const int c = i / ((UH + 2) * (UW / 4));
     const int r = i - c * ((UH + 2) * (UW / 4));
@@ -1391,29 +1405,21 @@ __global__ __launch_bounds__(kBlock) void k_project_update_v4(UpdateArgs A) {
   }
   __syncthreads();
 
-  const int q = threadIdx.x & (UW / 4 - 1), ty = threadIdx.x / (UW / 4);
-  const int h = h0 + ty, wq = w0 + 4 * q;
-  if (h >= H || wq >= W) return;
+  if (!mine) return;
   const int ly = ty + 1;
-  const size_t pix = (size_t)h * W + wq;
 
   const float s = A.scale[b];
   const float coef = A.structured[b];
   const float base = coef / (float)P;
-  const f4 m4 = *reinterpret_cast<const f4 *>(A.mask + (size_t)b * P + pix);
   f4 gm4 = zero4;
-  f4 gp4[3], pv4[3];
+  f4 gp4[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    const size_t off = ((size_t)b * 3 + c) * P + pix;
-    const f4 g4 = *reinterpret_cast<const f4 *>(A.g_adv + off);
-    const f4 p4 = *reinterpret_cast<const f4 *>(A.pattern + off);
-    const f4 x4 = *reinterpret_cast<const f4 *>(A.x + off);
-    pv4[c] = p4;
+    const f4 p4 = pv4[c];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int w = wq + k, lx = 4 + 4 * q + k;
-      float g = g4[k];
+      float g = g4[c][k];
       if (coef != 0.f) {
         const float up_left = (w >= 1) ? (base / (s_lv[ly][lx - 1] + 1e-5f)) / 3.f : 0.f;
         const float up_up = (h >= 1) ? (base / (s_lv[ly - 1][lx] + 1e-5f)) / 3.f : 0.f;
@@ -1439,7 +1445,7 @@ __global__ __launch_bounds__(kBlock) void k_project_update_v4(UpdateArgs A) {
       }
       const float gd = g * s;
       gp4[c][k] = gd * m4[k];
-      gm4[k] += gd * (p4[k] - x4[k]);
+      gm4[k] += gd * (p4[k] - x4[c][k]);
     }
   }
 
@@ -2946,10 +2952,14 @@ int launch_apply_fwd(int variant, const float *adv_x, const int32_t *table, int 
   const int s_per_block = cdiv(S, nchunk);
   nchunk = cdiv(S, s_per_block);
   DP_REQUIRE(nchunk <= 65535);
-  // launch order: a unit's chunks adjacent on one XCD (default) or the ABI-7 3-D grid (DP_DEBUG_APPLY_ORDER = 1)
+  // launch order: the 3-D grid (tile fastest: the launch writes the output as ONE ascending stream; default) or, with
+  // DP_DEBUG_APPLY_ORDER = 1, a unit's chunks adjacent on one XCD.  Measured at 64 x 32 x 224^2 (round 4,
+  // profiles/r04a_kbench_apply_order.txt + the bench's PMC pass): the XCD walk cuts the HBM traffic from 1.156 x to
+  // 1.039 x the algorithmic bytes (each source tile fetched once) and is 19 % SLOWER (0.238 vs 0.200 ms): the workgroups
+  // of an XCD then write 4 KiB pieces 602 KB apart, and the write stream's locality matters more than 190 MB of reads.
   const long units = (long)tiles * B;
   const long linear = ((units + 7) / 8) * 8 * nchunk;
-  const bool xcd_walk = g_apply_order == 0 && nchunk > 1 && linear <= 0x7fffffffL;
+  const bool xcd_walk = g_apply_order == 1 && nchunk > 1 && linear <= 0x7fffffffL;
   const dim3 grid = xcd_walk ? dim3((unsigned)linear, 1, 1) : dim3(tiles, nchunk, B), block(kBlock);
   const int xcd_units = xcd_walk ? (int)units : 0;
   const NormDev nd = make_norm(norm);
@@ -2967,6 +2977,136 @@ int launch_apply_fwd(int variant, const float *adv_x, const int32_t *table, int 
   else DP_LAUNCH_FWD(4, false);
 #undef DP_LAUNCH_FWD
   return launch_status();
+}
+
+
+// ----------------------------------------------------------------------------
+// a-8 candidate (round 4): the backbone's 3 x 3 / stride 1 / pad 1 convolutions on the matrix cores.
+// MIOpen runs them as fp32 Winograd on the VALUs (64 -> 64 @56^2, N = 512: 1.04 ms = 113 TFLOP/s effective); this is
+// the direct implicit GEMM on v_mfma_f32_32x32x2_f32 (exact f32, an fmaf chain over K — no Winograd rounding):
+//     D[oc][pixel] += sum_k  A[oc][k] * B[k][pixel],     k = (input channel, kh, kw),  K = 9 C
+//   A (weights)  lane l holds A[i = l & 31][k = l >> 5];   B (pixels)  lane l holds B[k = l >> 5][j = l & 31];
+//   D            lane l, register v:  oc = (v & 3) + 8 (v >> 2) + 4 (l >> 5),  pixel = l & 31
+// so a store instruction writes 2 output-channel rows x 32 consecutive pixels (128 B runs).
+// Workgroup = 8 output rows of one image (448 pixels = 14 fragments) x all 64 output channels; wave w owns channel
+// fragment w & 1 and the 7 pixel fragments (w >> 1) + 2 q: 7 accumulators of 16 VGPRs, 8 LDS reads per 7 MFMAs.
+// K walks in chunks of 8 input channels: the chunk's 10 input rows (zero halo; pitch 64 floats, column 0 at [4] so global
+// float4s land on aligned LDS float4s) and its pre-packed weights wt[chunk][t = (channel pair, kh, kw)][half][oc]
+// (dp_conv3x3 host packing; frozen weights: packed once) are double-buffered in LDS — the loads of chunk i + 1 are in
+// flight during the 252 MFMAs of chunk i, one barrier per chunk.  A k-step pairs channels (2 cp, 2 cp + 1) of the same tap:
+// the lane's half selects the channel, so every LDS address is lane base + compile-time immediate.
+// LDS 2 x 38.9 KB -> 2 workgroups per CU = 2 waves per SIMD (enough to keep the 64-cycle MFMA pipe fed).
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int kCvH = 56, kCvW = 56, kCvO = 64;
+constexpr int kCvRows = 8;                              // output rows per workgroup
+constexpr int kCvFrags = kCvRows * kCvW / 32;           // 14 pixel fragments
+constexpr int kCvPitch = 64, kCvX0 = 4;
+constexpr int kCvCh = 8;                                // input channels per K-chunk
+constexpr int kCvSteps = kCvCh / 2 * 9;                 // 36 MFMA k-steps per chunk
+constexpr int kCvInRows = kCvRows + 2;
+constexpr int kCvChStride = kCvInRows * kCvPitch;       // 640
+constexpr int kCvInFloats = kCvCh * kCvChStride;        // 5120
+constexpr int kCvWtFloats = kCvSteps * 2 * kCvO;        // 4608
+constexpr int kCvBuf = kCvInFloats + kCvWtFloats;       // 9728 floats = 38 912 B
+constexpr int kCvInF4 = kCvCh * kCvInRows * (kCvW / 4); // 1120 float4 per chunk
+constexpr int kCvWtF4 = kCvWtFloats / 4;                // 1152
+constexpr int kCvInIt = (kCvInF4 + kBlock - 1) / kBlock, kCvWtIt = (kCvWtF4 + kBlock - 1) / kBlock;   // 5, 5
+
+template <int C>
+__global__ __launch_bounds__(kBlock, 2) void k_conv3x3_mfma(const float *__restrict__ x, const float *__restrict__ wt,
+                                                            float *__restrict__ y) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kCvBuf];
+  constexpr int NCH = C / kCvCh;
+  constexpr int P = kCvH * kCvW;
+  const int n = blockIdx.y, r0 = blockIdx.x * kCvRows;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int ocf = wave & 1, pf0 = wave >> 1;
+  const float *xn = x + (size_t)n * C * P;
+
+  // halo columns (never written again) of both buffers
+  for (int i = tid; i < 2 * kCvCh * kCvInRows * 2; i += kBlock) {
+    const int buf = i / (kCvCh * kCvInRows * 2), r = i - buf * (kCvCh * kCvInRows * 2);
+    lds[buf * kCvBuf + (r >> 1) * kCvPitch + ((r & 1) ? (kCvX0 + kCvW) : (kCvX0 - 1))] = 0.f;
+  }
+
+  f4 pin[kCvInIt], pwt[kCvWtIt];
+  auto fetch = [&](int chunk) {          // global -> registers
+#pragma unroll
+    for (int it = 0; it < kCvInIt; ++it) {
+      const int i = tid + it * kBlock;
+      const int ch = i / (kCvInRows * (kCvW / 4)), rem = i - ch * (kCvInRows * (kCvW / 4));
+      const int row = rem / (kCvW / 4), q4 = rem - row * (kCvW / 4);
+      const int gr = r0 - 1 + row;
+      f4 v = {0.f, 0.f, 0.f, 0.f};
+      if (i < kCvInF4 && gr >= 0 && gr < kCvH)
+        v = *reinterpret_cast<const f4 *>(xn + ((size_t)(chunk * kCvCh + ch) * kCvH + gr) * kCvW + 4 * q4);
+      pin[it] = v;
+    }
+    const f4 *wsrc = reinterpret_cast<const f4 *>(wt + (size_t)chunk * kCvWtFloats);
+#pragma unroll
+    for (int it = 0; it < kCvWtIt; ++it) {
+      const int i = tid + it * kBlock;
+      pwt[it] = wsrc[i < kCvWtF4 ? i : 0];
+    }
+  };
+  auto stash = [&](int buf) {            // registers -> LDS
+    float *dst = lds + buf * kCvBuf;
+#pragma unroll
+    for (int it = 0; it < kCvInIt; ++it) {
+      const int i = tid + it * kBlock;
+      const int ch = i / (kCvInRows * (kCvW / 4)), rem = i - ch * (kCvInRows * (kCvW / 4));
+      const int row = rem / (kCvW / 4), q4 = rem - row * (kCvW / 4);
+      if (i < kCvInF4) *reinterpret_cast<f4 *>(dst + ch * kCvChStride + row * kCvPitch + kCvX0 + 4 * q4) = pin[it];
+    }
+#pragma unroll
+    for (int it = 0; it < kCvWtIt; ++it) {
+      const int i = tid + it * kBlock;
+      if (i < kCvWtF4) *reinterpret_cast<f4 *>(dst + kCvInFloats + 4 * i) = pwt[it];
+    }
+  };
+
+  // lane bases: A = weights [t][half][oc]; B = pixels of the lane's 7 fragments, channel parity = half
+  const int abase = kCvInFloats + half * kCvO + ocf * 32 + l32;
+  int boff[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const int p = (pf0 + 2 * q) * 32 + l32;
+    const int hl = p / kCvW, w = p - hl * kCvW;
+    boff[q] = half * kCvChStride + hl * kCvPitch + w + (kCvX0 - 1);
+  }
+  f16v acc[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
+
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int chunk = 0; chunk < NCH; ++chunk) {
+    if (chunk + 1 < NCH) fetch(chunk + 1);
+    const float *cur = lds + (chunk & 1) * kCvBuf;
+#pragma unroll
+    for (int t = 0; t < kCvSteps; ++t) {
+      const int cp = t / 9, kh = (t % 9) / 3, kw = t % 3;
+      const float a = cur[abase + t * 2 * kCvO];
+      const int koff = cp * 2 * kCvChStride + kh * kCvPitch + kw;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, cur[boff[q] + koff], acc[q], 0, 0, 0);
+    }
+    if (chunk + 1 < NCH) stash((chunk + 1) & 1);
+    __syncthreads();
+  }
+
+  float *yn = y + ((size_t)n * kCvO + ocf * 32 + 4 * half) * P + (size_t)r0 * kCvW + l32;
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    float *yq = yn + (pf0 + 2 * q) * 32;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) yq[(size_t)((v & 3) + 8 * (v >> 2)) * P] = acc[q][v];
+  }
 }
 
 // variant 0: fp32 VALU gather, 2 quads per thread (shipped); 2: the same with 4 quads per thread (measured slower, see
@@ -3264,6 +3404,15 @@ int dp_project_update(const dp_update_cfg_t *cfg, const float *x, const float *a
   else
     hipLaunchKernelGGL(k_project_update, dim3(cdiv(cfg->W, TW), cdiv(cfg->H, TH), cfg->B),
                        dim3(kBlock), 0, as_stream(stream), A);
+  return launch_status();
+}
+
+int dp_conv3x3_fwd(const float *x, const float *wt, int N, int C, int O, int H, int W, float *y, dp_stream_t stream) {
+  DP_REQUIRE(x && wt && y && aligned16(x) && aligned16(wt) && aligned16(y));
+  DP_REQUIRE(N > 0 && N <= 65535 && O == kCvO && H == kCvH && W == kCvW && (C == 64 || C == 16));
+  const dim3 grid(kCvH / kCvRows, N), block(kBlock);
+  if (C == 64) hipLaunchKernelGGL(k_conv3x3_mfma<64>, grid, block, 0, as_stream(stream), x, wt, y);
+  else hipLaunchKernelGGL(k_conv3x3_mfma<16>, grid, block, 0, as_stream(stream), x, wt, y);
   return launch_status();
 }
 

@@ -338,6 +338,27 @@ def project_update(x, adv_x, lv_x, g_adv, scale, structured, pattern, mask, *, s
     return gp, gm
 
 
+# ---------------------------------------------------------------- a-8 candidate: 3x3 convolution on the matrix cores
+def pack_conv3x3_weights(w):
+    """(64, C, 3, 3) frozen weights -> the k-walk order of dp_conv3x3_fwd: [chunk][cp][kh][kw][half][o] with input channel
+    8 chunk + 2 cp + half (include/dorpatch_hip.h).  Plain tensor reshuffle, done once per frozen convolution."""
+    O, C = w.shape[0], w.shape[1]
+    assert w.shape[2:] == (3, 3) and C % 8 == 0
+    return w.detach().float().reshape(O, C // 8, 4, 2, 3, 3).permute(1, 2, 4, 5, 3, 0).contiguous()
+
+
+def conv3x3_fwd(x, wt):
+    """y = conv2d(x, w, stride 1, padding 1) for x (N,C,56,56), wt = pack_conv3x3_weights(w), on v_mfma_f32_32x32x2_f32."""
+    lib = _lib.load()
+    _chk(x, torch.float32, "x"), _chk(wt, torch.float32, "wt")
+    N, C, H, W = x.shape
+    O = wt.shape[-1]
+    assert wt.numel() == C * 9 * O
+    y = torch.empty((N, O, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(lib.dp_conv3x3_fwd(_p(x), _p(wt), N, C, O, H, W, _p(y), _stream()), "dp_conv3x3_fwd")
+    return y
+
+
 # ---------------------------------------------------------------- a-8: fused GroupNorm + ReLU (frozen backbone)
 def gn_relu_supported(x, groups):
     """Shapes the fused kernel accepts: fp32 GPU NCHW, (C/groups)*H*W a multiple of 4 and < 2^20."""

@@ -54,8 +54,9 @@ const char *dp_error_string(int err);
  *   DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK  samples one dp_apply_affine_fwd workgroup walks (1..64; 0: sized from the grid)
  *   DP_DEBUG_UPDATE_VARIANT            dp_project_update: 1 = the 4-byte-lane kernel even where the 16-byte-lane
  *                                      kernel applies (0: 16-byte lanes whenever W % 4 == 0 and pointers are aligned)
- *   DP_DEBUG_APPLY_ORDER               dp_apply_fwd grid walk: 1 = the ABI-7 order (samples on the slow grid axis);
- *                                      0: a tile's samples adjacent in launch order */
+ *   DP_DEBUG_APPLY_ORDER               dp_apply_fwd grid walk: 1 = XCD-aware (a tile's samples adjacent on one XCD: 10 %
+ *                                      less HBM traffic, measured 19 % slower); 0: tile-fastest 3-D grid (one ascending
+ *                                      output stream) */
 #define DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK 1
 #define DP_DEBUG_UPDATE_VARIANT 2
 #define DP_DEBUG_APPLY_ORDER 3
@@ -210,6 +211,15 @@ int dp_project_update(const dp_update_cfg_t *cfg, const float *x,
                       float *best_pattern, float *best_mask,
                       float *g_pattern_out, float *g_mask_out,
                       dp_stream_t stream);
+
+/* ---- a-8 candidate: 3x3 / stride 1 / pad 1 convolution of the frozen backbone on the matrix cores ----
+ * (attack.py:222 through the classifier; today MIOpen's fp32 Winograd.)  Direct implicit GEMM on
+ * v_mfma_f32_32x32x2_f32: exact f32, y[n][o] = sum_{c,kh,kw} w[o][c][kh][kw] * x[n][c][.+kh-1][.+kw-1], zero padding.
+ * Shapes: O = 64, H = W = 56, C in {16, 64} (C = 16 exists for the CPU-emulation test).  x (N,C,56,56), y (N,64,56,56).
+ * wt = the weights PRE-PACKED for the kernel's k-walk (frozen: packed once by the host, dorpatch_amd/ops.py
+ * pack_conv3x3_weights): wt[chunk][cp][kh][kw][half][o] = w[o][8 chunk + 2 cp + half][kh][kw], C/8 x 4 x 3 x 3 x 2 x 64.
+ * Measured against MIOpen in tools/kbench (go / no-go for routing the backbone's 3x3 convolutions here). */
+int dp_conv3x3_fwd(const float *x, const float *wt, int N, int C, int O, int H, int W, float *y, dp_stream_t stream);
 
 /* ---- next-1  collect_failure (attack.py:384-406) / PatchCleanser (PatchCleanser.py:68-112) ----
  * pred[n] = argmax_k logits[n,k]  (first index on ties). */

@@ -280,6 +280,26 @@ inline hipemu_f4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipemu_f
   return d;
 }
 
+// v_mfma_f32_32x32x2_f32: A[i][k] in lane i + 32 k, B[k][j] in lane j + 32 k, D[i][j] in lane j + 32 ((i >> 2) & 1),
+// register (i & 3) + 4 (i >> 3); exact f32, an fmaf chain over k.
+typedef float hipemu_f16 __attribute__((ext_vector_type(16)));
+inline hipemu_f16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, hipemu_f16 c, int, int, int) {
+  const int lane = hipemu::S().cur->flat % hipemu::kWave;
+  const int j = lane & 31, hi = lane >> 5;
+  // gather the two operand matrices once (4 x 32 shuffles), then the lane's 16 results
+  float av[2][32], bv[2];
+  for (int k = 0; k < 2; ++k) {
+    bv[k] = hipemu::shuffle(b, j + 32 * k);
+    for (int i = 0; i < 32; ++i) av[k][i] = hipemu::shuffle(a, i + 32 * k);
+  }
+  hipemu_f16 d = c;
+  for (int v = 0; v < 16; ++v) {
+    const int i = (v & 3) + 8 * (v >> 2) + 4 * hi;
+    d[v] = fmaf(av[1][i], bv[1], fmaf(av[0][i], bv[0], d[v]));
+  }
+  return d;
+}
+
 // v_mul_i32_i24: the product of the operands' low 24 bits (sign-extended); exact for the small values it is used on
 inline int __mul24(int a, int b) { return ((a << 8) >> 8) * ((b << 8) >> 8); }
 

@@ -228,3 +228,57 @@ def test_end_metric_through_resnetv2_is_a_plausible_draw_from_the_reference_null
     model = NormModel(net, get_normalize("imagenet", "resnetv2")).eval().to(DEV)
     check_against_null(g, *run_product_batched(g, DEV, tmp_path, monkeypatch, [(model, np.arange(len(g["target"])))], 1000),
                        per_image=False)
+
+
+def test_end_metric_at_224_through_resnetv2_is_a_plausible_draw_from_the_reference_null(tmp_path, monkeypatch):
+    """The end metric AT THE SIZE IT IS QUOTED ON: 224 x 224 through ResNetV2-50x1-BiT with a 10-class
+    head (so that PatchCleanser has something to certify), well-conditioned seeded weights, S = 32, 100 iterations per stage
+    — tests/golden/end_metric_bit_224.npz: 2 images x (1 + 3) full runs of the UNMODIFIED reference on the CPU
+    (gen_golden.make_end_metric_bit224_fixture; runs 1-3 with 2 ulp of gradient noise = the reference-vs-reference spread).
+    Image 0 keeps the network's natural margin between the clean class and the target, image 1 has the target's head bias
+    raised (``gains`` = the shift) so that the margin is 0.15: one problem on each side of the tipping point.
+    The product runs the two problems through DorPatch.generate -> collect_failure -> PatchCleanser on the GPU from the
+    reference runs' seeds (B = 1: the same global RNG streams, index-for-index identical mask draws)."""
+    from conftest import load_golden
+    from dorpatch_amd.resnetv2 import WELL_CONDITIONED_GN_BIAS, resnetv2_50x1_bit, seeded_init_
+    from dorpatch_amd.utils import NormModel, get_normalize
+    import os
+    from conftest import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, "end_metric_bit_224.npz")):
+        pytest.skip("tests/golden/end_metric_bit_224.npz not generated yet (python -m oracle.gen_golden --only-end-metric-bit224)")
+    g = load_golden("end_metric_bit_224.npz")
+    H, S, n_it, eps = int(g["H"]), int(g["S"]), int(g["max_iterations"]), float(g["eps"])
+    assert (H, S, n_it, int(g["n_classes"])) == (224, 32, 100, 10)
+    monkeypatch.chdir(tmp_path)
+    table = ops.upload_table(masks.universe_rects(H, 2), DEV)
+    n = len(g["target"])
+    pred, cert = np.zeros((n, 4), np.int64), np.zeros((n, 4), bool)
+    n_fail, adv_pred = np.zeros(n, np.int64), np.zeros(n, np.int64)
+    for k in range(n):
+        net = seeded_init_(resnetv2_50x1_bit(10), seed=1234, gn_bias=WELL_CONDITIONED_GN_BIAS).fold_weight_standardization().freeze()
+        with torch.no_grad():
+            net.head.fc.bias[int(g["target"][k])] += float(g["gains"][k])          # gen_golden.bit224_problem
+        model = NormModel(net, get_normalize("imagenet", "resnetv2")).eval().to(DEV)
+        x = torch.from_numpy(g["x"][k:k + 1]).to(DEV)
+        y = torch.tensor([int(g["target"][k])], device=DEV)
+        with torch.no_grad():
+            assert int(model(x).argmax(-1)) == int(g["clean"][k])
+        torch.manual_seed(1234 + k)                   # gen_golden.run_reference(seed=1234 + k)
+        np.random.seed(1234 + k)
+        atk = DorPatch(verbose=False)
+        mask, pattern = atk.generate(model, x, float(g["patch_budget"]), 10, "res%d/cfg/sub" % k, 0, y=y, targeted=True,
+                                     sampling_size=S, max_iterations=n_it, eps=eps)
+        adv = x + ops.blend(mask, pattern, x, eps, add_x=False)[0]                       # main.py:140-141
+        n_fail[k] = len(atk.collect_failure(adv, y, table, True, model))
+        recs = [PatchCleanser(MaskWindow(H, float(r), 1), model).robust_predict(adv[0], True) for r in g["ratios"]]
+        pred[k], cert[k] = [r.prediction for r in recs], [r.certification for r in recs]
+        with torch.no_grad():
+            adv_pred[k] = int(model(adv).argmax(-1))
+    print("224 end metric: product pred %s cert %s n_fail %s adv_pred %s" % (pred.tolist(), cert.tolist(), n_fail.tolist(),
+                                                                            adv_pred.tolist()))
+    print("               reference runs: pred %s cert %s n_fail %s adv_pred %s" % (
+        g["pc_pred"].tolist(), g["pc_cert"].tolist(), g["n_fail"].tolist(), g["adv_pred"].tolist()))
+    check_against_null(g, pred, cert, n_fail, adv_pred, per_image=BIT224_PER_IMAGE)
+
+
+BIT224_PER_IMAGE = True     # the recorded runs' per-image failure counts are stable enough to hold the product to them

@@ -5,6 +5,7 @@ at rtol 1e-5 (+ small atol) — only summation order differs from the CPU refere
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -328,9 +329,10 @@ def test_project_update_wide_lanes_equal_the_scalar_kernel(stage, B, H, W):
 
 @pytest.mark.parametrize("B,S,H", [(3, 5, 56), (2, 4, 224), (9, 3, 40)])
 def test_apply_fwd_launch_orders_are_equivalent(B, S, H):
-    """dp_apply_fwd walks its workgroups XCD by XCD (a unit's samples adjacent on one XCD, the source tile fetched from
-    HBM once); DP_DEBUG_APPLY_ORDER = 1 is the ABI-7 3-D grid.  Same bytes either way, also when the number of
-    (image, tile) units is not a multiple of 8 (the padded workgroups of the 1-D launch exit)."""
+    """dp_apply_fwd's A/B launch order (DP_DEBUG_APPLY_ORDER = 1: workgroups walk XCD by XCD, a unit's samples adjacent
+    on one XCD, the source tile fetched from HBM once — less traffic, measured slower, not the default) against the
+    3-D grid.  Same bytes either way, also when the number of (image, tile) units is not a multiple of 8 (the padded
+    workgroups of the 1-D launch exit)."""
     from dorpatch_amd._lib import DP_DEBUG_APPLY_ORDER as KNOB
     x = _rand(B, 3, H, H, seed=3).to(DEV)
     table = ops.upload_table(masks.universe_rects(H, 2), DEV)
@@ -352,6 +354,31 @@ def test_debug_knobs_reject_unknown_values():
         ops.debug_set(99, 0)
     with pytest.raises(RuntimeError):
         ops.debug_set(2, 5)
+
+
+@pytest.mark.parametrize("N,C", [(1, 16), (3, 64)])
+def test_conv3x3_on_the_matrix_cores_matches_conv2d(N, C):
+    """dp_conv3x3_fwd (direct implicit GEMM on v_mfma_f32_32x32x2_f32, candidate for the backbone's 3x3 convolutions)
+    against F.conv2d: exact-f32 arithmetic, another summation order -> 1e-5 of the output scale.  Structured inputs
+    catch layout slips a random tensor would blur: a one-hot weight (each output channel copies ONE shifted input
+    channel: exact equality), an asymmetric ramp image, zero padding at all four borders.  C = 16 is the size the CPU
+    emulation can afford (2 K-chunks: the double buffer is exercised); C = 64 runs on the GPU only."""
+    if C == 64 and DEV == "cpu":
+        pytest.skip("C = 64 through the fibre emulation takes minutes: GPU only")
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(N, C, 56, 56, generator=g)
+    x[0, :, :, :] += torch.arange(56.0).view(1, 56, 1) * 0.1 + torch.arange(56.0).view(1, 1, 56) * 0.01
+    w = torch.randn(64, C, 3, 3, generator=g) / (3.0 * C ** 0.5)
+    want = F.conv2d(x, w, padding=1)
+    got = ops.conv3x3_fwd(x.to(DEV).contiguous(), ops.pack_conv3x3_weights(w).to(DEV)).cpu()
+    scale = float(want.abs().max())
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=1e-5 * scale)
+    # one-hot weights: output channel o = input channel (5 o + 3) % C shifted by tap (o % 3, (o // 3) % 3) — exact
+    w1 = torch.zeros(64, C, 3, 3)
+    for o in range(64):
+        w1[o, (5 * o + 3) % C, o % 3, (o // 3) % 3] = 1.0
+    got1 = ops.conv3x3_fwd(x.to(DEV).contiguous(), ops.pack_conv3x3_weights(w1).to(DEV)).cpu()
+    assert torch.equal(got1, F.conv2d(x, w1, padding=1))
 
 
 # ---------------------------------------------------------------- fused GroupNorm + ReLU (backbone, a-8)

@@ -284,6 +284,32 @@ int main(int argc, char **argv) {
   dp_norm_t norm = {1, {0.5f, 0.5f, 0.5f}, {0.5f, 0.5f, 0.5f}, 0.5f};
   const double out_bytes = (double)N * img;
 
+  if (g_filter && strstr(g_filter, "conv3x3")) {
+    // the 64 -> 64 3x3 convolution @56^2 at the training micro-batch (B here = N of the convolution)
+    // on the matrix cores; MIOpen's fp32 Winograd runs it in 1.04 ms at N = 512 (113 TFLOP/s effective).
+    const int Nc = B;
+    const size_t e = (size_t)Nc * 64 * 3136;
+    float *cx = (float *)dmalloc(e * 4), *cy = (float *)dmalloc(e * 4), *cw = (float *)dmalloc(64 * 576 * 4);
+    hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, st, (f4 *)cx, e / 4, 0.37f);
+    hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, st, (f4 *)cw, 64 * 576 / 4, 0.01f);
+    const double flop = 2.0 * Nc * 3136.0 * 64 * 576;
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0));
+      CK(hipEventCreate(&e1));
+      DP(dp_conv3x3_fwd(cx, cw, Nc, 64, 64, 56, 56, cy, st));
+      CK(hipEventRecord(e0, st));
+      for (int i = 0; i < iters; ++i) DP(dp_conv3x3_fwd(cx, cw, Nc, 64, 64, 56, 56, cy, st));
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= iters;
+      printf("dp_conv3x3_fwd 64->64 @56x56 N=%d (v_mfma_f32_32x32x2_f32)  %8.4f ms  %7.1f TFLOP/s  (%.1f%% of the 157.3 TFLOP/s f32 peak)\n",
+             Nc, ms, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 1.573);
+    }
+    return 0;
+  }
   if (g_filter && strstr(g_filter, "fma_rate")) {
     const int it = 4096, blocks = 256 * 16;
     for (int packed = 0; packed < 6; ++packed) {
@@ -347,7 +373,7 @@ int main(int argc, char **argv) {
   bench("dp_apply_fwd (default variant)", out_bytes + (double)B * img, iters, st,
         [&] { DP(dp_apply_fwd(adv, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, big, st)); });
   g_apply_order = 1;
-  bench("dp_apply_fwd (ABI-7 3-D grid order)", out_bytes + (double)B * img, iters, st,
+  bench("dp_apply_fwd (XCD-aware walk, A/B)", out_bytes + (double)B * img, iters, st,
         [&] { DP(dp_apply_fwd(adv, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, big, st)); });
   g_apply_order = 0;
   for (int variant : {1, 2, 4, 9, 10, 12, 16 + 4, 16 + 7, 16 + 8 + 4, 16 + 8 + 7, 32 + 9, 32 + 10, 32 + 1, 64 + 9, 64 + 10}) {
