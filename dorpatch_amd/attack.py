@@ -398,7 +398,10 @@ def _collect_failure(net, norm, adv_x, y_img, table, targeted_flags, batch_size,
     """Per-image failed-mask lists (attack.py:384-406).  ``y_img`` (B,) int64 device tensor,
     ``targeted_flags`` bool or (B,) bool array.  Ranks of ``pg`` each sweep a slice of the
     universe and exchange a (B, n_mask) failure bitmap.  ``plan``: [(first image, end image, masks per forward)]
-    (default: all images together, ``batch_size`` masks per forward — the reference's loop)."""
+    (default: all images together, ``batch_size`` masks per forward — the reference's loop).  With a plan the short last
+    chunk of a group is padded to the full row count (its last mask repeated, the extra predictions dropped): a new
+    batch size costs MIOpen a kernel lookup per layer + the determinism probes — 10 s per new size measured
+    (profiles/r04b_bench_whole_attack.json: 32 s of sweeps instead of 10 when a batch shrank to 3 and 2 images)."""
     B, _, H, W = adv_x.shape
     n_mask = table.shape[0]
     dev = adv_x.device
@@ -407,16 +410,20 @@ def _collect_failure(net, norm, adv_x, y_img, table, targeted_flags, batch_size,
     lo, hi = dp_dist.mask_bounds(n_mask, world, rank)
     fail = torch.zeros((B, n_mask), dtype=torch.int32, device=dev)
     tflag = torch.as_tensor(np.broadcast_to(np.asarray(targeted_flags, dtype=bool), (B,)).copy(), device=dev)
+    pad_tail = plan is not None       # the reference's own loop (public collect_failure) runs its short last batch as is
     if plan is None:
         plan = [(0, B, max(1, int(batch_size)))]
     for b0, b1, chunk in plan:
+        chunk = max(1, min(chunk, hi - lo))          # a universe (slice) smaller than one forward: no padding beyond it
         g = b1 - b0
         xg, yg, tg = adv_x[b0:b1], y_img[b0:b1].view(g, 1).to(torch.int32), tflag[b0:b1].view(g, 1)
         for j0 in range(lo, hi, chunk):
             j1 = min(hi, j0 + chunk)
             idx = torch.arange(j0, j1, dtype=torch.int32, device=dev)
+            if pad_tail and j1 - j0 < chunk:      # the last, short chunk: repeat its last mask so the classifier sees
+                idx = torch.cat([idx, idx[-1:].expand(chunk - (j1 - j0))])     # the row count it has seen all along
             inp = ops.apply_fwd(xg, table, idx, None, dn)
-            pred = ops.argmax(net(inp).float().contiguous()).view(g, j1 - j0)
+            pred = ops.argmax(net(inp).float().contiguous()).view(g, idx.numel())[:, :j1 - j0]
             same = pred == yg
             # untargeted: still classified as y => failure; targeted: not (yet) the target => failure
             fail[b0:b1, j0:j1] = torch.where(tg, ~same, same).to(torch.int32)

@@ -278,7 +278,24 @@ def test_end_metric_at_224_through_resnetv2_is_a_plausible_draw_from_the_referen
                                                                             adv_pred.tolist()))
     print("               reference runs: pred %s cert %s n_fail %s adv_pred %s" % (
         g["pc_pred"].tolist(), g["pc_cert"].tolist(), g["n_fail"].tolist(), g["adv_pred"].tolist()))
-    check_against_null(g, pred, cert, n_fail, adv_pred, per_image=BIT224_PER_IMAGE)
-
-
-BIT224_PER_IMAGE = True     # the recorded runs' per-image failure counts are stable enough to hold the product to them
+    # The four recorded runs are UNANIMOUS on everything (2 ulp of gradient noise moves nothing here): image 0 is not
+    # broken at all (2520 of 2520 masks fail, PatchCleanser certifies the clean class at all four ratios), image 1 is
+    # broken (1 failing mask of 2520; PatchCleanser returns the TARGET at all four ratios, certified at 0.015 / 0.03 / 0.06
+    # and not at 0.12) -> certified ASR 50 / 50 / 50 / 0 %, certified ACC 50 / 50 / 50 / 50 %.  With a two-image fixture
+    # the interval tests of check_against_null are vacuous (their slack is two images), so the product is held to the
+    # cells directly: at most ONE of the 8 (image, ratio) cells may differ for "certified attack success" and for
+    # "certified clean label", the clean adversarial images must land where the reference's do, and each failure count
+    # must lie within 10 % of the universe (250 masks) of the recorded range.
+    target, clean = g["target"], g["clean"]
+    ref_asr = (g["pc_pred"] == target[None, :, None]) & g["pc_cert"].astype(bool)
+    ref_acc = (g["pc_pred"] == clean[None, :, None]) & g["pc_cert"].astype(bool)
+    assert (ref_asr == ref_asr[0]).all() and (ref_acc == ref_acc[0]).all() and (g["n_fail"] == g["n_fail"][0]).all()
+    asr, acc = (pred == target[:, None]) & cert, (pred == clean[:, None]) & cert
+    print("certified ASR per ratio: product %s reference %s; certified ACC: product %s reference %s" % (
+        (asr.mean(0) * 100).tolist(), (ref_asr[0].mean(0) * 100).tolist(), (acc.mean(0) * 100).tolist(),
+        (ref_acc[0].mean(0) * 100).tolist()))
+    assert int((asr != ref_asr[0]).sum()) <= 1, (asr.tolist(), ref_asr[0].tolist())
+    assert int((acc != ref_acc[0]).sum()) <= 1, (acc.tolist(), ref_acc[0].tolist())
+    assert ((adv_pred == target) == (g["adv_pred"][0] == target)).all(), (adv_pred.tolist(), g["adv_pred"][0].tolist())
+    lo, hi = g["n_fail"].min(0), g["n_fail"].max(0)
+    assert (np.maximum(np.maximum(lo - n_fail, n_fail - hi), 0) <= 250).all(), (n_fail.tolist(), lo.tolist(), hi.tolist())

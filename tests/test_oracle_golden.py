@@ -82,3 +82,30 @@ def test_final_mask_is_cell_aligned(golden_steps_56):
     assert ((cells.min(axis=(3, 5)) == cells.max(axis=(3, 5)))).all()
     # patch budget 0.12 @56x56 -> floor(3136*0.12/49) = 7 cells
     assert m.sum() <= 7 * 49
+
+
+def test_end_metric_224_fixture_is_self_consistent():
+    """tests/golden/end_metric_bit_224.npz (unmodified reference, 224 x 224 through ResNetV2-50x1-BiT with a 10-class head,
+    gen_golden.make_end_metric_bit224_fixture): the problem definition can be rebuilt from what the file stores — the
+    seeded network + the recorded head-bias shift reproduces the recorded clean class, the target is the runner-up at the
+    stated margin — and the four recorded runs tell one story (image 0 unbroken and certified clean, image 1 broken:
+    the target certified at three of four ratios)."""
+    import torch
+    from conftest import load_golden
+    from dorpatch_amd.resnetv2 import WELL_CONDITIONED_GN_BIAS, resnetv2_50x1_bit, seeded_init_
+    from dorpatch_amd.utils import NormModel, get_normalize
+    g = load_golden("end_metric_bit_224.npz")
+    assert (int(g["H"]), int(g["S"]), int(g["max_iterations"]), int(g["n_classes"])) == (224, 32, 100, 10)
+    for k in range(2):
+        net = seeded_init_(resnetv2_50x1_bit(10), seed=1234, gn_bias=WELL_CONDITIONED_GN_BIAS).fold_weight_standardization().freeze()
+        with torch.no_grad():
+            net.head.fc.bias[int(g["target"][k])] += float(g["gains"][k])
+            logits = NormModel(net, get_normalize("imagenet", "resnetv2")).eval()(torch.from_numpy(g["x"][k:k + 1]))[0]
+        top = logits.topk(2)
+        assert int(top[1][0]) == int(g["clean"][k]) and int(top[1][1]) == int(g["target"][k])
+        if not np.isnan(g["margins"][k]):
+            assert abs(float(top[0][0] - top[0][1]) - float(g["margins"][k])) < 1e-4
+    assert (g["n_fail"] == np.array([2520, 1])).all() and (g["adv_pred"] == np.array([5, 1])).all()
+    asr = ((g["pc_pred"] == g["target"][None, :, None]) & g["pc_cert"]).mean(1) * 100
+    acc = ((g["pc_pred"] == g["clean"][None, :, None]) & g["pc_cert"]).mean(1) * 100
+    assert (asr == np.array([50.0, 50.0, 50.0, 0.0])).all() and (acc == 50.0).all()     # every run, every ratio
