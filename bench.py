@@ -124,6 +124,8 @@ def parse(argv=None):
     ap.add_argument("--attack-iterations", type=int, default=1000, help="--whole-attack: max_iterations per stage")
     ap.add_argument("--attack-batch", type=int, default=4, help="--whole-attack: images in the batch")
     ap.add_argument("--attack-modes", default="retire,no_retire", help="--whole-attack: which variants to run")
+    ap.add_argument("--no-attack-warmup", action="store_true",
+                    help="--whole-attack: skip the two throw-away 2-iteration attacks that warm the library's batch shapes")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): --samples masks per image PER GPU, the job grows with --gpus; strong: --samples "
                          "masks per image IN TOTAL, each of the N ranks takes 1/N of them (with --config 3: 512 in total = "
@@ -331,12 +333,22 @@ def whole_attack(args, dev, model=None, n_classes=None, extra_argv=()):
     from dorpatch_amd import driver
     B, K, S = args.attack_batch, args.attack_iterations, 128
     res = {}
-    for mode in [m for m in args.attack_modes.split(",") if m]:
+    modes = [m for m in args.attack_modes.split(",") if m]
+    if not args.no_attack_warmup:
+        # The first use of a batch SHAPE costs MIOpen tens of seconds of kernel loading plus the determinism probes
+        # (profiles/README.md) — once per process, whichever variant meets the shape first.  A batch whose images retire
+        # presents 128-row micro-batches (one image) that the non-retiring run never sees, so an unwarmed comparison bills
+        # that one-off to `retire` (measured: rounds r04a-c).  Two throw-away 2-iteration attacks — one image (128 rows)
+        # and the full batch (B x 128 rows) — warm every shape either variant will use; nothing of them is timed.
+        modes = ["warmup1", "warmupB"] + modes
+    for mode in modes:
         tmp = tempfile.mkdtemp(prefix="dp_whole_", dir="/tmp")
         cwd = os.getcwd()
         os.chdir(tmp)                       # the reference's result paths are relative (attack.py:103)
         try:
-            argv = ["--synthetic", "--targeted", "-b", str(B), "--num_images", "1", "--max_iterations", str(K),
+            warm = mode.startswith("warmup")
+            argv = ["--synthetic", "--targeted", "-b", str(1 if mode == "warmup1" else B), "--num_images", "1",
+                    "--max_iterations", str(2 if warm else K),
                     "--sampling_size", str(S), "--img_size", str(args.size), "--micro_batch", str(args.micro_batch),
                     "--quiet"] + (["--no_retire"] if mode == "no_retire" else []) + list(extra_argv)
             dargs = driver.build_parser().parse_args(argv)
@@ -350,6 +362,9 @@ def whole_attack(args, dev, model=None, n_classes=None, extra_argv=()):
         finally:
             os.chdir(cwd)
             shutil.rmtree(tmp, ignore_errors=True)
+        if mode.startswith("warmup"):
+            note("whole attack: shapes warmed (%s, %.1f s, not timed)" % (mode, total))
+            continue
         bd = out["attack_breakdown"][0]
         n = max(1, bd["images"])
         res[mode] = {
@@ -371,7 +386,7 @@ def whole_attack(args, dev, model=None, n_classes=None, extra_argv=()):
                                    "@%dx%d (reference defaults otherwise: patch_budget 0.12, dropout 2, eps 4), ResNetV2-50x1-BiT "
                                    "seeded random weights: stage 0 + stage 1 + collect_failure sweeps + PatchCleanser x4 ratios "
                                    "(reference main.py:82-153)" % (K, B, S, args.size, args.size)},
-            "variants": res}
+            "variants": res, "shapes_warmed_before_timing": not args.no_attack_warmup}
     if "retire" in res and "no_retire" in res:
         line["straggler_saving"] = {
             "seconds_per_image": round(res["no_retire"]["seconds_per_image"] - res["retire"]["seconds_per_image"], 3),

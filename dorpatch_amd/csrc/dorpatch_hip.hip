@@ -409,8 +409,11 @@ __device__ __forceinline__ void affine_src(const Affine &A, int ox, int oy, floa
 //             (source pixel, candidate).  A source pixel then tests its 2kx x 2ky candidate outputs (kx = ceil of the
 //             inverse map's row sum: 4 x 4 for the default placement range) with one LDS read each and accumulates the
 //             hits in row-major order of the outputs, samples ascending: deterministic.
-// A footprint that does not fit the LDS budget (extreme scale / rotation) takes the round-2 per-pixel code (slow path,
-// same arithmetic).  Identity placement stays bit-identical to dp_apply_fwd / dp_apply_bwd.
+// A footprint that does not fit the LDS budget (extreme scale / rotation) takes the round-2 per-pixel code (slow path:
+// the same tap positions and weights — both paths take them from affine_src — but the forward's staged path accumulates
+// its 4 taps with an fma chain where the per-pixel path uses separate multiplies and adds, so a sample that changes path
+// may differ in the last bit; the backward's two paths add the same products in the same order).  Identity placement
+// stays bit-identical to dp_apply_fwd / dp_apply_bwd.
 // Both kernels WALK several samples per workgroup: the next sample's loads are issued right after the barrier that
 // publishes the current one and land in registers during the current sample's LDS phase, and everything block-uniform
 // per sample (maps, footprint / region box, which occlusion windows touch it) is computed once per walk, one sample per
@@ -1331,32 +1334,39 @@ __global__ __launch_bounds__(kBlock) void k_project_update(UpdateArgs A) {
   }
 }
 
-// The same step with 16-byte lanes (W % 4 == 0, W <= 512, 16-byte aligned tensors: every size the attack runs at).
-// A workgroup owns 1024 CONSECUTIVE pixels of one image (row-major: 4.6 rows @224); one lane = 4 consecutive pixels x 3
-// channels, so g_adv, pattern, x, mask and the best-so-far copies move as float4 and every array is read / written as
-// one ascending 4 KiB run per workgroup (the scalar kernel above issues 4-byte requests on 32 x 8 tiles: 38 % of the HBM
-// roofline; a first 16-byte version on 32 x 32 tiles — 128-byte pieces of 32 rows per array — reached 54 %: write
-// streams in short pieces are what this GPU's memory system dislikes most, profiles/r02d_kbench_calibration_*).
-// Neighbours (left, up, and the two diagonal pixels the structural gradient needs) come from LDS: the window
-// [p0 - W - 4, p0 + 1024 + W + 4) of adv_x and [p0 - W - 4, p0 + 1024) of lv_x, staged with aligned float4 loads (zeros
-// outside the image; the row-edge conditions never let them be used).  The lane's own streaming operands are requested
-// before the staging so they are in flight across the barrier.  Arithmetic per pixel: the scalar kernel's, expression
-// for expression (bit-identical results: tests compare the two).
-constexpr int kUPix = kBlock * 4;   // pixels per workgroup
+// The same step with 16-byte lanes (W % 4 == 0, 16-byte aligned tensors: every shape the backbone takes).  A workgroup
+// owns a 32 x 32 pixel tile; one lane = 4 consecutive pixels of a row x 3 channels, so g_adv, pattern, x, mask, lv_x and
+// the best-so-far copies move as float4 (the scalar kernel above issues 4-byte requests: 38 % of the HBM roofline on a
+// 0.9 GB working set; this one 54 % in stage 0, 61 % in stage 1).  adv_x (1-pixel halo all round) and lv_x (halo up /
+// left) are staged in LDS with float4 interior loads; the arithmetic per pixel is the scalar kernel's, expression for
+// expression (bit-identical results: tests compare the two).
+// Measured and not kept (round 4, profiles/r04c_kbench_update_*_1d_variant.txt): the same lanes over 1024 CONSECUTIVE
+// pixels per workgroup (every array one ascending 4 KiB run, LDS window of 1024 + 2 W + 8 pixels) — 50 % / 59 %: the
+// window's 45 % halo (re-read from another XCD's L2 or HBM) costs more than the tidier streams gain; and issuing the
+// lane's 10 streaming loads before the tile staging instead of after the barrier changed nothing (0.2146 ms both ways):
+// the kernel is not latency-bound.
+constexpr int UW = 32, UH = 32;      // tile; 256 lanes = 32 rows x 8 float4 columns (224 = 7 tiles, 384 = 12)
+constexpr int URS = UW + 8;          // LDS row stride: pixel (., w0 + lx) at [4 + lx]; left halo [3], right halo [4 + UW]
 
-template <int MAXW>
+struct TileU {
+  float v[3][UH + 2][URS];           // [ly] <-> row h0 + ly - 1
+};
+
 __global__ __launch_bounds__(kBlock) void k_project_update_v4(UpdateArgs A) {
-  constexpr int NA = kUPix + 2 * MAXW + 8, NL = kUPix + MAXW + 4;
-  __shared__ __attribute__((aligned(16))) float sa[3][NA];   // sa[c][i] <-> pixel (p0 - W - 4) + i
-  __shared__ __attribute__((aligned(16))) float sl[NL];      // same origin
+  __shared__ __attribute__((aligned(16))) TileU t;
+  __shared__ __attribute__((aligned(16))) float s_lv[UH + 1][URS];   // [ly] <-> row h0 + ly - 1; same column layout
   __shared__ float s_wmean;
   const int H = A.H, W = A.W, P = H * W;
-  const int b = blockIdx.y;
-  const int p0 = blockIdx.x * kUPix, org = p0 - W - 4;       // both multiples of 4
+  const int b = blockIdx.z;
+  const int h0 = blockIdx.y * UH, w0 = blockIdx.x * UW;
+  const float *img = A.adv_x + (size_t)b * 3 * P;
   const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  const int p = p0 + 4 * threadIdx.x;
-  const bool mine = p < P;
-  const size_t pix = mine ? (size_t)p : 0;
+  // the lane's own streaming operands first: 10 independent 16-byte loads in flight while the tile is staged (issued
+  // after the barrier they would wait behind it: 0.214 -> see KERNELS.md)
+  const int q = threadIdx.x & (UW / 4 - 1), ty = threadIdx.x / (UW / 4);
+  const int h = h0 + ty, wq = w0 + 4 * q;
+  const bool mine = h < H && wq < W;
+  const size_t pix = mine ? (size_t)h * W + wq : 0;
   const f4 m4 = *reinterpret_cast<const f4 *>(A.mask + (size_t)b * P + pix);
   f4 g4[3], pv4[3], x4[3];
 #pragma unroll
@@ -1366,22 +1376,35 @@ __global__ __launch_bounds__(kBlock) void k_project_update_v4(UpdateArgs A) {
     pv4[c] = *reinterpret_cast<const f4 *>(A.pattern + off);
     x4[c] = *reinterpret_cast<const f4 *>(A.x + off);
   }
-  const float *img = A.adv_x + (size_t)b * 3 * P;
-  const int na4 = (kUPix + 2 * W + 8) >> 2;
-  for (int c = 0; c < 3; ++c)
-    for (int j = threadIdx.x; j < na4; j += kBlock) {
-      const int gp = org + 4 * j;
-      f4 v = zero4;
-      if (gp >= 0 && gp < P) v = *reinterpret_cast<const f4 *>(img + (size_t)c * P + gp);
-      *reinterpret_cast<f4 *>(&sa[c][4 * j]) = v;
-    }
+  for (int i = threadIdx.x; i < 3 * (UH + 2) * (UW / 4); i += kBlock) {
+    const int c = i / ((UH + 2) * (UW / 4));
+    const int r = i - c * ((UH + 2) * (UW / 4));
+    const int ly = r / (UW / 4), q = r - ly * (UW / 4);
+    const int h = h0 + ly - 1, w = w0 + 4 * q;
+    f4 val = zero4;
+    if (h >= 0 && h < H && w < W) val = *reinterpret_cast<const f4 *>(img + ((size_t)c * H + h) * W + w);
+    *reinterpret_cast<f4 *>(&t.v[c][ly][4 + 4 * q]) = val;
+  }
+  for (int i = threadIdx.x; i < 3 * (UH + 2) * 2; i += kBlock) {      // the two halo columns
+    const int c = i / ((UH + 2) * 2);
+    const int r = i - c * ((UH + 2) * 2);
+    const int ly = r >> 1, side = r & 1;
+    const int h = h0 + ly - 1, w = side ? (w0 + UW) : (w0 - 1);
+    float val = 0.f;
+    if (h >= 0 && h < H && w >= 0 && w < W) val = img[((size_t)c * H + h) * W + w];
+    t.v[c][ly][side ? (4 + UW) : 3] = val;
+  }
   const float *lvp = A.lv_x + (size_t)b * P;
-  const int nl4 = (kUPix + W + 4) >> 2;
-  for (int j = threadIdx.x; j < nl4; j += kBlock) {
-    const int gp = org + 4 * j;
-    f4 v = zero4;
-    if (gp >= 0 && gp < P) v = *reinterpret_cast<const f4 *>(lvp + gp);
-    *reinterpret_cast<f4 *>(&sl[4 * j]) = v;
+  for (int i = threadIdx.x; i < (UH + 1) * (UW / 4); i += kBlock) {
+    const int ly = i / (UW / 4), q = i - ly * (UW / 4);
+    const int h = h0 + ly - 1, w = w0 + 4 * q;
+    f4 val = zero4;
+    if (h >= 0 && h < H && w < W) val = *reinterpret_cast<const f4 *>(lvp + (size_t)h * W + w);
+    *reinterpret_cast<f4 *>(&s_lv[ly][4 + 4 * q]) = val;
+  }
+  if (threadIdx.x < UH + 1) {
+    const int ly = threadIdx.x, h = h0 + ly - 1, w = w0 - 1;
+    s_lv[ly][3] = (h >= 0 && h < H && w >= 0) ? lvp[(size_t)h * W + w] : 0.f;
   }
   const int nwindow = A.nwy * A.nwx;
   if (A.stage == 0 && threadIdx.x == 64) {
@@ -1390,10 +1413,10 @@ __global__ __launch_bounds__(kBlock) void k_project_update_v4(UpdateArgs A) {
     s_wmean = mean / (float)nwindow;
   }
   __syncthreads();
-  if (!mine) return;
 
-  const int h = p / W, wq = p - h * W;        // the lane's 4 pixels lie in one row (W % 4 == 0)
-  const int li = p - org;                     // local index of the first of them
+  if (!mine) return;
+  const int ly = ty + 1;
+
   const float s = A.scale[b];
   const float coef = A.structured[b];
   const float base = coef / (float)P;
@@ -1404,24 +1427,24 @@ __global__ __launch_bounds__(kBlock) void k_project_update_v4(UpdateArgs A) {
     const f4 p4 = pv4[c];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int w = wq + k, i = li + k;
+      const int w = wq + k, lx = 4 + 4 * q + k;
       float g = g4[c][k];
       if (coef != 0.f) {
-        const float up_left = (w >= 1) ? (base / (sl[i - 1] + 1e-5f)) / 3.f : 0.f;
-        const float up_up = (h >= 1) ? (base / (sl[i - W] + 1e-5f)) / 3.f : 0.f;
-        const float xc = sa[c][i];
+        const float up_left = (w >= 1) ? (base / (s_lv[ly][lx - 1] + 1e-5f)) / 3.f : 0.f;
+        const float up_up = (h >= 1) ? (base / (s_lv[ly - 1][lx] + 1e-5f)) / 3.f : 0.f;
+        const float xc = t.v[c][ly][lx];
         float gs = 0.f;
         if (w >= 1) {          // L at (h, w - 1): a = |v - right| (right = this pixel), b = |v - down|
-          const float v = sa[c][i - 1];
+          const float v = t.v[c][ly][lx - 1];
           const float a = fabsf(v - xc);                                          // w - 1 < W - 1 always
-          const float bb = (h < H - 1) ? fabsf(v - sa[c][i + W - 1]) : v;
+          const float bb = (h < H - 1) ? fabsf(v - t.v[c][ly + 1][lx - 1]) : v;
           const float mn = (a > bb) ? bb : a;
           const float dLda = mn + ((a > bb) ? 0.f : (a + bb));
           gs -= up_left * dLda * sgn(v - xc);
         }
         if (h >= 1) {          // L at (h - 1, w): a = |v - right|, b = |v - down| (down = this pixel)
-          const float v = sa[c][i - W];
-          const float a = (w < W - 1) ? fabsf(v - sa[c][i - W + 1]) : v;
+          const float v = t.v[c][ly - 1][lx];
+          const float a = (w < W - 1) ? fabsf(v - t.v[c][ly - 1][lx + 1]) : v;
           const float bb = fabsf(v - xc);                                         // h - 1 < H - 1 always
           const float mn = (a > bb) ? bb : a;
           const float dLdb = mn + ((a > bb) ? (a + bb) : 0.f);
@@ -1481,8 +1504,8 @@ __global__ __launch_bounds__(kBlock) void k_project_update_v4(UpdateArgs A) {
     f4 pn;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float pp = pv4[c][k] - lr * sgn(gp4[c][k]);
-      pn[k] = fminf(fmaxf(pp, A.clip_min), A.clip_max);
+      const float p = pv4[c][k] - lr * sgn(gp4[c][k]);
+      pn[k] = fminf(fmaxf(p, A.clip_min), A.clip_max);
     }
     *reinterpret_cast<f4 *>(A.pattern + ((size_t)b * 3 + c) * P + pix) = pn;
   }
@@ -3232,7 +3255,7 @@ static int launch_apply_affine_fwd(const float *x, const float *delta, const flo
                                    const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
                                    const dp_norm_t *norm, float *out, dp_stream_t stream, hipEvent_t ev_start,
                                    hipEvent_t ev_stop) {
-  DP_REQUIRE(x && delta && theta && out && aligned16(x) && aligned16(out));
+  DP_REQUIRE(x && delta && theta && out && aligned16(x) && aligned16(out) && aligned16(delta));   // b128 buffer loads of delta
   const int rc = check_occlusion_args(table, R, idx, idx_bstride, B, S, H, W, norm);
   if (rc) return rc;
   const int tiles_x = cdiv(W, kAffT), tiles_y = cdiv(H, kAffT);
@@ -3268,7 +3291,7 @@ static int g_aff_bwd_cap = 0;   // tools/kbench: 2048 selects the 48 KiB variant
 int dp_apply_affine_bwd(const float *G, const float *theta, const float *theta_inv, const int32_t *table, int R,
                         const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
                         const dp_norm_t *norm, float *slabs, dp_stream_t stream) {
-  DP_REQUIRE(G && theta && theta_inv && slabs);
+  DP_REQUIRE(G && theta && theta_inv && slabs && aligned16(G));   // affine_region_load reads G as float4
   const int rc = check_occlusion_args(table, R, idx, idx_bstride, B, S, H, W, norm);
   if (rc) return rc;
   DP_REQUIRE(H < (1 << 22) && W < (1 << 22));   // 24-bit multiplies in the region addressing
@@ -3387,12 +3410,9 @@ int dp_project_update(const dp_update_cfg_t *cfg, const float *x, const float *a
                     aligned16(g_adv) && aligned16(pattern) && aligned16(mask) &&
                     (!best_pattern || aligned16(best_pattern)) && (!best_mask || aligned16(best_mask)) &&
                     (!g_pattern_out || aligned16(g_pattern_out)) && (!g_mask_out || aligned16(g_mask_out));
-  if (wide && cfg->W <= 256)
-    hipLaunchKernelGGL(k_project_update_v4<256>, dim3(cdiv(cfg->H * cfg->W, kUPix), cfg->B), dim3(kBlock), 0,
-                       as_stream(stream), A);
-  else if (wide && cfg->W <= 512)
-    hipLaunchKernelGGL(k_project_update_v4<512>, dim3(cdiv(cfg->H * cfg->W, kUPix), cfg->B), dim3(kBlock), 0,
-                       as_stream(stream), A);
+  if (wide)
+    hipLaunchKernelGGL(k_project_update_v4, dim3(cdiv(cfg->W, UW), cdiv(cfg->H, UH), cfg->B),
+                       dim3(kBlock), 0, as_stream(stream), A);
   else
     hipLaunchKernelGGL(k_project_update, dim3(cdiv(cfg->W, TW), cdiv(cfg->H, TH), cfg->B),
                        dim3(kBlock), 0, as_stream(stream), A);

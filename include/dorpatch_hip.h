@@ -53,7 +53,7 @@ const char *dp_error_string(int err);
  * DORPATCH_AFFINE_SPB environment variable of ABI 7.  Returns 1 (hipErrorInvalidValue) for an unknown knob / value.
  *   DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK  samples one dp_apply_affine_fwd workgroup walks (1..64; 0: sized from the grid)
  *   DP_DEBUG_UPDATE_VARIANT            dp_project_update: 1 = the 4-byte-lane kernel even where the 16-byte-lane
- *                                      kernel applies (0: 16-byte lanes whenever W % 4 == 0, W <= 512 and pointers are aligned)
+ *                                      kernel applies (0: 16-byte lanes whenever W % 4 == 0 and pointers are aligned)
  *   DP_DEBUG_APPLY_ORDER               dp_apply_fwd grid walk: 1 = XCD-aware (a tile's samples adjacent on one XCD: 10 %
  *                                      less HBM traffic, measured 19 % slower); 0: tile-fastest 3-D grid (one ascending
  *                                      output stream) */

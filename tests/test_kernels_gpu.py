@@ -281,9 +281,9 @@ def test_project_update_grads_and_update(stage, B, H):
 @pytest.mark.parametrize("stage", [0, 1])
 @pytest.mark.parametrize("B,H,W", [(2, 56, 56), (1, 224, 224), (1, 384, 384), (3, 40, 36), (2, 33, 100), (1, 7, 8)])
 def test_project_update_wide_lanes_equal_the_scalar_kernel(stage, B, H, W):
-    """dp_project_update's 16-byte-lane kernel (one lane = 4 pixels x 3 channels, 1024 consecutive pixels per workgroup) against the 4-byte-lane
+    """dp_project_update's 16-byte-lane kernel (one lane = 4 pixels x 3 channels, 32 x 32 tiles) against the 4-byte-lane
     kernel (DP_DEBUG_UPDATE_VARIANT = 1) it replaces: gradients incl. the NaN cells, best-so-far copies and updated
-    parameters bit for bit, at the attack sizes (224, 384), ragged ones (36, 100 wide; a last workgroup with idle lanes) and a single cell."""
+    parameters bit for bit, on tile-aligned sizes (224 = 7 tiles), ragged ones (36, 100, 40 rows) and a single cell."""
     from dorpatch_amd._lib import DP_DEBUG_UPDATE_VARIANT as KNOB
     g = torch.Generator().manual_seed(100 * stage + H + W)
     r = lambda *shape: torch.rand(*shape, generator=g).to(DEV)

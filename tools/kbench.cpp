@@ -98,6 +98,30 @@ __global__ __launch_bounds__(256) void k_copy_u(const f4 *__restrict__ in, f4 *_
   }
 }
 
+// The access pattern of dp_project_update without its arithmetic or its halo: per pixel read x 12 + adv 12 + g 12 + lv 4 +
+// pattern 12 + mask 4, write pattern 12 + mask 4 IN PLACE — what this GPU's memory system gives a 6-stream read /
+// 2-stream read-modify-write kernel (the ceiling the real kernel can be held to).  One lane = 4 consecutive pixels.
+__global__ __launch_bounds__(256) void k_calib_update_pattern(const float *__restrict__ x, const float *__restrict__ adv,
+                                                              const float *__restrict__ g, const float *__restrict__ lv,
+                                                              float *__restrict__ pattern, float *__restrict__ mask, int P) {
+  const int b = blockIdx.y;
+  const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (p >= P) return;
+  const f4 m4 = *reinterpret_cast<const f4 *>(mask + (size_t)b * P + p);
+  const f4 l4 = *reinterpret_cast<const f4 *>(lv + (size_t)b * P + p);
+  f4 acc = m4 + l4;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const size_t off = ((size_t)b * 3 + c) * P + p;
+    const f4 a = *reinterpret_cast<const f4 *>(x + off), d = *reinterpret_cast<const f4 *>(adv + off);
+    const f4 e = *reinterpret_cast<const f4 *>(g + off), q = *reinterpret_cast<const f4 *>(pattern + off);
+    const f4 r = (a - d) * e + q * 0.999f;
+    acc = acc + r;
+    *reinterpret_cast<f4 *>(pattern + off) = r;
+  }
+  *reinterpret_cast<f4 *>(mask + (size_t)b * P + p) = acc * 0.5f;
+}
+
 __global__ __launch_bounds__(256) void k_count_diff(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, size_t n,
                                                     int *__restrict__ count) {
   int local = 0;
@@ -478,6 +502,9 @@ int main(int argc, char **argv) {
   bench("dp_mask_stats", (double)B * P * 4, iters, st,
         [&] { DP(dp_mask_stats(mask, B, H, W, unit, win, cell, wsum, gl, dens, st)); });
   // ---- a-2 bwd + a-5/a-6 grads + a-9
+  bench("dp_project_update calib: bare 6-read / 2-RMW stream", (double)B * P * 72.0, iters, st, [&] {
+    hipLaunchKernelGGL(k_calib_update_pattern, dim3(cdiv(P, 1024), B), dim3(256), 0, st, x, adv, g_adv, lv, pattern, mask, P);
+  });
   for (int stage = 0; stage < 2; ++stage) {
     dp_update_cfg_t cfg = {B, H, W, stage, unit, win, 1, 1e-3f, 0.f, 1.f};
     // x 12 + adv_x 12 + lv 4 + g_adv 12 + pattern 12 r + 12 w + mask 4 r (+ 4 w in stage 0)
