@@ -16,7 +16,7 @@ from .build import LIB_PATH
 
 DP_ABI_VERSION = 8
 DP_MAX_RECTS = 4
-DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK, DP_DEBUG_UPDATE_VARIANT, DP_DEBUG_APPLY_ORDER = 1, 2, 3     # dp_debug_set knobs (tests / A-B)
+DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK, DP_DEBUG_UPDATE_VARIANT, DP_DEBUG_APPLY_ORDER, DP_DEBUG_AFFINE_GATHER = 1, 2, 3, 4   # dp_debug_set knobs
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers
 c_int_p = ctypes.c_void_p

@@ -34,6 +34,7 @@ constexpr int kBlock = 256;  // threads per workgroup: 4 waves of 64
 int g_aff_samples_per_block = 0;   // DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK (tools/kbench sweeps it too)
 int g_update_variant = 0;          // DP_DEBUG_UPDATE_VARIANT
 int g_apply_order = 0;             // DP_DEBUG_APPLY_ORDER
+int g_aff_gather = 0;              // DP_DEBUG_AFFINE_GATHER
 
 // Register-allocation hint: the compiler must forget what it knows about a lane-private value (so that it re-derives
 // addresses / predicates from it instead of keeping dozens of them alive).  No semantics; empty in the host emulation.
@@ -774,7 +775,7 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
     const float *__restrict__ G, const float *__restrict__ theta, const float *__restrict__ theta_inv,
     const int32_t *__restrict__ table, int R, const int32_t *__restrict__ idx,
     const int32_t *__restrict__ idx2, int idx_bstride, int B, int S, int H, int W, int tiles_x, int s_per_slab,
-    NormDev nd, float *__restrict__ slabs) {
+    NormDev nd, float *__restrict__ slabs, int g_dev_gather) {
   __shared__ __attribute__((aligned(16))) float sg[3 * CAP];
   __shared__ __attribute__((aligned(16))) float swx[CAP], swy[CAP];
   __shared__ __attribute__((aligned(16))) int stap[CAP];
@@ -920,6 +921,7 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
           acc[1][2] += wgt * g2;
         }
       };
+      if (g_dev_gather == 1) {   // round-3 gather (A/B, DP_DEBUG_AFFINE_GATHER = 1): a branch per candidate
       // A row of the window is <= 2 kx + 2 records (6 for the default placement range): its first 6 records are read
       // back to back before any is tested (one LDS round trip per row instead of one per candidate — the gather spent
       // its time waiting on them); order of accumulation unchanged: rows ascending, records ascending.
@@ -933,6 +935,56 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
         for (int u = 0; u < kRowAhead; ++u)
           if (e0 + u <= e1) candidate(e0 + u, rec[u]);
         for (int e = e0 + kRowAhead; e <= e1; ++e) candidate(e, stap[e]);
+      }
+      } else {
+      // Round 4: the same candidates in the same order, BRANCH-FREE.  The round-3 loop was latency-bound (SQ counters:
+      // VALU active 26 %, waves parked 44 %): every candidate was a data-dependent branch around five dependent LDS reads,
+      // and since some lane of the wave hits at almost every window position the wave executed nearly all of them anyway,
+      // one round trip at a time.  Here a row's 6 records AND their weights / gradients (36 dwords) are requested back to
+      // back, unconditionally, then tested and folded in with selects: two LDS round trips per row instead of ~7, no
+      // branches.  Trip counts are block-uniform (2 ky + 1 rows, ceil((2 kx + 2) / 6) column groups); a slot outside the
+      // thread's own window reads a clamped (valid) address and is discarded by its select.  acc = hit ? acc + w g : acc
+      // keeps every bit of the round-3 result (a non-hit leaves the accumulator untouched, not acc + 0).
+      constexpr int kCols = 6;
+      const int nrow = (cqx0 <= cqx1) ? (cqy1 - cqy0 + 1) : 0, ncol = cqx1 - cqx0 + 1;
+      const int rows_max = 2 * ky + 1, cols_max = 2 * kx + 2;
+      const int qy_safe = min(max(cqy0, 0), Q.QH - 1), qx_safe = min(max(cqx0, 0), QWp - 1);
+      for (int r = 0; r < rows_max; ++r) {
+        const bool rok = r < nrow;
+        const int er = __mul24(rok ? cqy0 + r : qy_safe, QWp);
+        for (int cb = 0; cb < cols_max; cb += kCols) {
+          int rec[kCols];
+          float fxs[kCols], fys[kCols], ga[kCols], gb[kCols], gc[kCols];
+#pragma unroll
+          for (int u = 0; u < kCols; ++u) {
+            const bool ok = rok && cb + u < ncol;
+            const int e = er + (ok ? cqx0 + cb + u : qx_safe);
+            rec[u] = stap[e];
+            fxs[u] = swx[e];
+            fys[u] = swy[e];
+            ga[u] = sg[e];
+            gb[u] = sg[CAP + e];
+            gc[u] = sg[2 * CAP + e];
+          }
+#pragma unroll
+          for (int u = 0; u < kCols; ++u) {
+            const bool ok = rok && cb + u < ncol;
+            const int d0 = want0 - rec[u], d1 = d0 + 1;
+            const bool hit0 = ok && ((unsigned)d0 & ~0x101u) == 0u, hit1 = ok && ((unsigned)d1 & ~0x101u) == 0u;
+            const float fx = fxs[u], fy = fys[u];
+            float w0 = (d0 & 1) ? fx : 1.f - fx;
+            w0 = (((d0 >> 8) & 1) ? fy : 1.f - fy) * w0;
+            float w1 = (d1 & 1) ? fx : 1.f - fx;
+            w1 = (((d1 >> 8) & 1) ? fy : 1.f - fy) * w1;
+            acc[0][0] = hit0 ? acc[0][0] + w0 * ga[u] : acc[0][0];
+            acc[0][1] = hit0 ? acc[0][1] + w0 * gb[u] : acc[0][1];
+            acc[0][2] = hit0 ? acc[0][2] + w0 * gc[u] : acc[0][2];
+            acc[1][0] = hit1 ? acc[1][0] + w1 * ga[u] : acc[1][0];
+            acc[1][1] = hit1 ? acc[1][1] + w1 * gb[u] : acc[1][1];
+            acc[1][2] = hit1 ? acc[1][2] + w1 * gc[u] : acc[1][2];
+          }
+        }
+      }
       }
     }
   }
@@ -3162,6 +3214,10 @@ int dp_debug_set(int knob, int value) {
       DP_REQUIRE(value == 0 || value == 1);
       g_apply_order = value;
       return 0;
+    case DP_DEBUG_AFFINE_GATHER:
+      DP_REQUIRE(value == 0 || value == 1);
+      g_aff_gather = value;
+      return 0;
     default:
       return (int)hipErrorInvalidValue;
   }
@@ -3303,11 +3359,11 @@ int dp_apply_affine_bwd(const float *G, const float *theta, const float *theta_i
   if (g_aff_bwd_cap == 2048)
     hipLaunchKernelGGL(k_apply_affine_bwd<2048>, dim3(tiles_x * tiles_y, nslab, B), dim3(kBlock), 0, as_stream(stream), G,
                        theta, theta_inv, table, R, idx, idx2, idx_bstride, B, S, H, W, tiles_x, s_per_slab,
-                       make_norm(norm), slabs);
+                       make_norm(norm), slabs, g_aff_gather);
   else
     hipLaunchKernelGGL(k_apply_affine_bwd<kAffCapB>, dim3(tiles_x * tiles_y, nslab, B), dim3(kBlock), 0, as_stream(stream),
                        G, theta, theta_inv, table, R, idx, idx2, idx_bstride, B, S, H, W, tiles_x, s_per_slab,
-                       make_norm(norm), slabs);
+                       make_norm(norm), slabs, g_aff_gather);
   return launch_status();
 }
 

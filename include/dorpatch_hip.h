@@ -56,10 +56,13 @@ const char *dp_error_string(int err);
  *                                      kernel applies (0: 16-byte lanes whenever W % 4 == 0 and pointers are aligned)
  *   DP_DEBUG_APPLY_ORDER               dp_apply_fwd grid walk: 1 = XCD-aware (a tile's samples adjacent on one XCD: 10 %
  *                                      less HBM traffic, measured 19 % slower); 0: tile-fastest 3-D grid (one ascending
- *                                      output stream) */
+ *                                      output stream)
+ *   DP_DEBUG_AFFINE_GATHER             dp_apply_affine_bwd: 1 = the round-3 gather loop (a branch per candidate); 0: the
+ *                                      branch-free loop (same candidates, same order, same bits) */
 #define DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK 1
 #define DP_DEBUG_UPDATE_VARIANT 2
 #define DP_DEBUG_APPLY_ORDER 3
+#define DP_DEBUG_AFFINE_GATHER 4
 int dp_debug_set(int knob, int value);
 
 /* ---- a-2  utils.clip (utils.py:105-110) + adv_x = delta + x (attack.py:184-185) ---- */

@@ -118,6 +118,32 @@ def test_forward_is_bit_identical_for_any_number_of_samples_per_workgroup(B, S, 
         assert torch.equal(outs[spb], outs[1]), spb
 
 
+@pytest.mark.parametrize("B,S,H,affine", [(2, 5, 56, (10.0, (0.9, 1.1), 8.0)), (2, 5, 56, (25.0, (0.7, 1.3), 6.0)),
+                                          (1, 6, 96, (30.0, (0.45, 0.6), 3.0)), (1, 4, 224, (10.0, (0.9, 1.1), 8.0))])
+def test_backward_gather_variants_are_bit_identical(B, S, H, affine):
+    """dp_apply_affine_bwd's branch-free gather (round 4: a row's records, weights and gradients requested back to back,
+    folded in with selects) against the round-3 loop it replaces (DP_DEBUG_AFFINE_GATHER = 1: one branch per candidate):
+    the same candidates in the same order, so the same bits — default placement range, the wide range (windows of up to
+    4 x 4 half-widths -> more than one column group per row), small scales (regions that go to the per-pixel path) and
+    the full 224 x 224 plane with two mask sets."""
+    from dorpatch_amd._lib import DP_DEBUG_AFFINE_GATHER as KNOB
+    x, delta, table_np, idx_np, idx2_np, theta = _setup(B, S, H, seed=31, dual=True, affine=affine)
+    table = ops.upload_table(table_np, DEV)
+    idx, idx2 = torch.from_numpy(idx_np).int().to(DEV), torch.from_numpy(idx2_np).int().to(DEV)
+    th, thi = torch.from_numpy(theta).to(DEV), torch.from_numpy(PL.invert(theta)).to(DEV)
+    G = torch.randn(B * S, 3, H, H, generator=torch.Generator().manual_seed(9)).to(DEV)
+    norm = ops.make_norm(*NORM, 0.5)
+    outs = []
+    try:
+        for variant in (1, 0):
+            ops.debug_set(KNOB, variant)
+            outs.append(ops.apply_affine_bwd(G, th, thi, table, idx, idx2, norm, B=B).cpu())
+    finally:
+        ops.debug_set(KNOB, 0)
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+    assert outs[0].abs().max() > 0
+
+
 def test_full_size_launch_adjoint_and_walk_invariance():
     """The benchmark's own launch — 64 images x 32 samples at 224^2, default placement range, PatchCleanser double masks:
     the launcher's choice (8 samples per forward workgroup) is bit-identical to a walk of 1; <A d, G> == <d, A^T G> in
