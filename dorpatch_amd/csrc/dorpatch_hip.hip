@@ -921,7 +921,7 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
           acc[1][2] += wgt * g2;
         }
       };
-      if (g_dev_gather == 1) {   // round-3 gather (A/B, DP_DEBUG_AFFINE_GATHER = 1): a branch per candidate
+      if (g_dev_gather == 0) {   // the shipped gather: a branch per candidate
       // A row of the window is <= 2 kx + 2 records (6 for the default placement range): its first 6 records are read
       // back to back before any is tested (one LDS round trip per row instead of one per candidate — the gather spent
       // its time waiting on them); order of accumulation unchanged: rows ascending, records ascending.
@@ -937,14 +937,16 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
         for (int e = e0 + kRowAhead; e <= e1; ++e) candidate(e, stap[e]);
       }
       } else {
-      // Round 4: the same candidates in the same order, BRANCH-FREE.  The round-3 loop was latency-bound (SQ counters:
-      // VALU active 26 %, waves parked 44 %): every candidate was a data-dependent branch around five dependent LDS reads,
-      // and since some lane of the wave hits at almost every window position the wave executed nearly all of them anyway,
-      // one round trip at a time.  Here a row's 6 records AND their weights / gradients (36 dwords) are requested back to
-      // back, unconditionally, then tested and folded in with selects: two LDS round trips per row instead of ~7, no
-      // branches.  Trip counts are block-uniform (2 ky + 1 rows, ceil((2 kx + 2) / 6) column groups); a slot outside the
-      // thread's own window reads a clamped (valid) address and is discarded by its select.  acc = hit ? acc + w g : acc
-      // keeps every bit of the round-3 result (a non-hit leaves the accumulator untouched, not acc + 0).
+      // A/B variant (DP_DEBUG_AFFINE_GATHER = 1; round 4, measured and NOT kept): the same candidates in the same order,
+      // BRANCH-FREE.  Hypothesis: the loop above is latency-bound (SQ counters: VALU active 26 %, waves parked 44 %) — every
+      // candidate is a data-dependent branch around five dependent LDS reads — so request a row's 6 records AND their
+      // weights / gradients (36 dwords) back to back, unconditionally, and fold them in with selects: two LDS round trips per
+      // row instead of ~7, no branches, block-uniform trip counts (2 ky + 1 rows, ceil((2 kx + 2) / 6) column groups), a
+      // slot outside the thread's own window reads a clamped address and is discarded; acc = hit ? acc + w g : acc keeps
+      // every bit.  Result (64 x 32 x 224^2, profiles/r04d_kbench_affine.txt): 1.58 ms against 1.18 — waves parked 44 -> 27 %,
+      // but VALU active 26 -> 35 % of a longer run: three of four (pixel, candidate) pairs are misses, and the branchy loop
+      // skips their weight / accumulate arithmetic while this one executes it.  The gather form's cost is the 3:1 ratio
+      // of tested to hit candidates, not its round trips.
       constexpr int kCols = 6;
       const int nrow = (cqx0 <= cqx1) ? (cqy1 - cqy0 + 1) : 0, ncol = cqx1 - cqx0 + 1;
       const int rows_max = 2 * ky + 1, cols_max = 2 * kx + 2;

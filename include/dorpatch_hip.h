@@ -57,8 +57,8 @@ const char *dp_error_string(int err);
  *   DP_DEBUG_APPLY_ORDER               dp_apply_fwd grid walk: 1 = XCD-aware (a tile's samples adjacent on one XCD: 10 %
  *                                      less HBM traffic, measured 19 % slower); 0: tile-fastest 3-D grid (one ascending
  *                                      output stream)
- *   DP_DEBUG_AFFINE_GATHER             dp_apply_affine_bwd: 1 = the round-3 gather loop (a branch per candidate); 0: the
- *                                      branch-free loop (same candidates, same order, same bits) */
+ *   DP_DEBUG_AFFINE_GATHER             dp_apply_affine_bwd: 1 = branch-free gather loop (same candidates, same order, same
+ *                                      bits; measured 34 % slower); 0: a branch per candidate */
 #define DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK 1
 #define DP_DEBUG_UPDATE_VARIANT 2
 #define DP_DEBUG_APPLY_ORDER 3

@@ -121,9 +121,9 @@ def test_forward_is_bit_identical_for_any_number_of_samples_per_workgroup(B, S, 
 @pytest.mark.parametrize("B,S,H,affine", [(2, 5, 56, (10.0, (0.9, 1.1), 8.0)), (2, 5, 56, (25.0, (0.7, 1.3), 6.0)),
                                           (1, 6, 96, (30.0, (0.45, 0.6), 3.0)), (1, 4, 224, (10.0, (0.9, 1.1), 8.0))])
 def test_backward_gather_variants_are_bit_identical(B, S, H, affine):
-    """dp_apply_affine_bwd's branch-free gather (round 4: a row's records, weights and gradients requested back to back,
-    folded in with selects) against the round-3 loop it replaces (DP_DEBUG_AFFINE_GATHER = 1: one branch per candidate):
-    the same candidates in the same order, so the same bits — default placement range, the wide range (windows of up to
+    """dp_apply_affine_bwd's gather (one branch per candidate) against the branch-free A/B variant (DP_DEBUG_AFFINE_GATHER
+    = 1: a row's records, weights and gradients requested back to back, folded in with selects — measured slower, kept
+    as evidence): the same candidates in the same order, so the same bits — default placement range, the wide range (windows of up to
     4 x 4 half-widths -> more than one column group per row), small scales (regions that go to the per-pixel path) and
     the full 224 x 224 plane with two mask sets."""
     from dorpatch_amd._lib import DP_DEBUG_AFFINE_GATHER as KNOB

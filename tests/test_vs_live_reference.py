@@ -184,6 +184,51 @@ def test_patchcleanser_sweep_against_the_live_reference(ref):
     assert len(branches) >= 3, branches
 
 
+class _HalfSums(torch.nn.Module):
+    """A classifier whose one-mask predictions TIE 18 : 18: class 3's logit is the sum over the left half of the image,
+    class 7's the sum over the right half (everything else far below).  On an all-zero image the only non-zero pixels are
+    the 0.5-filled occlusion window, so a first-round mask votes for the side it mostly covers — windows in columns 0-2 of
+    the 6 x 6 grid say 3, columns 3-5 say 7."""
+
+    def forward(self, x):
+        half = x.shape[-1] // 2
+        out = torch.full((x.shape[0], 10), -1e3, dtype=x.dtype, device=x.device)
+        out[:, 3] = x[..., :half].sum((1, 2, 3))
+        out[:, 7] = x[..., half:].sum((1, 2, 3))
+        return out
+
+
+def test_patchcleanser_majority_vote_on_a_count_tie(ref):
+    """defenses/PatchCleanser.py:74-75: ``labels, counts = preds_1.unique(sorted=False, return_counts=True);
+    label_majority = labels[counts.argmax()]`` — on a count tie the first of the tied labels IN THE ORDER ``unique``
+    RETURNS THEM wins.  The product takes the smallest tied label (np.unique, ascending: what torch's GPU ``unique``
+    returns whatever ``sorted`` says, and what this torch's CPU ``unique`` returns too — checked here, so a torch whose
+    ``sorted=False`` order changes fails this test instead of silently changing the metric).  The recorded fixture holds
+    no tie; this one is an exact 18 : 18 split, run through the unmodified reference and the product."""
+    from tests_hipemu import patch as emu_patch
+    if emu_patch.build_emu.host_compiler() is None:
+        pytest.skip("no host clang++ for the HIP emulation build")
+    from dorpatch_amd.patchcleanser import MaskWindow, PatchCleanser
+    H, net = 56, _HalfSums()
+    img = torch.zeros(3, H, H)
+    with emu_patch.emulated_ops(), torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        for r in (0.03, 0.06):
+            pc_ref = ref.PatchCleanser.PatchCleanser(ref.PatchCleanser.MaskWindow(H, r, 1), net)
+            pc = PatchCleanser(MaskWindow(H, r, 1, device="cpu"), net)
+            for certify in (True, False):
+                want, got = pc_ref.robust_predict(img, certify), pc.robust_predict(img, certify)
+                labels, counts = np.unique(want.preds_1, return_counts=True)
+                assert labels.tolist() == [3, 7] and counts.tolist() == [18, 18], (r, labels, counts)     # the tie
+                assert int(want.prediction) == 3                       # the reference resolves it to the smaller label
+                assert got.prediction == int(want.prediction) and bool(got.certification) == bool(want.certification)
+                assert np.array_equal(got.preds_1, want.preds_1)
+                assert (got.preds_2 is None) == (want.preds_2 is None)
+                if want.preds_2 is not None:
+                    assert np.array_equal(got.preds_2, want.preds_2)
+    l, c = torch.tensor([7, 3, 7, 3]).unique(sorted=False, return_counts=True)
+    assert l.tolist() == [3, 7] and c.tolist() == [2, 2]               # the order the product's np.unique assumes
+
+
 @pytest.mark.parametrize("hyper", [dict(eps=1.0, confidence=0.5, density=5e-3, structured=5e-3, patch_budget=0.06),
                                    dict(eps=8.0, confidence=0.0, density=1e-2, structured=1e-4, patch_budget=0.0204, lr=0.05)])
 def test_hot_loop_steps_under_other_hyper_parameters(ref, hyper):

@@ -476,7 +476,7 @@ int main(int argc, char **argv) {
       if (nslab > 1) DP(dp_sum_slabs(slabs, nslab, (int64_t)B * 3 * P, g_adv, 0, st));
     });
     g_aff_gather = 1;
-    bench("dp_apply_affine_bwd, round-3 gather loop (A/B)", out_bytes + (double)B * img, iters, st, [&] {
+    bench("dp_apply_affine_bwd, branch-free gather (A/B)", out_bytes + (double)B * img, iters, st, [&] {
       DP(dp_apply_affine_bwd(big2, d_th, d_thi, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, nslab == 1 ? g_adv : slabs, st));
       if (nslab > 1) DP(dp_sum_slabs(slabs, nslab, (int64_t)B * 3 * P, g_adv, 0, st));
     });
