@@ -3151,17 +3151,36 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3_mfma(const float *__restr
   for (int chunk = 0; chunk < NCH; ++chunk) {
     if (chunk + 1 < NCH) fetch(chunk + 1);
     const float *cur = lds + (chunk & 1) * kCvBuf;
-#pragma unroll
-    for (int t = 0; t < kCvSteps; ++t) {
+    // Explicit software pipeline over the k-steps: the 8 operands of step t + 1 are requested BEFORE the 7 MFMAs of step t
+    // (448 cycles of matrix pipe: more than an LDS round trip), and scheduling barriers keep the compiler from undoing it.
+    // Left to itself hipcc hoisted whole groups of steps' reads until all 256 VGPRs were taken and then had to issue
+    // read -> s_waitcnt lgkmcnt(0) -> MFMA back to back at the group seams: SQ counters 78 % MFMA-busy, 19 % of wave
+    // cycles parked (profiles/r04c_sq_counters_conv3x3.txt).
+    auto operands = [&](int t, float &a, float (&bv)[7]) {
       const int cp = t / 9, kh = (t % 9) / 3, kw = t % 3;
-      const float a = cur[abase + t * 2 * kCvO];
       const int koff = cp * 2 * kCvChStride + kh * kCvPitch + kw;
+      a = cur[abase + t * 2 * kCvO];
 #pragma unroll
-      for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, cur[boff[q] + koff], acc[q], 0, 0, 0);
+      for (int q = 0; q < 7; ++q) bv[q] = cur[boff[q] + koff];
+    };
+    float a0, b0[7], a1, b1[7];
+    operands(0, a0, b0);
+#pragma unroll
+    for (int t = 0; t < kCvSteps; t += 2) {
+      operands(t + 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[q], acc[q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
       // the next chunk goes to the OTHER buffer (nobody reads it during this chunk) half-way through: its global loads
       // have landed by then, the LDS stores hide behind the remaining MFMAs, and every wave reaches the barrier with
       // nothing left to do but its last MFMAs
       if (t == kCvSteps / 2 && chunk + 1 < NCH) stash((chunk + 1) & 1);
+      if (t + 2 < kCvSteps) operands(t + 2, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[q], acc[q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }

@@ -49,7 +49,8 @@ def test_apply_fwd_exact(H, dropout, normalize):
     rng = np.random.RandomState(H + dropout)
     idx = rng.randint(0, table_np.shape[0], size=(B, S))
     adv = _rand(B, 3, H, H, seed=4)
-    keep = masks.rects_to_bool(table_np, H)
+    keep = R.mask_universe(H, dropout)        # the ORACLE's bool masks (a restatement of PatchCleanser.py:6-59, pinned to the
+    assert torch.equal(keep, masks.rects_to_bool(table_np, H))      # reference by geometry.npz), not the product's own
     norm = ops.make_norm([0.5] * 3, [0.5] * 3, 0.5) if normalize else ops.RAW_NORM
     out = ops.apply_fwd(adv.to(DEV), table, torch.from_numpy(idx).int().to(DEV), None, norm).cpu()
     out = out.view(B, S, 3, H, H)
