@@ -88,6 +88,10 @@ def parse(argv=None):
                     help="library route of the backbone's frozen 1x1/1 convolutions: the committed per-shape gfx950 "
                          "table (deterministic, default), measured per shape at first use (auto), always the batched "
                          "GEMM, or always MIOpen (dorpatch_amd/conv1x1.py)")
+    ap.add_argument("--conv3x3", default=None, choices=["table", "on", "off"],
+                    help="route of the backbone's stride-1 3x3 convolutions: the committed per-shape table (default: "
+                         "dp_conv3x3_fwd, the hand-written fp32-MFMA implicit GEMM, where it measured faster than MIOpen's "
+                         "Winograd), every supported shape on dp_conv3x3_fwd, or MIOpen only (dorpatch_amd/libconv.py)")
     ap.add_argument("--deterministic", default="auto", choices=["auto", "on", "off"],
                     help="DorPatch(deterministic=...): auto = verify on the first micro-batch that the library "
                          "convolutions are bit-reproducible and only otherwise force deterministic kernels (default); "
@@ -514,8 +518,10 @@ def main(argv=None):
     if args.no_fused_gn:
         from dorpatch_amd.resnetv2 import GroupNormAct
         GroupNormAct.fused = False
-    from dorpatch_amd import conv1x1
+    from dorpatch_amd import conv1x1, libconv as _libconv
     conv1x1.MODE = args.conv1x1
+    if args.conv3x3 is not None:
+        _libconv.CONV3X3 = args.conv3x3
     B, H = args.batch, args.size
     if args.scaling == "strong":                 # fixed total: --samples masks per image over all ranks
         S, S_local = args.samples, args.samples // world
@@ -638,6 +644,7 @@ def main(argv=None):
                                     "samples_forward": loop.n_forward, "samples_with_gradient": loop.n_active,
                                     "samples_back_propagated": loop.n_backward, "tape_micro_batches": loop._tape_tabs,
                                     "step_ms": step_ms, "samples_with_gradient_each_step": active_each},
+                       "conv3x3": libconv.report_conv3x3(),
                        "conv1x1": dict(mode=args.conv1x1, gemm_solutions=conv1x1.report_tuned(),
                                        tuned_selftest=conv1x1.selftest_report(), **conv1x1.report()),
                        "parallelism": "eot-sample sharding x%d, 1 all-reduce per step (patch gradient + loss slabs)%s"

@@ -3044,70 +3044,93 @@ int launch_apply_fwd(int variant, const float *adv_x, const int32_t *table, int 
 
 
 // ----------------------------------------------------------------------------
-// a-8 candidate (round 4): the backbone's 3 x 3 / stride 1 / pad 1 convolutions on the matrix cores.
-// MIOpen runs them as fp32 Winograd on the VALUs (64 -> 64 @56^2, N = 512: 1.04 ms = 113 TFLOP/s effective); this is
+// a-8 (round 4): the backbone's 3 x 3 / stride 1 / pad 1 convolutions on the matrix cores.
+// MIOpen runs them as fp32 Winograd on the VALUs (64 -> 64 @56^2, N = 512: 1.09 ms = 108 TFLOP/s effective); this is
 // the direct implicit GEMM on v_mfma_f32_32x32x2_f32 (exact f32, an fmaf chain over K — no Winograd rounding):
 //     D[oc][pixel] += sum_k  A[oc][k] * B[k][pixel],     k = (input channel, kh, kw),  K = 9 C
 //   A (weights)  lane l holds A[i = l & 31][k = l >> 5];   B (pixels)  lane l holds B[k = l >> 5][j = l & 31];
 //   D            lane l, register v:  oc = (v & 3) + 8 (v >> 2) + 4 (l >> 5),  pixel = l & 31
 // so a store instruction writes 2 output-channel rows x 32 consecutive pixels (128 B runs).
-// Workgroup = 8 output rows of one image (448 pixels = 14 fragments) x all 64 output channels; wave w owns channel
-// fragment w & 1 and the 7 pixel fragments (w >> 1) + 2 q: 7 accumulators of 16 VGPRs, 8 LDS reads per 7 MFMAs.
-// K walks in chunks of 8 input channels: the chunk's 10 input rows (zero halo; pitch 64 floats, column 0 at [4] so global
-// float4s land on aligned LDS float4s) and its pre-packed weights wt[chunk][t = (channel pair, kh, kw)][half][oc]
-// (dp_conv3x3 host packing; frozen weights: packed once) are double-buffered in LDS — the loads of chunk i + 1 are in
-// flight during the 252 MFMAs of chunk i, one barrier per chunk.  A k-step pairs channels (2 cp, 2 cp + 1) of the same tap:
-// the lane's half selects the channel, so every LDS address is lane base + compile-time immediate.
-// LDS 2 x 38.9 KB -> 2 workgroups per CU = 2 waves per SIMD (enough to keep the 64-cycle MFMA pipe fed).
+// Workgroup = 448 consecutive pixels of the batch (n, h, w in row-major order: 8 rows of a 56 x 56 plane, 16 rows of
+// 28 x 28, 2.3 planes of 14 x 14, 9.1 planes of 7 x 7 — a tile may span images) x 64 output channels (grid.y = O / 64);
+// wave w owns channel fragment w & 1 and the 7 pixel fragments (w >> 1) + 2 q: 7 accumulators of 16 VGPRs.
+// K walks in chunks of 8 input channels.  The chunk's input rows go to LDS as a stack of rows with a zero row between
+// images and above / below the tile ("virtual row" n (S + 1) + h: the zero row is the bottom padding of image n AND the top
+// padding of image n + 1), zero columns left and right (pitch >= S + 2, column 0 at X0 so that global vectors land on
+// aligned LDS vectors: float4 for S = 56 / 28, float2 for 14, scalars for 7), so every tap of every pixel is
+// lane base + compile-time immediate; the chunk's pre-packed weights wt[oc group][chunk][t = (channel pair, kh, kw)][half][oc]
+// (frozen: packed once by the host) follow.  Both are double-buffered: the loads of chunk i + 1 are in flight during the
+// 252 MFMAs of chunk i and are stored to the other buffer half-way through them, one barrier per chunk.  A k-step pairs
+// channels (2 cp, 2 cp + 1) of the same tap: the lane's half selects the channel.
+// LDS <= 2 x 40.3 KB -> 2 workgroups per CU = 2 waves per SIMD.
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-constexpr int kCvH = 56, kCvW = 56, kCvO = 64;
-constexpr int kCvRows = 8;                              // output rows per workgroup
-constexpr int kCvFrags = kCvRows * kCvW / 32;           // 14 pixel fragments
-constexpr int kCvPitch = 64, kCvX0 = 4;
-constexpr int kCvCh = 8;                                // input channels per K-chunk
-constexpr int kCvSteps = kCvCh / 2 * 9;                 // 36 MFMA k-steps per chunk
-constexpr int kCvInRows = kCvRows + 2;
-constexpr int kCvChStride = kCvInRows * kCvPitch;       // 640
-constexpr int kCvInFloats = kCvCh * kCvChStride;        // 5120
-constexpr int kCvWtFloats = kCvSteps * 2 * kCvO;        // 4608
-constexpr int kCvBuf = kCvInFloats + kCvWtFloats;       // 9728 floats = 38 912 B
-constexpr int kCvInF4 = kCvCh * kCvInRows * (kCvW / 4); // 1120 float4 per chunk
-constexpr int kCvWtF4 = kCvWtFloats / 4;                // 1152
-constexpr int kCvInIt = (kCvInF4 + kBlock - 1) / kBlock, kCvWtIt = (kCvWtF4 + kBlock - 1) / kBlock;   // 5, 5
+constexpr int kCvO = 64;                               // output channels per workgroup
+constexpr int kCvPix = 448, kCvFrags = kCvPix / 32;    // pixels per workgroup (14 fragments)
+constexpr int kCvCh = 8;                               // input channels per K-chunk
+constexpr int kCvSteps = kCvCh / 2 * 9;                // 36 MFMA k-steps per chunk
+constexpr int kCvWtFloats = kCvSteps * 2 * kCvO;       // 4608 floats per (oc group, chunk)
+constexpr int kCvWtF4 = kCvWtFloats / 4, kCvWtIt = (kCvWtF4 + kBlock - 1) / kBlock;
 
-template <int C>
+template <int S>
+struct CvGeom {
+  static constexpr int VW = (S % 4 == 0) ? 4 : (S % 2 == 0) ? 2 : 1;      // floats per staging load
+  static constexpr int X0 = VW;                                            // LDS column of image column 0
+  static constexpr int PITCH = ((S + X0 + 1 + VW - 1) / VW) * VW;         // 64 / 36 / 18 / 9
+  // rows of a tile (448 / S: tiles start at row starts since 448 % S == 0) + one zero row per image boundary it can cross
+  // + the rows above and below: 8 + 0 + 2 (56 % 8 == 0: never crosses) / 16 + 1 + 2 / 32 + 3 + 2 / 64 + 10 + 2
+  static constexpr int ROWS = S == 56 ? 10 : S == 28 ? 19 : S == 14 ? 37 : 76;
+  static constexpr int CHS = ROWS * PITCH;                                 // floats per channel
+  static constexpr int IN = kCvCh * CHS;                                   // floats per chunk
+  static constexpr int BUF = IN + kCvWtFloats;
+  static constexpr int VPR = S / VW;                                       // staging vectors per row
+  static constexpr int NV = kCvCh * ROWS * VPR, IT = (NV + kBlock - 1) / kBlock;
+};
+
+template <int VW> struct CvVec;
+template <> struct CvVec<4> { typedef f4 T; };
+template <> struct CvVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <> struct CvVec<1> { typedef float T; };
+
+template <int S>
 __global__ __launch_bounds__(kBlock, 2) void k_conv3x3_mfma(const float *__restrict__ x, const float *__restrict__ wt,
-                                                            float *__restrict__ y) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * kCvBuf];
-  constexpr int NCH = C / kCvCh;
-  constexpr int P = kCvH * kCvW;
-  const int n = blockIdx.y, r0 = blockIdx.x * kCvRows;
+                                                            float *__restrict__ y, int N, int C, int O) {
+  typedef CvGeom<S> G;
+  typedef typename CvVec<G::VW>::T vec_t;
+  __shared__ __attribute__((aligned(16))) float lds[2 * G::BUF];
+  constexpr int HW = S * S;
+  const int NCH = C / kCvCh;
+  const int total = N * HW;                                  // < 2^31 (checked by the launcher)
+  const int g0 = blockIdx.x * kCvPix;                        // first pixel of the tile (batch-linear)
+  const int n0 = g0 / HW, h0 = (g0 - n0 * HW) / S;
+  const int vr0 = n0 * (S + 1) + h0 - 1;                     // virtual row of LDS row 0 (the zero / halo row above the tile)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l32 = lane & 31;
   const int ocf = wave & 1, pf0 = wave >> 1;
-  const float *xn = x + (size_t)n * C * P;
+  const float *wtg = wt + (size_t)blockIdx.y * NCH * kCvWtFloats;
 
-  // halo columns (never written again) of both buffers
-  for (int i = tid; i < 2 * kCvCh * kCvInRows * 2; i += kBlock) {
-    const int buf = i / (kCvCh * kCvInRows * 2), r = i - buf * (kCvCh * kCvInRows * 2);
-    lds[buf * kCvBuf + (r >> 1) * kCvPitch + ((r & 1) ? (kCvX0 + kCvW) : (kCvX0 - 1))] = 0.f;
+  // zero columns (never written again) of both buffers: [X0 - 1] and [X0 + S] of every row
+  for (int i = tid; i < 2 * kCvCh * G::ROWS * 2; i += kBlock) {
+    const int buf = i / (kCvCh * G::ROWS * 2), r = i - buf * (kCvCh * G::ROWS * 2);
+    lds[buf * G::BUF + (r >> 1) * G::PITCH + ((r & 1) ? (G::X0 + S) : (G::X0 - 1))] = 0.f;
   }
 
-  f4 pin[kCvInIt], pwt[kCvWtIt];
+  vec_t pin[G::IT];
+  f4 pwt[kCvWtIt];
   auto fetch = [&](int chunk) {          // global -> registers
 #pragma unroll
-    for (int it = 0; it < kCvInIt; ++it) {
+    for (int it = 0; it < G::IT; ++it) {
       const int i = tid + it * kBlock;
-      const int ch = i / (kCvInRows * (kCvW / 4)), rem = i - ch * (kCvInRows * (kCvW / 4));
-      const int row = rem / (kCvW / 4), q4 = rem - row * (kCvW / 4);
-      const int gr = r0 - 1 + row;
-      f4 v = {0.f, 0.f, 0.f, 0.f};
-      if (i < kCvInF4 && gr >= 0 && gr < kCvH)
-        v = *reinterpret_cast<const f4 *>(xn + ((size_t)(chunk * kCvCh + ch) * kCvH + gr) * kCvW + 4 * q4);
+      const int ch = i / (G::ROWS * G::VPR), rem = i - ch * (G::ROWS * G::VPR);
+      const int row = rem / G::VPR, q = rem - row * G::VPR;
+      const int vr = vr0 + row;
+      const int n = vr / (S + 1), h = vr - n * (S + 1);
+      vec_t v = {};
+      if (i < G::NV && vr >= 0 && h < S && n < N)
+        v = *reinterpret_cast<const vec_t *>(x + (((size_t)n * C + chunk * kCvCh + ch) * S + h) * S + q * G::VW);
       pin[it] = v;
     }
-    const f4 *wsrc = reinterpret_cast<const f4 *>(wt + (size_t)chunk * kCvWtFloats);
+    const f4 *wsrc = reinterpret_cast<const f4 *>(wtg + (size_t)chunk * kCvWtFloats);
 #pragma unroll
     for (int it = 0; it < kCvWtIt; ++it) {
       const int i = tid + it * kBlock;
@@ -3115,29 +3138,32 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3_mfma(const float *__restr
     }
   };
   auto stash = [&](int buf) {            // registers -> LDS
-    float *dst = lds + buf * kCvBuf;
+    float *dst = lds + buf * G::BUF;
 #pragma unroll
-    for (int it = 0; it < kCvInIt; ++it) {
+    for (int it = 0; it < G::IT; ++it) {
       const int i = tid + it * kBlock;
-      const int ch = i / (kCvInRows * (kCvW / 4)), rem = i - ch * (kCvInRows * (kCvW / 4));
-      const int row = rem / (kCvW / 4), q4 = rem - row * (kCvW / 4);
-      if (i < kCvInF4) *reinterpret_cast<f4 *>(dst + ch * kCvChStride + row * kCvPitch + kCvX0 + 4 * q4) = pin[it];
+      const int ch = i / (G::ROWS * G::VPR), rem = i - ch * (G::ROWS * G::VPR);
+      const int row = rem / G::VPR, q = rem - row * G::VPR;
+      if (i < G::NV) *reinterpret_cast<vec_t *>(dst + ch * G::CHS + row * G::PITCH + G::X0 + q * G::VW) = pin[it];
     }
 #pragma unroll
     for (int it = 0; it < kCvWtIt; ++it) {
       const int i = tid + it * kBlock;
-      if (i < kCvWtF4) *reinterpret_cast<f4 *>(dst + kCvInFloats + 4 * i) = pwt[it];
+      if (i < kCvWtF4) *reinterpret_cast<f4 *>(dst + G::IN + 4 * i) = pwt[it];
     }
   };
 
-  // lane bases: A = weights [t][half][oc]; B = pixels of the lane's 7 fragments, channel parity = half
-  const int abase = kCvInFloats + half * kCvO + ocf * 32 + l32;
+  // lane bases: A = weights [t][half][oc]; B = the lane's pixel of each of its 7 fragments, channel parity = half.
+  // A pixel past the end of the batch (last tile only) reads the tile's first pixel and is never stored.
+  const int abase = G::IN + half * kCvO + ocf * 32 + l32;
   int boff[7];
 #pragma unroll
   for (int q = 0; q < 7; ++q) {
-    const int p = (pf0 + 2 * q) * 32 + l32;
-    const int hl = p / kCvW, w = p - hl * kCvW;
-    boff[q] = half * kCvChStride + hl * kCvPitch + w + (kCvX0 - 1);
+    int g = g0 + (pf0 + 2 * q) * 32 + l32;
+    if (g >= total) g = g0;
+    const int n = g / HW, p = g - n * HW;
+    const int h = p / S, w = p - h * S;
+    boff[q] = half * G::CHS + (n * (S + 1) + h - vr0 - 1) * G::PITCH + w + (G::X0 - 1);
   }
   f16v acc[7];
 #pragma unroll
@@ -3150,15 +3176,15 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3_mfma(const float *__restr
   __syncthreads();
   for (int chunk = 0; chunk < NCH; ++chunk) {
     if (chunk + 1 < NCH) fetch(chunk + 1);
-    const float *cur = lds + (chunk & 1) * kCvBuf;
+    const float *cur = lds + (chunk & 1) * G::BUF;
     // Explicit software pipeline over the k-steps: the 8 operands of step t + 1 are requested BEFORE the 7 MFMAs of step t
     // (448 cycles of matrix pipe: more than an LDS round trip), and scheduling barriers keep the compiler from undoing it.
     // Left to itself hipcc hoisted whole groups of steps' reads until all 256 VGPRs were taken and then had to issue
     // read -> s_waitcnt lgkmcnt(0) -> MFMA back to back at the group seams: SQ counters 78 % MFMA-busy, 19 % of wave
-    // cycles parked (profiles/r04c_sq_counters_conv3x3.txt).
+    // cycles parked, 125.7 TFLOP/s; with the pipeline 134.5 (profiles/r04c_ / r04e_sq_counters_conv3x3.txt).
     auto operands = [&](int t, float &a, float (&bv)[7]) {
       const int cp = t / 9, kh = (t % 9) / 3, kw = t % 3;
-      const int koff = cp * 2 * kCvChStride + kh * kCvPitch + kw;
+      const int koff = cp * 2 * G::CHS + kh * G::PITCH + kw;
       a = cur[abase + t * 2 * kCvO];
 #pragma unroll
       for (int q = 0; q < 7; ++q) bv[q] = cur[boff[q] + koff];
@@ -3185,12 +3211,15 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3_mfma(const float *__restr
     __syncthreads();
   }
 
-  float *yn = y + ((size_t)n * kCvO + ocf * 32 + 4 * half) * P + (size_t)r0 * kCvW + l32;
+  const int oc0 = blockIdx.y * kCvO + ocf * 32 + 4 * half;
 #pragma unroll
   for (int q = 0; q < 7; ++q) {
-    float *yq = yn + (pf0 + 2 * q) * 32;
+    const int g = g0 + (pf0 + 2 * q) * 32 + l32;
+    if (g >= total) continue;
+    const int n = g / HW, p = g - n * HW;
+    float *yq = y + ((size_t)n * O + oc0) * HW + p;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) yq[(size_t)((v & 3) + 8 * (v >> 2)) * P] = acc[q][v];
+    for (int v = 0; v < 16; ++v) yq[(size_t)((v & 3) + 8 * (v >> 2)) * HW] = acc[q][v];
   }
 }
 
@@ -3498,10 +3527,16 @@ int dp_project_update(const dp_update_cfg_t *cfg, const float *x, const float *a
 
 int dp_conv3x3_fwd(const float *x, const float *wt, int N, int C, int O, int H, int W, float *y, dp_stream_t stream) {
   DP_REQUIRE(x && wt && y && aligned16(x) && aligned16(wt) && aligned16(y));
-  DP_REQUIRE(N > 0 && N <= 65535 && O == kCvO && H == kCvH && W == kCvW && (C == 64 || C == 16));
-  const dim3 grid(kCvH / kCvRows, N), block(kBlock);
-  if (C == 64) hipLaunchKernelGGL(k_conv3x3_mfma<64>, grid, block, 0, as_stream(stream), x, wt, y);
-  else hipLaunchKernelGGL(k_conv3x3_mfma<16>, grid, block, 0, as_stream(stream), x, wt, y);
+  DP_REQUIRE(N > 0 && C > 0 && C % kCvCh == 0 && O > 0 && O % kCvO == 0 && O / kCvO <= 65535 && H == W);
+  DP_REQUIRE(H == 56 || H == 28 || H == 14 || H == 7);
+  DP_REQUIRE((long)N * H * W + kCvPix < (1L << 31));      // 32-bit pixel arithmetic in the kernel
+  const long tiles = ((long)N * H * W + kCvPix - 1) / kCvPix;
+  const dim3 grid((unsigned)tiles, O / kCvO), block(kBlock);
+  hipStream_t st = as_stream(stream);
+  if (H == 56) hipLaunchKernelGGL(k_conv3x3_mfma<56>, grid, block, 0, st, x, wt, y, N, C, O);
+  else if (H == 28) hipLaunchKernelGGL(k_conv3x3_mfma<28>, grid, block, 0, st, x, wt, y, N, C, O);
+  else if (H == 14) hipLaunchKernelGGL(k_conv3x3_mfma<14>, grid, block, 0, st, x, wt, y, N, C, O);
+  else hipLaunchKernelGGL(k_conv3x3_mfma<7>, grid, block, 0, st, x, wt, y, N, C, O);
   return launch_status();
 }
 

@@ -15,8 +15,19 @@ The reference sets ``cudnn.benchmark = True`` (``utils.py:17``) and is not repro
 
 ``POLICY`` is process-global (a MIOpen property of the box, not of a run); ``merge_across(pg)`` ORs it over the ranks of
 a process group so every replica forces the same problems.
+
+**The stride-1 3x3 convolutions** (round 4).  MIOpen runs them as fp32 Winograd on the VALUs (108 TFLOP/s effective at
+64 -> 64 @56^2, N = 512); ``dp_conv3x3_fwd`` — a direct implicit GEMM on the fp32 matrix cores, hand-written in
+``csrc/dorpatch_hip.hip`` — runs the same convolution and, on transposed + flipped weights, its input gradient.  It is
+exact f32 (an fmaf chain in a fixed order: deterministic by construction, so it never needs the probe above) and is used
+for the (direction, channels, plane) problems the committed table ``conv3x3_gfx950.json`` lists as faster at the batch in
+question (measured once on an MI355X by ``scripts/conv3x3_vs_miopen.py``; ``CONV3X3`` / the environment variable
+``DORPATCH_CONV3X3`` = ``table`` (default) | ``on`` (every supported shape) | ``off`` (MIOpen)).  The packed weights
+(one reshuffle per frozen filter and direction) are cached on the weight tensor itself.
 """
 import contextlib
+import json
+import os
 
 import torch
 import torch.nn.functional as F
@@ -24,6 +35,61 @@ import torch.nn.functional as F
 MODE = "off"        # "off": call the library as is;  "auto": probe each new problem once, force the non-reproducible ones
 POLICY = {}         # (direction, N, C, O, k, stride, H, W) -> True (force deterministic kernels) | False (reproducible as is)
 PROBE_RUNS = 3
+
+CONV3X3 = os.environ.get("DORPATCH_CONV3X3", "table")
+if CONV3X3 not in ("table", "on", "off"):
+    raise ValueError("DORPATCH_CONV3X3 must be table, on or off, got %r" % CONV3X3)
+_HERE = os.path.dirname(os.path.abspath(__file__))
+try:
+    with open(os.path.join(_HERE, "conv3x3_gfx950.json")) as _f:
+        _doc3 = json.load(_f)
+    CONV3X3_TABLE = {int(n): {tuple([k.split(":")[0]] + [int(v) for v in k.split(":")[1:]]): v for k, v in t.items()}
+                     for n, t in _doc3["routes"].items()}
+except (OSError, ValueError, KeyError):
+    CONV3X3_TABLE = {}
+_used3 = {}          # (direction, route) -> set of (N, C, S) routed (report_conv3x3())
+
+
+def _conv3x3_route(direction, x, w, stride, padding):
+    """True: run this stride-1 3x3 problem on dp_conv3x3_fwd.  ``x`` = the tensor the kernel would read (the input, or dy)."""
+    if CONV3X3 == "off":
+        return False
+    from . import ops
+    if not ops.conv3x3_supported(x, w if direction == "fwd" else w.transpose(0, 1), stride, padding):
+        return False
+    N, C, S = int(x.shape[0]), int(w.shape[1]), int(x.shape[2])
+    if CONV3X3 == "on":
+        use = True
+    else:       # the column of the largest measured batch <= N; smaller batches than any measured: MIOpen
+        cols = [n for n in sorted(CONV3X3_TABLE) if n <= N]
+        use = bool(cols) and CONV3X3_TABLE[cols[-1]].get((direction, C, S)) == "mfma"
+    _used3.setdefault((direction, "mfma" if use else "miopen"), set()).add((N, C, S))
+    return use
+
+
+def _packed3(w, transpose):
+    """pack_conv3x3_weights(w[, transposed + flipped]) cached on the weight tensor (dies with it; invalidated by an in-place
+    update or a move to another device)."""
+    from . import ops
+    key = (bool(transpose), w._version, w.data_ptr(), str(w.device))
+    cache = getattr(w, "_dp_conv3x3_pack", None)
+    if cache is None or cache[0] != key[1:]:
+        cache = (key[1:], {})
+        try:
+            w._dp_conv3x3_pack = cache
+        except AttributeError:      # a tensor type that refuses attributes: pack every time
+            pass
+    if key[0] not in cache[1]:
+        cache[1][key[0]] = ops.pack_conv3x3_weights(w, transpose=transpose)
+    return cache[1][key[0]]
+
+
+def report_conv3x3():
+    """{"mode", "fwd": {"mfma": n, "miopen": m}, "bwd": {...}}: distinct (batch, channels, plane) problems per route."""
+    out = {"mode": CONV3X3}
+    for d in ("fwd", "bwd"):
+        out[d] = {r: len(_used3.get((d, r), ())) for r in ("mfma", "miopen")}
+    return out
 
 
 @contextlib.contextmanager
@@ -60,6 +126,9 @@ def _key(direction, n, w, stride, hw_in, padding=(0, 0)):
 
 def conv_fwd(x, w, stride=(1, 1), padding=(0, 0)):
     """``F.conv2d(x, w, None, stride, padding)`` for a frozen filter."""
+    if w.shape[2] == 3 and _conv3x3_route("fwd", x, w, stride, padding):
+        from . import ops
+        return ops.conv3x3_fwd(x, _packed3(w, False))
     if MODE != "auto":
         return F.conv2d(x, w, None, stride, padding)
     return guard(_key("fwd", x.shape[0], w, stride, x.shape[2:], padding), lambda: F.conv2d(x, w, None, stride, padding))
@@ -68,6 +137,10 @@ def conv_fwd(x, w, stride=(1, 1), padding=(0, 0)):
 def conv_bwd_data(dy, x_ref, w, stride=(1, 1), padding=(0, 0)):
     """Input gradient of the same convolution — exactly the call autograd makes (``x_ref`` is passed for its shape:
     MIOpen's backward-data never reads it, but ATen wants a dense tensor there)."""
+    if w.shape[2] == 3 and dy.shape[2:] == x_ref.shape[2:] and _conv3x3_route("bwd", dy, w, stride, padding):
+        from . import ops
+        return ops.conv3x3_fwd(dy, _packed3(w, True))
+
     def call():
         return torch.ops.aten.convolution_backward(dy, x_ref, w, None, tuple(stride), tuple(padding), (1, 1), False,
                                                    (0, 0), 1, (True, False, False))[0]

@@ -338,21 +338,38 @@ def project_update(x, adv_x, lv_x, g_adv, scale, structured, pattern, mask, *, s
     return gp, gm
 
 
-# ---------------------------------------------------------------- a-8 candidate: 3x3 convolution on the matrix cores
-def pack_conv3x3_weights(w):
-    """(64, C, 3, 3) frozen weights -> the k-walk order of dp_conv3x3_fwd: [chunk][cp][kh][kw][half][o] with input channel
-    8 chunk + 2 cp + half (include/dorpatch_hip.h).  Plain tensor reshuffle, done once per frozen convolution."""
+# ---------------------------------------------------------------- a-8: 3x3 convolutions on the matrix cores
+CONV3X3_SIDES = (56, 28, 14, 7)
+
+
+def conv3x3_supported(x, weight, stride=(1, 1), padding=(1, 1)):
+    """Shapes dp_conv3x3_fwd takes: fp32 GPU NCHW, 3x3 / stride 1 / pad 1, square planes of side 56 / 28 / 14 / 7,
+    C % 8 == 0, O % 64 == 0 (every stride-1 3x3 convolution of ResNetV2-50 at 224 x 224)."""
+    return (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+            and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
+            and x.shape[2] == x.shape[3] and x.shape[2] in CONV3X3_SIDES and weight.shape[1] == x.shape[1]
+            and weight.shape[1] % 8 == 0 and weight.shape[0] % 64 == 0)
+
+
+def pack_conv3x3_weights(w, transpose=False):
+    """(O, C, 3, 3) frozen weights -> the k-walk order of dp_conv3x3_fwd: [og][chunk][cp][kh][kw][half][o] with output
+    channel 64 og + o and input channel 8 chunk + 2 cp + half (include/dorpatch_hip.h).  ``transpose``: the weights of the
+    INPUT-GRADIENT convolution instead (w'[c][o][kh][kw] = w[o][c][2-kh][2-kw]: dx = conv3x3(dy, w')).  Plain tensor
+    reshuffle, done once per frozen convolution."""
+    w = w.detach().float()
+    if transpose:
+        w = w.flip(2, 3).transpose(0, 1)
     O, C = w.shape[0], w.shape[1]
-    assert w.shape[2:] == (3, 3) and C % 8 == 0
-    return w.detach().float().reshape(O, C // 8, 4, 2, 3, 3).permute(1, 2, 4, 5, 3, 0).contiguous()
+    assert w.shape[2:] == (3, 3) and C % 8 == 0 and O % 64 == 0
+    return w.reshape(O // 64, 64, C // 8, 4, 2, 3, 3).permute(0, 2, 3, 5, 6, 4, 1).contiguous()
 
 
 def conv3x3_fwd(x, wt):
-    """y = conv2d(x, w, stride 1, padding 1) for x (N,C,56,56), wt = pack_conv3x3_weights(w), on v_mfma_f32_32x32x2_f32."""
+    """y = conv2d(x, w, stride 1, padding 1) for x (N,C,S,S), wt = pack_conv3x3_weights(w), on v_mfma_f32_32x32x2_f32."""
     lib = _lib.load()
     _chk(x, torch.float32, "x"), _chk(wt, torch.float32, "wt")
     N, C, H, W = x.shape
-    O = wt.shape[-1]
+    O = wt.shape[0] * wt.shape[-1]
     assert wt.numel() == C * 9 * O
     y = torch.empty((N, O, H, W), dtype=torch.float32, device=x.device)
     _lib.check(lib.dp_conv3x3_fwd(_p(x), _p(wt), N, C, O, H, W, _p(y), _stream()), "dp_conv3x3_fwd")

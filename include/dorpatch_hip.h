@@ -215,13 +215,16 @@ int dp_project_update(const dp_update_cfg_t *cfg, const float *x,
                       float *g_pattern_out, float *g_mask_out,
                       dp_stream_t stream);
 
-/* ---- a-8 candidate: 3x3 / stride 1 / pad 1 convolution of the frozen backbone on the matrix cores ----
- * (attack.py:222 through the classifier; today MIOpen's fp32 Winograd.)  Direct implicit GEMM on
+/* ---- a-8: 3x3 / stride 1 / pad 1 convolutions of the frozen backbone on the matrix cores ----
+ * (attack.py:222, 247 through the classifier; MIOpen runs them as fp32 Winograd on the VALUs.)  Direct implicit GEMM on
  * v_mfma_f32_32x32x2_f32: exact f32, y[n][o] = sum_{c,kh,kw} w[o][c][kh][kw] * x[n][c][.+kh-1][.+kw-1], zero padding.
- * Shapes: O = 64, H = W = 56, C in {16, 64} (C = 16 exists for the CPU-emulation test).  x (N,C,56,56), y (N,64,56,56).
- * wt = the weights PRE-PACKED for the kernel's k-walk (frozen: packed once by the host, dorpatch_amd/ops.py
- * pack_conv3x3_weights): wt[chunk][cp][kh][kw][half][o] = w[o][8 chunk + 2 cp + half][kh][kw], C/8 x 4 x 3 x 3 x 2 x 64.
- * Measured against MIOpen in tools/kbench (go / no-go for routing the backbone's 3x3 convolutions here). */
+ * Shapes: H = W in {56, 28, 14, 7} (the planes of ResNetV2-50 at 224 x 224), C % 8 == 0, O % 64 == 0.
+ * x (N,C,H,W), y (N,O,H,W), dense NCHW.  wt = the weights PRE-PACKED for the kernel's k-walk (frozen: packed once by the
+ * host, dorpatch_amd/ops.py pack_conv3x3_weights):
+ *   wt[og][chunk][cp][kh][kw][half][o] = w[64 og + o][8 chunk + 2 cp + half][kh][kw],   O/64 x C/8 x 4 x 3 x 3 x 2 x 64.
+ * The input gradient of the same convolution is the same entry point on dy with the weights transposed and flipped
+ * (w'[c][o][kh][kw] = w[o][c][2-kh][2-kw]).  Deterministic (fixed summation order: channels ascending, taps row-major).
+ * Measured against MIOpen by scripts/conv3x3_vs_miopen.py; routed per shape by dorpatch_amd/libconv.py. */
 int dp_conv3x3_fwd(const float *x, const float *wt, int N, int C, int O, int H, int W, float *y, dp_stream_t stream);
 
 /* ---- next-1  collect_failure (attack.py:384-406) / PatchCleanser (PatchCleanser.py:68-112) ----

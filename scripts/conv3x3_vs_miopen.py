@@ -1,10 +1,11 @@
 """Go / no-go measurement: dp_conv3x3_fwd (direct implicit GEMM on v_mfma_f32_32x32x2_f32) against
 MIOpen's route for the same convolution, on the GPU box, same process, same tensors.
 
-    python scripts/conv3x3_vs_miopen.py [N]        # default 512 = the headline micro-batch
+    python scripts/conv3x3_vs_miopen.py [N ...]    # default 512 = the headline micro-batch
 
-Prints one JSON line: ms and effective TFLOP/s of both, the max abs difference relative to the output scale, and the same
-for the input gradient (dgrad = the same kernel with flipped / transposed weights)."""
+Prints one JSON line per (batch, shape) — the four stride-1 3x3 convolutions of ResNetV2-50 at 224 x 224: ms and effective
+TFLOP/s of both routes, forward and input gradient (= the same kernel on transposed + flipped weights), and the max abs
+difference relative to the output scale.  The route table dorpatch_amd/conv3x3_gfx950.json is derived from this output."""
 import json
 import os
 import sys
@@ -29,30 +30,38 @@ def timed(fn, iters=10):
     return a.elapsed_time(b) / iters
 
 
-def main():
-    N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-    torch.backends.cudnn.benchmark = False          # the product's setting: MIOpen immediate mode
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(N, 64, 56, 56, generator=g).cuda()
-    w = (torch.randn(64, 64, 3, 3, generator=g) / 24).cuda()
-    wt = ops.pack_conv3x3_weights(w)
-    wt_bwd = ops.pack_conv3x3_weights(w.flip(2, 3).transpose(0, 1).contiguous())     # dgrad as a forward convolution
-    flop = 2.0 * N * 3136 * 64 * 576
+SHAPES = ((64, 56), (128, 28), (256, 14), (512, 7))      # (channels, side) of ResNetV2-50's stride-1 3x3 convolutions @224
+
+
+def one(N, C, S):
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(N, C, S, S, generator=g).cuda()
+    w = (torch.randn(C, C, 3, 3, generator=g) / (3.0 * C ** 0.5)).cuda()
+    wt, wt_bwd = ops.pack_conv3x3_weights(w), ops.pack_conv3x3_weights(w, transpose=True)
+    flop = 2.0 * N * S * S * C * C * 9
     want = F.conv2d(x, w, padding=1)
     got = ops.conv3x3_fwd(x, wt)
     err = float((got - want).abs().max() / want.abs().max())
-    dy = torch.randn(N, 64, 56, 56, generator=g).cuda()
+    dy = torch.randn(N, C, S, S, generator=g).cuda()
     bwd_lib = lambda: torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
                                                           (True, False, False))[0]
     want_b, got_b = bwd_lib(), ops.conv3x3_fwd(dy, wt_bwd)
     err_b = float((got_b - want_b).abs().max() / want_b.abs().max())
     ms = dict(miopen_fwd=timed(lambda: F.conv2d(x, w, padding=1)), mfma_fwd=timed(lambda: ops.conv3x3_fwd(x, wt)),
               miopen_bwd_data=timed(bwd_lib), mfma_bwd_data=timed(lambda: ops.conv3x3_fwd(dy, wt_bwd)))
-    out = dict(shape="N=%d 64->64 3x3/1 @56x56 fp32" % N, gflop=flop / 1e9, ms={k: round(v, 4) for k, v in ms.items()},
-               tflops_effective={k: round(flop / (v * 1e-3) / 1e12, 1) for k, v in ms.items()},
-               max_rel_diff_fwd=err, max_rel_diff_bwd_data=err_b,
-               go_threshold="mfma_fwd >= 130 TFLOP/s effective and logits within 2e-6 (VERDICT r3 item 7)")
-    print(json.dumps(out))
+    return dict(shape="N=%d %d->%d 3x3/1 @%dx%d fp32" % (N, C, C, S, S), gflop=round(flop / 1e9, 2),
+                ms={k: round(v, 4) for k, v in ms.items()},
+                tflops_effective={k: round(flop / (v * 1e-3) / 1e12, 1) for k, v in ms.items()},
+                speedup=dict(fwd=round(ms["miopen_fwd"] / ms["mfma_fwd"], 3), bwd_data=round(ms["miopen_bwd_data"] / ms["mfma_bwd_data"], 3)),
+                max_rel_diff_fwd=err, max_rel_diff_bwd_data=err_b)
+
+
+def main():
+    torch.backends.cudnn.benchmark = False          # the product's setting: MIOpen immediate mode
+    batches = [int(a) for a in sys.argv[1:]] or [512]
+    for N in batches:
+        for C, S in SHAPES:
+            print(json.dumps(one(N, C, S)), flush=True)
 
 
 if __name__ == "__main__":

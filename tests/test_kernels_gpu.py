@@ -357,29 +357,44 @@ def test_debug_knobs_reject_unknown_values():
         ops.debug_set(2, 5)
 
 
-@pytest.mark.parametrize("N,C", [(1, 16), (3, 64)])
-def test_conv3x3_on_the_matrix_cores_matches_conv2d(N, C):
-    """dp_conv3x3_fwd (direct implicit GEMM on v_mfma_f32_32x32x2_f32, candidate for the backbone's 3x3 convolutions)
-    against F.conv2d: exact-f32 arithmetic, another summation order -> 1e-5 of the output scale.  Structured inputs
-    catch layout slips a random tensor would blur: a one-hot weight (each output channel copies ONE shifted input
-    channel: exact equality), an asymmetric ramp image, zero padding at all four borders.  C = 16 is the size the CPU
-    emulation can afford (2 K-chunks: the double buffer is exercised); C = 64 runs on the GPU only."""
-    if C == 64 and DEV == "cpu":
-        pytest.skip("C = 64 through the fibre emulation takes minutes: GPU only")
-    g = torch.Generator().manual_seed(C)
-    x = torch.randn(N, C, 56, 56, generator=g)
-    x[0, :, :, :] += torch.arange(56.0).view(1, 56, 1) * 0.1 + torch.arange(56.0).view(1, 1, 56) * 0.01
-    w = torch.randn(64, C, 3, 3, generator=g) / (3.0 * C ** 0.5)
+CONV3X3_CASES = [   # (N, C, O, S, emulation-sized)
+    (1, 16, 64, 56, True),      # one plane = 7 tiles; 2 K-chunks: the double buffer is exercised
+    (3, 16, 64, 28, True),      # 5.25 tiles: tiles that start mid-plane, cross into the next image, and a ragged last tile
+    (5, 16, 64, 14, True),      # 2.2 tiles of 2.3 planes each (float2 staging)
+    (23, 8, 128, 7, True),      # 2.5 tiles of 9.1 planes each (scalar staging), two output-channel groups, ONE K-chunk
+    (3, 64, 64, 56, False), (5, 128, 128, 28, False), (9, 256, 256, 14, False), (37, 512, 512, 7, False),   # ResNetV2-50's four
+]
+
+
+@pytest.mark.parametrize("N,C,O,S,small", CONV3X3_CASES)
+def test_conv3x3_on_the_matrix_cores_matches_conv2d(N, C, O, S, small):
+    """dp_conv3x3_fwd (direct implicit GEMM on v_mfma_f32_32x32x2_f32: the backbone's 3x3 / 1 convolutions) against
+    F.conv2d, forward and — the same entry point on transposed + flipped weights — input gradient: exact-f32 arithmetic,
+    another summation order -> 1e-5 of the output scale.  Structured inputs catch layout slips a random tensor would blur:
+    one-hot weights (each output channel copies ONE shifted input channel: exact equality, including the zero padding at
+    all four borders of every image and at the seams between the images a tile spans), an asymmetric ramp image.  The
+    small cases are what the CPU emulation can afford; the four real shapes run on the GPU only."""
+    if not small and DEV == "cpu":
+        pytest.skip("full-width shapes through the fibre emulation take minutes: GPU only")
+    g = torch.Generator().manual_seed(C + S)
+    x = torch.randn(N, C, S, S, generator=g)
+    x[0] += torch.arange(float(S)).view(1, S, 1) * 0.1 + torch.arange(float(S)).view(1, 1, S) * 0.01
+    w = torch.randn(O, C, 3, 3, generator=g) / (3.0 * C ** 0.5)
     want = F.conv2d(x, w, padding=1)
     got = ops.conv3x3_fwd(x.to(DEV).contiguous(), ops.pack_conv3x3_weights(w).to(DEV)).cpu()
-    scale = float(want.abs().max())
-    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=1e-5 * scale)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=1e-5 * float(want.abs().max()))
     # one-hot weights: output channel o = input channel (5 o + 3) % C shifted by tap (o % 3, (o // 3) % 3) — exact
-    w1 = torch.zeros(64, C, 3, 3)
-    for o in range(64):
+    w1 = torch.zeros(O, C, 3, 3)
+    for o in range(O):
         w1[o, (5 * o + 3) % C, o % 3, (o // 3) % 3] = 1.0
     got1 = ops.conv3x3_fwd(x.to(DEV).contiguous(), ops.pack_conv3x3_weights(w1).to(DEV)).cpu()
     assert torch.equal(got1, F.conv2d(x, w1, padding=1))
+    if C % 64 == 0:        # input gradient = the same kernel on dy with transposed, flipped weights
+        dy = torch.randn(N, O, S, S, generator=g)
+        want_dx = torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                      (True, False, False))[0]
+        got_dx = ops.conv3x3_fwd(dy.to(DEV).contiguous(), ops.pack_conv3x3_weights(w, transpose=True).to(DEV)).cpu()
+        np.testing.assert_allclose(got_dx.numpy(), want_dx.numpy(), rtol=0, atol=1e-5 * float(want_dx.abs().max()))
 
 
 # ---------------------------------------------------------------- fused GroupNorm + ReLU (backbone, a-8)

@@ -88,3 +88,34 @@ def test_merge_across_ranks_is_an_or(monkeypatch):
     libconv.merge_across(object())
     assert libconv.POLICY == {("fwd", 8, 1, 1, 3, 1, 4, 4): True, ("bwd", 8, 1, 1, 3, 1, 4, 4): True,
                               ("fwd", 4, 1, 1, 3, 1, 4, 4): False}
+
+
+def test_conv3x3_route_table_and_pack_cache(monkeypatch):
+    """The stride-1 3x3 convolutions go to dp_conv3x3_fwd only for the (direction, channels, plane) problems the committed
+    table lists at the largest measured batch <= N; CPU tensors never do (the kernel is GPU-only: no fallback is hidden
+    here, the library call is the other ROUTE of the product).  The packed weights are cached on the weight tensor and
+    rebuilt after an in-place update."""
+    from dorpatch_amd import libconv, ops
+    x, w = torch.randn(2, 64, 56, 56), torch.randn(64, 64, 3, 3)
+    assert libconv._conv3x3_route("fwd", x, w, (1, 1), (1, 1)) is False                  # CPU tensor
+    monkeypatch.setattr(ops, "conv3x3_supported", lambda *a, **k: True)
+    monkeypatch.setattr(libconv, "CONV3X3_TABLE", {128: {("fwd", 64, 56): "mfma"}, 512: {("fwd", 64, 56): "miopen", ("bwd", 64, 56): "mfma"}})
+    monkeypatch.setattr(libconv, "CONV3X3", "table")
+    big, mid, small = torch.empty(512, 64, 56, 56, device="meta"), torch.empty(200, 64, 56, 56, device="meta"), torch.empty(8, 64, 56, 56, device="meta")
+    assert libconv._conv3x3_route("fwd", mid, w, (1, 1), (1, 1)) is True                 # column 128
+    assert libconv._conv3x3_route("fwd", big, w, (1, 1), (1, 1)) is False                # column 512 says miopen
+    assert libconv._conv3x3_route("bwd", big, w, (1, 1), (1, 1)) is True
+    assert libconv._conv3x3_route("fwd", small, w, (1, 1), (1, 1)) is False              # below every measured batch
+    monkeypatch.setattr(libconv, "CONV3X3", "on")
+    assert libconv._conv3x3_route("fwd", small, w, (1, 1), (1, 1)) is True
+    monkeypatch.setattr(libconv, "CONV3X3", "off")
+    assert libconv._conv3x3_route("fwd", mid, w, (1, 1), (1, 1)) is False
+    a = libconv._packed3(w, False)
+    assert libconv._packed3(w, False) is a and libconv._packed3(w, True) is not a
+    assert a.shape == (1, 8, 4, 3, 3, 2, 64) and float(a[0, 2, 1, 0, 2, 1, 5]) == float(w[5, 2 * 8 + 2 + 1, 0, 2])
+    t = libconv._packed3(w, True)                                                        # dgrad weights: transposed + flipped
+    assert float(t[0, 2, 1, 0, 2, 1, 5]) == float(w[2 * 8 + 2 + 1, 5, 2, 0])
+    w.mul_(2.0)
+    b = libconv._packed3(w, False)
+    assert b is not a and torch.equal(b, 2 * a)
+    assert set(libconv.report_conv3x3()) == {"mode", "fwd", "bwd"}

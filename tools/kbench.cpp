@@ -309,28 +309,33 @@ int main(int argc, char **argv) {
   const double out_bytes = (double)N * img;
 
   if (g_filter && strstr(g_filter, "conv3x3")) {
-    // the 64 -> 64 3x3 convolution @56^2 at the training micro-batch (B here = N of the convolution)
-    // on the matrix cores; MIOpen's fp32 Winograd runs it in 1.04 ms at N = 512 (113 TFLOP/s effective).
+    // the stride-1 3x3 convolutions of ResNetV2-50 at the training micro-batch (B here = N of the
+    // convolution) on the matrix cores; all four have the same 118 GFLOP at N = 512.
     const int Nc = B;
-    const size_t e = (size_t)Nc * 64 * 3136;
-    float *cx = (float *)dmalloc(e * 4), *cy = (float *)dmalloc(e * 4), *cw = (float *)dmalloc(64 * 576 * 4);
-    hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, st, (f4 *)cx, e / 4, 0.37f);
-    hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, st, (f4 *)cw, 64 * 576 / 4, 0.01f);
-    const double flop = 2.0 * Nc * 3136.0 * 64 * 576;
-    for (int rep = 0; rep < 3; ++rep) {
-      hipEvent_t e0, e1;
-      CK(hipEventCreate(&e0));
-      CK(hipEventCreate(&e1));
-      DP(dp_conv3x3_fwd(cx, cw, Nc, 64, 64, 56, 56, cy, st));
-      CK(hipEventRecord(e0, st));
-      for (int i = 0; i < iters; ++i) DP(dp_conv3x3_fwd(cx, cw, Nc, 64, 64, 56, 56, cy, st));
-      CK(hipEventRecord(e1, st));
-      CK(hipEventSynchronize(e1));
-      float ms;
-      CK(hipEventElapsedTime(&ms, e0, e1));
-      ms /= iters;
-      printf("dp_conv3x3_fwd 64->64 @56x56 N=%d (v_mfma_f32_32x32x2_f32)  %8.4f ms  %7.1f TFLOP/s  (%.1f%% of the 157.3 TFLOP/s f32 peak)\n",
-             Nc, ms, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 1.573);
+    const int shapes[4][2] = {{64, 56}, {128, 28}, {256, 14}, {512, 7}};
+    for (auto &sh : shapes) {
+      const int Cc = sh[0], Sc = sh[1];
+      const size_t e = (size_t)Nc * Cc * Sc * Sc;
+      float *cx = (float *)dmalloc(e * 4), *cy = (float *)dmalloc(e * 4), *cw = (float *)dmalloc((size_t)Cc * Cc * 9 * 4);
+      hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, st, (f4 *)cx, e / 4, 0.37f);
+      hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, st, (f4 *)cw, (size_t)Cc * Cc * 9 / 4, 0.01f);
+      const double flop = 2.0 * Nc * Sc * Sc * (double)Cc * Cc * 9;
+      for (int rep = 0; rep < 2; ++rep) {
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        DP(dp_conv3x3_fwd(cx, cw, Nc, Cc, Cc, Sc, Sc, cy, st));
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < iters; ++i) DP(dp_conv3x3_fwd(cx, cw, Nc, Cc, Cc, Sc, Sc, cy, st));
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= iters;
+        printf("dp_conv3x3_fwd %3d->%3d @%2dx%2d N=%d (v_mfma_f32_32x32x2_f32)  %8.4f ms  %7.1f TFLOP/s  (%.1f%% of the 157.3 TFLOP/s f32 peak)\n",
+               Cc, Cc, Sc, Sc, Nc, ms, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 1.573);
+      }
+      CK(hipFree(cx)); CK(hipFree(cy)); CK(hipFree(cw));
     }
     return 0;
   }
