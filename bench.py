@@ -79,6 +79,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC passes (roofline.traffic = null)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the separately-timed collect_failure sweep")
+    ap.add_argument("--no-update-roofline", action="store_true",
+                    help="skip the dp_project_update roofline pass after the timed steps (for kernel-trace runs: its 13 "
+                         "launches on a 256-image working set would mix into the step's per-kernel statistics)")
     ap.add_argument("--stage", type=int, default=0)
     ap.add_argument("--find", type=int, default=0,
                     help="1: torch.backends.cudnn.benchmark=True (MIOpen exhaustive find: minutes on a fresh box); "
@@ -605,7 +608,7 @@ def main(argv=None):
         dt_sweep = time.perf_counter() - t1
         note("collect_failure sweep done: %.3f s" % dt_sweep)
     roof2 = None
-    if rank == 0 and H % 8 == 0 and H >= 56:
+    if rank == 0 and H % 8 == 0 and H >= 56 and not args.no_update_roofline:
         roof2 = project_update_roofline(dev, H, args.stage)
         note("dp_project_update roofline pass done: %.4f ms" % roof2["avg_launch_ms"])
     det_report = loop.deterministic_in_effect          # read before close() restores the caller's settings

@@ -384,9 +384,15 @@ def test_finished_images_leave_the_batch(mb, dual, stage):
     parameters agree to the last bit whenever the classifier's library kernels are batch-size invariant (torch-CPU
     convolutions under the emulation: asserted bit-exact; MIOpen chooses its kernel by batch size, there the two runs
     agree to fp32 round-off — the GPU's bit-exact statement is the next test), and a finished image's rows stay frozen."""
-    on, off = _retire_run(True, mb=mb, dual=dual, stage=stage), _retire_run(False, mb=mb, dual=dual, stage=stage)
+    exact = DEV == "cpu"      # torch-CPU convolutions are batch-size invariant ON ONE THREAD (with more, oneDNN splits the
+    threads = torch.get_num_threads()      # batch differently for 18 and for 24 rows); MIOpen picks its kernel by batch size
+    if exact:
+        torch.set_num_threads(1)
+    try:
+        on, off = _retire_run(True, mb=mb, dual=dual, stage=stage), _retire_run(False, mb=mb, dual=dual, stage=stage)
+    finally:
+        torch.set_num_threads(threads)
     S, B = 6, 4
-    exact = DEV == "cpu"      # torch-CPU convolutions are batch-size invariant; MIOpen picks its kernel by batch size
     assert off["n_fwd"] == [B * S * (k + 1) for k in range(6)]                     # everything rides along
     assert on["n_fwd"] == [24, 48, 48 + 18, 48 + 18 + 12, 48 + 18 + 24, 48 + 18 + 36]
     assert (off["swept"], on["swept"]) == (12, 4 + 3 + 2)                          # sweeps at steps 0, 2, 4

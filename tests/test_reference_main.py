@@ -21,16 +21,33 @@ if emu_patch.build_emu.host_compiler() is None:
     pytest.skip("no host clang++ for the HIP emulation build", allow_module_level=True)
 
 
-def _run(work, *flags):
+def _start(work, *flags):
     env = dict(os.environ, OMP_NUM_THREADS="2", DORPATCH_REFMAIN_BATCHES="1")
-    res = subprocess.run([sys.executable, os.path.join(HERE, "run_reference_main.py"), str(work)] + list(flags),
-                         capture_output=True, text=True, timeout=1500, env=env)
-    assert res.returncode == 0, res.stderr[-4000:]
-    return json.loads(res.stdout.strip().splitlines()[-1])
+    return subprocess.Popen([sys.executable, os.path.join(HERE, "run_reference_main.py"), str(work)] + list(flags),
+                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
 
 
-def test_unmodified_reference_main_runs_against_the_drop_in_modules(tmp_path):
-    out = _run(tmp_path, "--targeted")
+def _finish(proc):
+    out, err = proc.communicate(timeout=1500)
+    assert proc.returncode == 0, err[-4000:]
+    return json.loads(out.strip().splitlines()[-1])
+
+
+def _run(work, *flags):
+    return _finish(_start(work, *flags))
+
+
+@pytest.fixture(scope="module")
+def first_runs(tmp_path_factory):
+    """The targeted and the untargeted run of main.py, side by side (each ~75 s under the emulation: 2 x 2520 + 2664 masked
+    224 x 224 images through the fibre-emulated occlusion kernel)."""
+    dirs = {k: tmp_path_factory.mktemp(k) for k in ("targeted", "untargeted")}
+    procs = {"targeted": _start(dirs["targeted"], "--targeted"), "untargeted": _start(dirs["untargeted"])}
+    return {k: (dirs[k], _finish(p)) for k, p in procs.items()}
+
+
+def test_unmodified_reference_main_runs_against_the_drop_in_modules(first_runs):
+    tmp_path, out = first_runs["targeted"]
     # main.py's names are bound to the product, not to anything of the reference
     assert out["bound"] == dict(DorPatch="dorpatch_amd.attack", PatchCleanser="dorpatch_amd.patchcleanser",
                                 MaskWindow="dorpatch_amd.patchcleanser", clip="dorpatch_amd.utils", NormModel="dorpatch_amd.utils")
@@ -63,12 +80,12 @@ def test_unmodified_reference_main_runs_against_the_drop_in_modules(tmp_path):
 
 
 
-def test_unmodified_reference_main_resumes_from_its_files(tmp_path):
+def test_unmodified_reference_main_resumes_from_its_files(first_runs):
     """Untargeted (main.py's default; its resume branch for --targeted re-derives the target from the stage-0 files and
     asserts the attack had succeeded, main.py:112-118 — not after 3 iterations).  A second invocation in the same
     directory takes main.py:102-104 / 144-147: no generate() call, the PatchCleanser records are unpickled — through the
     drop-in ``defenses.PatchCleanser`` — and the same metric line comes out."""
-    first = _run(tmp_path)
+    tmp_path, first = first_runs["untargeted"]
     assert len(first["calls"]) == 1 and first["calls"][0]["targeted"] is False and first["calls"][0]["y"] is None
     last = first["stdout"].strip().splitlines()[-1]
     assert last.startswith("clean accuracy: 100.00%") and "certified_ASR@PC:" in last
