@@ -235,8 +235,8 @@ def cpu_baseline(size, n_masks=32, warm=3, timed=5, budget_s=40.0, threads=None,
             "detail": out}
 
 
-def pmc_traffic_live(B, S, H, timeout_s=150):
-    """HBM bytes of ONE dp_apply_fwd launch of this run's geometry, measured now: a child process replays
+def pmc_traffic_live(B, S, H, timeout_s=150, bench_filter="dp_apply_fwd (default", kernel="k_apply_fwd"):
+    """HBM bytes of ONE launch of `kernel` (default: dp_apply_fwd at this run's geometry), measured now: a child process replays
     the launch (tools/kbench, same kernel, same grid) under `rocprofv3 --pmc WRITE_SIZE` and, in a second
     pass, `--pmc FETCH_SIZE` (MI355X_MICROARCH.md: the two do not fit one pass).  Corrections per that guide's
     HBM section: both counters are in KiB; on gfx950 FETCH_SIZE tallies the 128-B requests of a wide coalesced
@@ -255,7 +255,7 @@ def pmc_traffic_live(B, S, H, timeout_s=150):
     for ctr in ("WRITE_SIZE", "FETCH_SIZE"):
         d = tempfile.mkdtemp(prefix="dp_pmc_", dir="/tmp")
         cmd = [rocprof, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "kb", "--",
-               exe, str(B), str(S), str(H), "2", "dp_apply_fwd (default"]
+               exe, str(B), str(S), str(H), "2", bench_filter]
         try:
             subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
@@ -263,10 +263,10 @@ def pmc_traffic_live(B, S, H, timeout_s=150):
             for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(path) as f:
                     for row in csv.DictReader(f):
-                        if "k_apply_fwd" in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
+                        if kernel in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
                             vals.append(float(row["Counter_Value"]))
             if not vals:
-                return None, "no %s rows for k_apply_fwd in the rocprofv3 output" % ctr
+                return None, "no %s rows for %s in the rocprofv3 output" % (ctr, kernel)
             kib[ctr] = float(np.mean(vals))
         except (subprocess.SubprocessError, OSError, ValueError, KeyError) as e:
             return None, "%s pass failed: %r" % (ctr, e)
@@ -629,6 +629,9 @@ def main(argv=None):
             traffic, traffic_note = None, "measured at --gpus 1 only"
         else:
             traffic, traffic_note = pmc_traffic_live(B, S_local, H)
+            if roof2 is not None and args.stage == 0:      # the same two passes for the second roofline kernel
+                roof2["traffic"], roof2["traffic_source"] = pmc_traffic_live(
+                    256, 1, H, bench_filter="dp_project_update stage 0", kernel="k_project_update_v4")
         note("PMC passes done: %s" % traffic_note)
         out = {
             "metric": "EOT-samples/sec", "value": round(value, 2), "unit": "EOT-samples/s",

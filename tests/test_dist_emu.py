@@ -137,6 +137,68 @@ def test_hot_loop_two_ranks_equals_one(world, tmp_path):
         assert torch.equal(outs[0]["pattern"], other["pattern"]) and torch.equal(outs[0]["mask"], other["mask"])
 
 
+# ---------------------------------------------------------------- finished images leave the batch, on two ranks
+def _run_retire(pg, rank, retire):
+    """4 steps of a 2-image loop whose image 0 is marked finished before step 2 (attack.py:311-316), sweeps at steps 0, 2."""
+    from dorpatch_amd.attack import DorPatch, HotLoop
+    x, m, p, y, rows, net = _problem()
+    rows = [r + [np.random.RandomState(99 + b).choice(N_MASK, S, replace=False)] for b, r in enumerate(rows)]
+    seen = []
+    hook = lambda d: seen.append(dict(loss_adv=d["loss_adv"].copy(), g_adv=d["g_adv"].clone(), lr=d["lr"].copy()))
+    loop = HotLoop(DorPatch(micro_batch=6, process_group=pg, verbose=False), net, x, 0.12, 10, "t/cfg/sub", 0, y,
+                   True, 1e-2, 1e-1, 0, 1, 10 ** 6, 7, 'topk', 1, S, 1e-3, 1e-3, 4.0, False,
+                   dict(init_mask=m, init_pattern=p, rngs=[FixedDraw(rows[b]) for b in range(B)], step_hook=hook,
+                        failure_refresh=2, retire=retire))
+    preds = []
+    for i in range(4):
+        if i == 2:
+            loop.img[0].active = False
+        loop.step(i)
+        preds.append(loop.pred_host.copy())
+    out = dict(seen=seen, preds=preds, pattern=loop.adv_pattern.clone(), mask=loop.adv_mask.clone(),
+               failed=[list(st.failed_idxs) for st in loop.img], n_fwd=loop.n_forward, swept=loop.swept_images)
+    loop.close()
+    return out
+
+
+def _retire_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)          # torch-CPU convolutions are batch-size invariant on one thread only
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        with _emu_patch().emulated_ops():
+            out = {r: _run_retire(dist.group.WORLD, rank, r) for r in (True, False)}
+        torch.save(out, os.path.join(out_dir, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_retiring_images_on_two_ranks(tmp_path):
+    """The dense batch of the running images under EOT-sample sharding: each rank gathers the same rows (the `active`
+    flags are host state derived from all-reduced losses, identical everywhere), fills its own loss / prediction slab for
+    them, and the one all-reduce of the step carries zero gradient rows for the finished image.  Against `retire=False`
+    on the same two ranks the running image's gradients, losses, failure list and parameters are bit-identical, the
+    finished image's prediction row keeps its last value, and the ranks stay in lock-step."""
+    mp.spawn(_retire_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    outs = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(2)]
+    for o in outs:
+        on, off = o[True], o[False]
+        assert on["n_fwd"] == (2 + 2 + 1 + 1) * (S // 2) and off["n_fwd"] == 8 * (S // 2)     # this rank's half of the samples
+        assert (on["swept"], off["swept"]) == (2 + 1, 2 + 2)
+        for k in range(4):
+            a, w = on["seen"][k], off["seen"][k]
+            assert np.array_equal(a["lr"], w["lr"]) and (k < 2 or a["lr"][0] == 0)
+            assert np.array_equal(a["loss_adv"][1], w["loss_adv"][1]) and torch.equal(a["g_adv"][1], w["g_adv"][1])
+            if k >= 2:
+                assert not a["g_adv"][0].any()
+            assert np.array_equal(on["preds"][k], off["preds"][k])
+        assert on["failed"][1] == off["failed"][1]
+        assert torch.equal(on["pattern"], off["pattern"]) and torch.equal(on["mask"], off["mask"])
+    for key in (True, False):                                   # lock-step across the ranks
+        assert torch.equal(outs[0][key]["pattern"], outs[1][key]["pattern"])
+        assert all(torch.equal(a["g_adv"], b["g_adv"]) for a, b in zip(outs[0][key]["seen"], outs[1][key]["seen"]))
+
+
 def _placement_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
