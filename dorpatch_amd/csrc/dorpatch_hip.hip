@@ -3117,10 +3117,17 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3_mfma(const float *__restr
 
   vec_t pin[G::IT];
   f4 pwt[kCvWtIt];
+  // (For the planes below 56 x 56, fetch / stash re-derive their element decode from a LAUNDERED copy of the thread index
+  // every time: left alone, hipcc keeps the per-iteration global and LDS offsets — 2 x IT values, loop-invariant — alive
+  // across the whole MFMA loop, which with IT = 9 / 17 (14 x 14 / 7 x 7) spilled 136 / 572 B per lane; the decode is ~10
+  // integer ops per element.  Measured, N = 512: 28 x 28 0.964 -> 0.907 ms, 14 x 14 1.085 -> 1.039, 7 x 7 1.506 -> 1.161 —
+  // but 56 x 56 0.880 -> 0.927 (the 256-VGPR schedule with its 8 B of scratch is the faster one there), so not for S = 56.)
   auto fetch = [&](int chunk) {          // global -> registers
+    int tl = tid;
+    if (S != 56) DP_LAUNDER(tl);
 #pragma unroll
     for (int it = 0; it < G::IT; ++it) {
-      const int i = tid + it * kBlock;
+      const int i = tl + it * kBlock;
       const int ch = i / (G::ROWS * G::VPR), rem = i - ch * (G::ROWS * G::VPR);
       const int row = rem / G::VPR, q = rem - row * G::VPR;
       const int vr = vr0 + row;
@@ -3139,9 +3146,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3_mfma(const float *__restr
   };
   auto stash = [&](int buf) {            // registers -> LDS
     float *dst = lds + buf * G::BUF;
+    int tl = tid;
+    if (S != 56) DP_LAUNDER(tl);
 #pragma unroll
     for (int it = 0; it < G::IT; ++it) {
-      const int i = tid + it * kBlock;
+      const int i = tl + it * kBlock;
       const int ch = i / (G::ROWS * G::VPR), rem = i - ch * (G::ROWS * G::VPR);
       const int row = rem / G::VPR, q = rem - row * G::VPR;
       if (i < G::NV) *reinterpret_cast<vec_t *>(dst + ch * G::CHS + row * G::PITCH + G::X0 + q * G::VW) = pin[it];

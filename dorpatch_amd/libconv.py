@@ -47,6 +47,9 @@ try:
                      for n, t in _doc3["routes"].items()}
 except (OSError, ValueError, KeyError):
     CONV3X3_TABLE = {}
+for _extra in filter(None, os.environ.get("DORPATCH_CONV3X3_ALSO", "").split(",")):     # A/B knob: "fwd:512:7,bwd:512:7"
+    _d, _c, _s = _extra.split(":")                                                       # -> also on dp_conv3x3_fwd, at
+    CONV3X3_TABLE.setdefault(512, {})[(_d, int(_c), int(_s))] = "mfma"                   # batches >= 512
 _used3 = {}          # (direction, route) -> set of (N, C, S) routed (report_conv3x3())
 
 
