@@ -7,14 +7,18 @@
         --master-port P bench.py --gpus N --steps K --warmup W
     python bench.py --config 3 --scaling strong --gpus 8   # BASELINE configs[3]: 512 EOT samples of one image, 64 per GPU
     python bench.py --config {0,2,3}            # the other single-GPU BASELINE configs (parity-test cases, also timed)
+    python bench.py --whole-attack              # NOT the headline: seconds per image of a whole attack as main.py runs it
+                                                # (stage 0 + stage 1 + failure sweeps + PatchCleanser), retiring finished
+                                                # images vs not; library batch shapes warmed first
     DORPATCH_TRACE=1: roctx ranges around the step's phases (for `rocprofv3 --marker-trace --kernel-trace`).
-    A/B switches: --deterministic {auto,on,off}, --conv1x1 {table,auto,gemm,miopen}, DORPATCH_TUNABLEOP=0, --stem-split, --skip-satisfied {on,off},
+    A/B switches: --deterministic {auto,on,off}, --conv1x1 {table,auto,gemm,miopen}, --conv3x3 {table,on,off}, DORPATCH_TUNABLEOP=0, --stem-split, --skip-satisfied {on,off},
                   --satisfied F (what-if),
                   --no-fused-gn, --micro-batch N, --find 1
 
 One "step" = one pass of the hot path (reference attack.py:184-342, stage 0) over one batch of
 synthetic input: blend/L2-project -> sample masks -> fused occlude+normalise (dp_apply_fwd) ->
-frozen ResNetV2-50x1-BiT forward + input-gradient backward (fp32, MIOpen) -> CW loss ->
+frozen ResNetV2-50x1-BiT forward + input-gradient backward (fp32: MIOpen / hipBLASLt, the stride-1 3x3 convolutions
+on the hand-written fp32-MFMA kernel dp_conv3x3_fwd where the committed table routes them) -> CW loss ->
 S-reduction of the input gradients (dp_apply_bwd) -> structural / density / group-lasso terms ->
 bookkeeping -> signed update (dp_project_update).  Workload = BASELINE.json configs[1]:
 64 images x 32 sampled double-masks = 2048 EOT samples per step per GPU at 224x224.  With N > 1
@@ -28,7 +32,8 @@ through, and exits non-zero if any rank fails (the others are terminated).  The 
 more than one GPU is nn.DataParallel inside one process (main.py:53).
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
-  "roofline":     dp_apply_fwd, algorithmic bytes (602 112 B/sample @224) / HIP-event time, vs 8 TB/s;
+  "roofline":     dp_apply_fwd, algorithmic bytes (602 112 B/sample @224) / HIP-event time, vs 8 TB/s
+                  ("roofline_project_update": the same for dp_project_update on a 256-image working set);
                   "traffic" = HBM bytes per launch from rocprofv3 PMC passes run live (a child process
                   replays the same launch through tools/kbench under `rocprofv3 --pmc`), or null
   "cpu_baseline": the CPU oracle (a port of the reference step) timed on this host's cores on a
