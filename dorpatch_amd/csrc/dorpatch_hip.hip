@@ -1615,6 +1615,9 @@ struct GnArgs {
   const float *res;   // forward: optional residual, the normalised tensor is x + res (nullptr: x)
   float *sum_out;     // forward: x + res is also written here (the next block's shortcut)
   const float *dres;  // backward: optional extra gradient w.r.t. (x + res), added to the result
+  float *ab;          // forward: optional (N, C, 2) table of the affine coefficients a = rstd * gamma, b = beta - mean * a
+                      // (what the store phase applies), for convolutions that fold the apply into their operand staging
+                      // (k_conv1x1_mfma FOLD); with y == nullptr the forward is a statistics-only pass
   int C, HW, Cg;      // channels, pixels per channel, channels per group
   float eps, inv_hw;  // inv_hw = 1 / HW
   // backward, gather form (dp_gn_relu_bwd_gather): output sample n takes its x / mean / rstd from SOURCE sample
@@ -1682,6 +1685,17 @@ __device__ __forceinline__ void gn_coeffs(const float *ga, const float *be, floa
       b[j] = be[c] - mean * a[j];
     }
   }
+}
+
+// thread c (< Cg) of the (sample, group) workgroup writes channel cbase + c's coefficients — gn_coeffs' expressions
+__device__ __forceinline__ void gn_store_ab(const GnArgs &A, int ng, int cbase, const float *ga, const float *be,
+                                            float mean, float rstd) {
+  const int G = A.C / A.Cg, n = ng / G, c = threadIdx.x;
+  const float aa = rstd * ga[c];
+  const float bb = be[c] - mean * aa;
+  float *dst = A.ab + 2 * ((size_t)n * A.C + cbase + c);
+  dst[0] = aa;
+  dst[1] = bb;
 }
 
 template <bool NT>
@@ -1776,9 +1790,11 @@ __global__ __launch_bounds__(T, MW) void k_gn_relu_fwd(GnArgs A, float *__restri
     mean_out[ng] = mean;
     rstd_out[ng] = rstd;
   }
-  const bool uniform = (A.HW & 3) == 0;
   const float *ga = LC ? s_gb : A.gamma + cbase;
   const float *be = LC ? s_gb + kGnLdsCh : A.beta + cbase;
+  if (A.ab && (int)threadIdx.x < A.Cg) gn_store_ab(A, ng, cbase, ga, be, mean, rstd);
+  if (!y) return;                       // statistics-only pass (uniform): the consumer applies the affine + ReLU itself
+  const bool uniform = (A.HW & 3) == 0;
 #pragma unroll
   for (int k = 0; k < V; ++k) {
     const int i = threadIdx.x + k * T;
@@ -2050,6 +2066,8 @@ __global__ __launch_bounds__(kGnStreamT) void k_gn_relu_fwd_stream(GnArgs A, flo
     mean_out[ng] = mean;
     rstd_out[ng] = rstd;
   }
+  if (A.ab && (int)threadIdx.x < A.Cg) gn_store_ab(A, ng, cbase, A.gamma + cbase, A.beta + cbase, mean, rstd);
+  if (!y) return;
   const bool uniform = (A.HW & 3) == 0;
   for (int i = threadIdx.x; i < L4; i += T) {
     const f4 v = x4[i];
@@ -3232,6 +3250,227 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3_mfma(const float *__restr
   }
 }
 
+// ----------------------------------------------------------------------------
+// a-8 (round 5, VERDICT r4 items 1 + 2): the backbone's 1 x 1 / stride 1 convolutions on the matrix cores — 33 of
+// ResNetV2-50's 53 convolutions, 17.4 of the 33.5 TFLOP of a configs[1] step, until now Tensile / MIOpen NHWC kernels.
+//     forward         y[n]  (O x HW) = W   (O x C) x[n]  (C x HW)
+//     input gradient  dx[n] (C x HW) = W^T (C x O) dy[n] (O x HW)        — the same kernel on the transposed weights
+// on the NCHW tensors as they lie (a 1 x 1 convolution has no halo: the B operand of channel k is a run of pixels).  Same
+// MFMA walk as k_conv3x3_mfma (v_mfma_f32_32x32x2_f32, weights = A operand, D lanes along pixels, exact f32 fmaf chain
+// over the channels in ascending order: deterministic by construction), one tap instead of nine:
+//   workgroup = 448 batch-linear pixels x 64 output channels, wave w = channel fragment w & 1 x pixel fragments (w >> 1) + 2 q;
+//   K walks in chunks of 16 input channels = 8 k-steps = 56 MFMAs per wave and barrier; the chunk's activations
+//   [channel][448 pixels] and pre-packed weights [channel][64 oc] are double-buffered in LDS (2 x 32 KB: 2 workgroups
+//   per CU), fetched to registers during the previous chunk's MFMAs and stored half-way through them.
+// Staging is a flat copy in both layouts: item j = (float4 j of the chunk's LDS image) <-> one 16-byte global load.
+//   row mode  (HW % 4 == 0): tile = 448 consecutive batch-linear pixels (may span images: a float4 never does),
+//             item j = (channel j / 112, pixel quad j % 112);
+//   flat mode (FHW = 49: the 7 x 7 planes, whose rows are not 16-byte multiples): tile = 9 whole images (441 pixels, 7 idle
+//             lanes), LDS image [image][16 channels x 49] = what lies contiguously in memory (16 x 49 x 4 B = 196 float4 per
+//             image and chunk), the k-step stride is 49 floats.
+// FOLD: the input is the RAW tensor a GroupNorm + ReLU would have normalised; the affine + ReLU is
+// applied between the global load and the LDS store, with the per-(sample, channel) coefficients a = rstd * gamma,
+// b = beta - mean * a that dp_gn_relu_fwd's statistics pass wrote ((N, C, 2) table `ab`), by the same expression
+// (x * a + b, un-fused, then max 0): the normalised activation is never written to or re-read from HBM.
+// RES: y = conv + res (res may be y itself): the bottleneck's residual add / the accumulation of the downsample branch's
+// gradient in the epilogue.
+// Workgroup ids are decoded XCD-aware (block b runs on XCD b % 8): the O / 64 channel groups of one pixel tile are
+// consecutive workgroups of ONE XCD, so a tile of x is fetched from HBM once and re-read from that XCD's L2.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr int kC1O = 64;                               // output channels per workgroup
+constexpr int kC1Pix = 448;                            // pixels per workgroup (14 fragments)
+constexpr int kC1Ch = 16;                              // input channels per K-chunk
+constexpr int kC1Steps = kC1Ch / 2;                    // 8 MFMA k-steps per chunk
+constexpr int kC1Wt = kC1Ch * kC1O;                    // 1024 floats of packed weights per (oc group, chunk): one f4 per thread
+constexpr int kC1In = kC1Ch * kC1Pix;                  // 7168 floats of activations per chunk
+constexpr int kC1Buf = kC1In + kC1Wt;                  // 32 KB
+constexpr int kC1It = kC1In / 4 / kBlock;              // 7 staging float4 per thread and chunk
+static_assert(kC1Wt == 4 * kBlock && kC1It * 4 * kBlock == kC1In, "one weight float4 / seven activation float4 per thread");
+
+struct C1Args {
+  const float *x, *wt;
+  const float *ab;      // FOLD: (N, C, 2) coefficients of the fused GroupNorm + ReLU on the input
+  const float *res;     // RES: added to the result (layout of y; may alias y)
+  float *y;
+  int N, C, O, HW;
+  int tiles;            // pixel tiles
+  int og;               // O / 64
+  int spt;              // flat mode: images per tile (448 / HW)
+};
+
+template <int FHW, bool FOLD, bool RES>
+__global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kC1Buf];
+  constexpr bool FLAT = FHW != 0;
+  const int wg = blockIdx.x, xcd = wg & 7, slot = wg >> 3;
+  const int tl = slot / A.og, og = slot - tl * A.og;
+  const int tile = tl * 8 + xcd;
+  if (tile >= A.tiles) return;                               // grid padded to a multiple of 8 tiles
+  const int HW = FLAT ? FHW : A.HW;
+  const int CHS = FLAT ? FHW : kC1Pix;                       // LDS stride between channels
+  const int NCH = A.C / kC1Ch;
+  const int total = A.N * HW;                                // < 2^31 (checked by the launcher)
+  const int g0 = FLAT ? 0 : tile * kC1Pix;                   // row mode: first pixel of the tile (batch-linear)
+  const int n0 = FLAT ? tile * A.spt : 0;                    // flat mode: first image of the tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int ocf = wave & 1, pf0 = wave >> 1;
+  const float *wtg = A.wt + (size_t)og * NCH * kC1Wt + 4 * tid;
+
+  // staging items: element offset of the item's float4 at chunk 0 (-1: nothing to load) and, FOLD, of its coefficients
+  int xoff[kC1It], aoff[kC1It];
+#pragma unroll
+  for (int it = 0; it < kC1It; ++it) {
+    const int j = tid + it * kBlock;
+    if (!FLAT) {
+      const int ch = j / (kC1Pix / 4), quad = j - ch * (kC1Pix / 4);
+      const int g = g0 + 4 * quad;
+      const bool ok = g < total;
+      const int n = ok ? g / HW : 0, p = ok ? g - n * HW : 0;
+      xoff[it] = ok ? (n * A.C + ch) * HW + p : -1;
+      aoff[it] = n * A.C + ch;
+    } else {
+      const int s = j / (kC1Ch / 4 * FHW), f = j - s * (kC1Ch / 4 * FHW);
+      const bool ok = s < A.spt && n0 + s < A.N;
+      xoff[it] = ok ? (n0 + s) * A.C * FHW + 4 * f : -1;
+      aoff[it] = 0;
+    }
+  }
+
+  f4 pin[kC1It], pwt;
+  f2 pab[FOLD ? kC1It : 1];
+  auto fetch = [&](int chunk) {          // global -> registers; every load is issued unconditionally
+    const float *xc = A.x + (size_t)chunk * kC1Ch * HW;
+#pragma unroll
+    for (int it = 0; it < kC1It; ++it) pin[it] = *reinterpret_cast<const f4 *>(xc + (xoff[it] < 0 ? 0 : xoff[it]));
+    if (FOLD) {
+      const float *abc = A.ab + (size_t)chunk * kC1Ch * 2;
+#pragma unroll
+      for (int it = 0; it < kC1It; ++it) pab[it] = *reinterpret_cast<const f2 *>(abc + 2 * (size_t)aoff[it]);
+    }
+    pwt = *reinterpret_cast<const f4 *>(wtg + (size_t)chunk * kC1Wt);
+  };
+  auto stash = [&](int buf) {            // registers -> LDS (flat copy), with the fused GroupNorm-apply + ReLU
+    float *dst = lds + buf * kC1Buf;
+#pragma unroll
+    for (int it = 0; it < kC1It; ++it) {
+      f4 v = pin[it];
+      if (FOLD) {                        // dp_gn_relu_fwd's own expression: x * a + b (not fused), max 0
+        const float a = pab[it].x, b = pab[it].y;
+        v.x = fmaxf(v.x * a + b, 0.f);
+        v.y = fmaxf(v.y * a + b, 0.f);
+        v.z = fmaxf(v.z * a + b, 0.f);
+        v.w = fmaxf(v.w * a + b, 0.f);
+      }
+      if (xoff[it] < 0) v = f4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f4 *>(dst + 4 * (tid + it * kBlock)) = v;
+    }
+    *reinterpret_cast<f4 *>(dst + kC1In + 4 * tid) = pwt;
+  };
+
+  // lane bases: A = weights [channel][oc]; B = the lane's pixel of each of its 7 fragments, channel parity = half.
+  // Lanes without a pixel (past the end of the batch / of the tile's images) read a valid LDS word and never store.
+  const int abase = kC1In + half * kC1O + ocf * 32 + l32;
+  int boff[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const int gl = (pf0 + 2 * q) * 32 + l32;
+    if (!FLAT) {
+      boff[q] = half * kC1Pix + gl;
+    } else {
+      int s = gl / FHW, p = gl - s * FHW;
+      if (s >= A.spt) s = 0, p = 0;
+      boff[q] = s * (kC1Ch * FHW) + half * FHW + p;
+    }
+  }
+  f16v acc[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
+
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int chunk = 0; chunk < NCH; ++chunk) {
+    if (chunk + 1 < NCH) fetch(chunk + 1);
+    const float *cur = lds + (chunk & 1) * kC1Buf;
+    // the k-step software pipeline of k_conv3x3_mfma: step t + 1's 8 operands are requested before step t's 7 MFMAs
+    auto operands = [&](int t, float &a, float (&bv)[7]) {
+      a = cur[abase + t * 2 * kC1O];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) bv[q] = cur[boff[q] + t * 2 * CHS];
+    };
+    float a0, b0[7], a1, b1[7];
+    operands(0, a0, b0);
+#pragma unroll
+    for (int t = 0; t < kC1Steps; t += 2) {
+      operands(t + 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[q], acc[q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t == kC1Steps / 2 && chunk + 1 < NCH) stash((chunk + 1) & 1);     // the other buffer: nobody reads it now
+      if (t + 2 < kC1Steps) operands(t + 2, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[q], acc[q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+  const int oc0 = og * kC1O + ocf * 32 + 4 * half;
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const int gl = (pf0 + 2 * q) * 32 + l32;
+    int n, p;
+    bool ok;
+    if (!FLAT) {
+      const int g = g0 + gl;
+      ok = g < total;
+      n = g / HW, p = g - n * HW;
+    } else {
+      const int s = gl / FHW;
+      p = gl - s * FHW, n = n0 + s;
+      ok = s < A.spt && n < A.N;
+    }
+    if (!ok) continue;
+    const size_t o = ((size_t)n * A.O + oc0) * HW + p;
+    float *yq = A.y + o;
+    if (RES) {
+      const float *rq = A.res + o;
+      float r[16];
+#pragma unroll
+      for (int v = 0; v < 16; ++v) r[v] = rq[(size_t)((v & 3) + 8 * (v >> 2)) * HW];
+#pragma unroll
+      for (int v = 0; v < 16; ++v) yq[(size_t)((v & 3) + 8 * (v >> 2)) * HW] = acc[q][v] + r[v];
+    } else {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) yq[(size_t)((v & 3) + 8 * (v >> 2)) * HW] = acc[q][v];
+    }
+  }
+}
+
+int launch_conv1x1(const C1Args &A, bool flat, hipStream_t st) {
+  const dim3 grid((unsigned)(cdiv(A.tiles, 8) * 8 * A.og)), block(kBlock);
+  const bool fold = A.ab != nullptr, res = A.res != nullptr;
+#define DP_LAUNCH_C1(FHW_, FOLD_, RES_) hipLaunchKernelGGL((k_conv1x1_mfma<FHW_, FOLD_, RES_>), grid, block, 0, st, A)
+  if (flat) {
+    if (res) DP_LAUNCH_C1(49, false, true);
+    else DP_LAUNCH_C1(49, false, false);
+  } else if (fold) {
+    if (res) DP_LAUNCH_C1(0, true, true);
+    else DP_LAUNCH_C1(0, true, false);
+  } else {
+    if (res) DP_LAUNCH_C1(0, false, true);
+    else DP_LAUNCH_C1(0, false, false);
+  }
+#undef DP_LAUNCH_C1
+  return launch_status();
+}
+
 // variant 0: fp32 VALU gather, 2 quads per thread (shipped); 2: the same with 4 quads per thread (measured slower, see
 // k_stem_dgrad); 1: matrix cores (k_stem_dgrad_mfma; needs K % 4 == 0, else the default is used; measured slower)
 constexpr int kStemDefaultVariant = 0;
@@ -3549,6 +3788,25 @@ int dp_conv3x3_fwd(const float *x, const float *wt, int N, int C, int O, int H, 
   return launch_status();
 }
 
+int dp_conv1x1_fwd(const float *x, const float *wt, const float *ab, const float *res, int N, int C, int O, int HW,
+                   float *y, dp_stream_t stream) {
+  DP_REQUIRE(x && wt && y && aligned16(x) && aligned16(wt) && aligned16(y));
+  DP_REQUIRE(N > 0 && HW > 0 && C > 0 && C % kC1Ch == 0 && O > 0 && O % kC1O == 0);
+  DP_REQUIRE((long)N * C * HW < (1L << 31) && (long)N * HW + kC1Pix < (1L << 31));   // 32-bit element offsets in the kernel
+  DP_REQUIRE(!ab || (reinterpret_cast<uintptr_t>(ab) & 7u) == 0);
+  const bool flat = (HW & 3) != 0;
+  DP_REQUIRE(!flat || (HW == 49 && !ab));     // 7 x 7 planes: whole-image tiles; the GroupNorm fold needs HW % 4 == 0
+  C1Args A;
+  A.x = x; A.wt = wt; A.ab = ab; A.res = res; A.y = y;
+  A.N = N; A.C = C; A.O = O; A.HW = HW;
+  A.og = O / kC1O;
+  A.spt = flat ? kC1Pix / HW : 0;
+  const long tiles = flat ? ((long)N + A.spt - 1) / A.spt : ((long)N * HW + kC1Pix - 1) / kC1Pix;
+  DP_REQUIRE((tiles + 7) / 8 * 8 * A.og < (1L << 31));
+  A.tiles = (int)tiles;
+  return launch_conv1x1(A, flat, as_stream(stream));
+}
+
 int dp_argmax(const float *logits, int N, int C, int32_t *pred, dp_stream_t stream) {
   DP_REQUIRE(logits && pred && N > 0 && C > 0);
   hipLaunchKernelGGL(k_argmax, dim3(cdiv(N, kBlock / 64)), dim3(kBlock), 0, as_stream(stream),
@@ -3564,7 +3822,7 @@ static int gn_check(const float *x, const float *gamma, const float *beta, int N
   DP_REQUIRE((L & 3) == 0 && L < (1L << 20));  // float4 lanes; chan_of() exactness bound
   DP_REQUIRE((long)N * G <= 0x7fffffffL);
   A.x = x; A.gamma = gamma; A.beta = beta;
-  A.res = nullptr; A.sum_out = nullptr; A.dres = nullptr;
+  A.res = nullptr; A.sum_out = nullptr; A.dres = nullptr; A.ab = nullptr;
   A.smap = nullptr; A.tab_rows = 0;
   for (int k = 0; k < kGnMaxTabs; ++k) A.xtab[k] = nullptr;
   A.C = C; A.HW = HW; A.Cg = C / G;
@@ -3583,6 +3841,19 @@ int dp_gn_relu_fwd(const float *x, const float *res, float *sum_out, const float
   A.res = res;
   A.sum_out = res ? sum_out : nullptr;
   return launch_gn_fwd(kGnDefaultVariant, A, N, y, mean, rstd, as_stream(stream));
+}
+
+int dp_gn_stats(const float *x, const float *res, float *sum_out, const float *gamma, const float *beta, int N, int C,
+                int HW, int G, float eps, float *mean, float *rstd, float *ab, dp_stream_t stream) {
+  GnArgs A;
+  const int rc = gn_check(x, gamma, beta, N, C, HW, G, A, eps);
+  if (rc) return rc;
+  DP_REQUIRE(mean && rstd && ab && (reinterpret_cast<uintptr_t>(ab) & 7u) == 0);
+  DP_REQUIRE(!res || (sum_out && aligned16(res) && aligned16(sum_out)));
+  A.res = res;
+  A.sum_out = res ? sum_out : nullptr;
+  A.ab = ab;
+  return launch_gn_fwd(kGnDefaultVariant, A, N, nullptr, mean, rstd, as_stream(stream));
 }
 
 int dp_gn_relu_bwd(const float *dy, const float *dres, const float *x, const float *gamma,

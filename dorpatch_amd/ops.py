@@ -376,6 +376,74 @@ def conv3x3_fwd(x, wt):
     return y
 
 
+# ---------------------------------------------------------------- a-8: 1x1 convolutions on the matrix cores (round 5)
+def conv1x1_supported(x, weight):
+    """Shapes dp_conv1x1_fwd takes: fp32 GPU NCHW, (O, C, 1, 1) filter with C % 16 == 0 and O % 64 == 0, planes of
+    H*W % 4 == 0 pixels or 7 x 7 (every stride-1 1x1 convolution of ResNetV2-50 at 224 x 224 and 384 x 384)."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
+        return False
+    HW = x.shape[2] * x.shape[3]
+    return (weight.dim() == 4 and tuple(weight.shape[2:]) == (1, 1) and weight.shape[1] == x.shape[1]
+            and weight.shape[1] % 16 == 0 and weight.shape[0] % 64 == 0 and (HW % 4 == 0 or HW == 49)
+            and x.shape[0] * max(weight.shape[0], weight.shape[1]) * HW < 2 ** 31)
+
+
+def pack_conv1x1_weights(w, transpose=False):
+    """(O, C[, 1, 1]) frozen weights -> the k-walk order of dp_conv1x1_fwd: [og][chunk][k][o] with output channel 64 og + o
+    and input channel 16 chunk + k (include/dorpatch_hip.h).  ``transpose``: the weights of the INPUT-GRADIENT convolution
+    (dx = conv1x1(dy, w^T)).  Plain tensor reshuffle, done once per frozen convolution."""
+    w = w.detach().float().reshape(w.shape[0], w.shape[1])
+    if transpose:
+        w = w.t()
+    O, C = w.shape
+    assert C % 16 == 0 and O % 64 == 0
+    return w.reshape(O // 64, 64, C // 16, 16).permute(0, 2, 3, 1).contiguous()
+
+
+def conv1x1_fwd(x, wt, ab=None, res=None, out=None):
+    """y = conv2d(x', w) [+ res] for x (N,C,H,W) and wt = pack_conv1x1_weights(w), on v_mfma_f32_32x32x2_f32.
+    ``ab`` (N,C,2) from ``gn_stats``: x' = relu(group_norm(x)) applied while staging (x is the RAW tensor), else x' = x.
+    ``res`` (N,O,H,W) is added in the epilogue; ``out`` may be ``res`` itself (in-place accumulation)."""
+    lib = _lib.load()
+    _chk(x, torch.float32, "x"), _chk(wt, torch.float32, "wt")
+    N, C, H, W = x.shape
+    O = wt.shape[0] * wt.shape[-1]
+    assert wt.numel() == C * O, (wt.shape, C, O)
+    if ab is not None:
+        _chk(ab, torch.float32, "ab")
+        assert ab.numel() == N * C * 2
+    if res is not None:
+        _chk(res, torch.float32, "res")
+        assert tuple(res.shape) == (N, O, H, W)
+    if out is None:
+        out = torch.empty((N, O, H, W), dtype=torch.float32, device=x.device)
+    else:
+        _chk(out, torch.float32, "out")
+        assert tuple(out.shape) == (N, O, H, W)
+    _lib.check(lib.dp_conv1x1_fwd(_p(x), _p(wt), _p(ab), _p(res), N, C, O, H * W, _p(out), _stream()), "dp_conv1x1_fwd")
+    return out
+
+
+def gn_stats(x, weight, bias, groups, eps, res=None):
+    """Statistics-only GroupNorm pass: (mean, rstd, ab, s) with s = x (+ res) and ab (N,C,2) the affine coefficients of
+    ``relu(group_norm(s))`` for a consumer that applies them itself (``conv1x1_fwd(..., ab=ab)``)."""
+    lib = _lib.load()
+    _chk(x, torch.float32, "x"), _chk(weight, torch.float32, "weight"), _chk(bias, torch.float32, "bias")
+    N, C = x.shape[0], x.shape[1]
+    HW = int(np.prod(x.shape[2:]))
+    mean = torch.empty((N * groups,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    ab = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
+    ssum = None
+    if res is not None:
+        _chk(res, torch.float32, "res")
+        assert res.shape == x.shape
+        ssum = torch.empty_like(x)
+    _lib.check(lib.dp_gn_stats(_p(x), _p(res), _p(ssum), _p(weight), _p(bias), N, C, HW, int(groups), float(eps),
+                               _p(mean), _p(rstd), _p(ab), _stream()), "dp_gn_stats")
+    return mean, rstd, ab, (x if res is None else ssum)
+
+
 # ---------------------------------------------------------------- a-8: fused GroupNorm + ReLU (frozen backbone)
 def gn_relu_supported(x, groups):
     """Shapes the fused kernel accepts: fp32 GPU NCHW, (C/groups)*H*W a multiple of 4 and < 2^20."""

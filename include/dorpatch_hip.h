@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DP_ABI_VERSION 8
+#define DP_ABI_VERSION 9
 #define DP_MAX_RECTS 4 /* occlusion windows per mask-table entry */
 
 typedef void *dp_stream_t; /* hipStream_t */
@@ -227,6 +227,23 @@ int dp_project_update(const dp_update_cfg_t *cfg, const float *x,
  * Measured against MIOpen by scripts/conv3x3_vs_miopen.py; routed per shape by dorpatch_amd/libconv.py. */
 int dp_conv3x3_fwd(const float *x, const float *wt, int N, int C, int O, int H, int W, float *y, dp_stream_t stream);
 
+/* ---- a-8: 1x1 / stride 1 convolutions of the frozen backbone on the matrix cores (round 5) ----
+ * (attack.py:222, 247 through the classifier: 33 of ResNetV2-50's 53 convolutions; until round 4 batched library GEMMs /
+ * MIOpen NHWC kernels.)  On the NCHW tensors as they lie:  y[n] (O x HW) = W (O x C) x[n] (C x HW), an exact-f32 fmaf chain
+ * over the input channels in ascending order on v_mfma_f32_32x32x2_f32 (deterministic).  The input gradient of the same
+ * convolution is the same entry point on dy with the TRANSPOSED weights packed.
+ * x (N,C,HW), y (N,O,HW) dense; C % 16 == 0, O % 64 == 0; HW % 4 == 0, or HW == 49 (the 7 x 7 planes; no `ab` there).
+ * wt = the weights pre-packed for the kernel's k-walk (frozen: packed once, dorpatch_amd/ops.py pack_conv1x1_weights):
+ *   wt[og][chunk][k][o] = w[64 og + o][16 chunk + k],     O/64 x C/16 x 16 x 64.
+ * ab  (may be NULL) (N,C,2): fold `relu(group_norm(x))` into the operand staging — the kernel reads the RAW x and applies
+ *     max(x * ab[n][c][0] + ab[n][c][1], 0) on the way to LDS, with the coefficients dp_gn_stats wrote: the normalised
+ *     activation never exists in HBM (saves its 4 B/elem write and 4 B/elem re-read).  Bit-identical to dp_gn_relu_fwd
+ *     followed by the plain convolution.
+ * res (may be NULL; may alias y) (N,O,HW): y = conv + res — the bottleneck's residual add, or the accumulation of a second
+ *     branch's input gradient, in the epilogue. */
+int dp_conv1x1_fwd(const float *x, const float *wt, const float *ab, const float *res, int N, int C, int O, int HW,
+                   float *y, dp_stream_t stream);
+
 /* ---- next-1  collect_failure (attack.py:384-406) / PatchCleanser (PatchCleanser.py:68-112) ----
  * pred[n] = argmax_k logits[n,k]  (first index on ties). */
 int dp_argmax(const float *logits, int N, int C, int32_t *pred,
@@ -252,6 +269,13 @@ int dp_gn_relu_fwd(const float *x, const float *res, float *sum_out, const float
 int dp_gn_relu_bwd(const float *dy, const float *dres, const float *x, const float *gamma,
                    const float *beta, const float *mean, const float *rstd, int N, int C, int HW,
                    int G, float *dx, dp_stream_t stream);
+/* Statistics-only form of dp_gn_relu_fwd (round 5), for consumers that apply the affine + ReLU themselves while staging
+ * their operand (dp_conv1x1_fwd / dp_conv3x3_fwd with `ab`): same reads, same exact two-pass mean / variance, same
+ * optional residual add (sum_out = x + res), but y is never written; instead ab (N,C,2) receives, per sample and channel,
+ * a = rstd * gamma[c] and b = beta[c] - mean * a — the coefficients dp_gn_relu_fwd's store phase uses.  mean / rstd as
+ * dp_gn_relu_fwd (the backward still needs them).  Traffic: 4 B/elem read (+ 4 read + 4 write with res). */
+int dp_gn_stats(const float *x, const float *res, float *sum_out, const float *gamma, const float *beta, int N, int C,
+                int HW, int G, float eps, float *mean, float *rstd, float *ab, dp_stream_t stream);
 /* Gather form of the backward, for a backward pass over only the EOT samples that still carry gradient (the CW hinge
  * of attack.py:16-23 gives an exactly zero logit gradient to every sample whose margin is met, and the frozen,
  * per-sample-normalised backbone then yields an exactly zero input gradient for it): output sample n (of M) takes its

@@ -400,6 +400,86 @@ def test_conv3x3_on_the_matrix_cores_matches_conv2d(N, C, O, S, small):
         np.testing.assert_allclose(got_dx.numpy(), want_dx.numpy(), rtol=0, atol=1e-5 * float(want_dx.abs().max()))
 
 
+CONV1X1_CASES = [   # (N, C, O, H, emulation-sized)
+    (3, 32, 64, 14, True),      # 1.3 tiles of 2.3 planes each, ragged last tile, 2 K-chunks (the double buffer)
+    (11, 16, 128, 7, True),     # flat mode: 9 whole images per tile + a ragged second tile, two output-channel groups, ONE chunk
+    (1, 16, 64, 28, True),      # 1.75 tiles inside one plane
+    (2, 64, 256, 56, False), (2, 256, 64, 56, False), (2, 256, 128, 56, False), (3, 128, 512, 28, False),
+    (3, 512, 128, 28, False), (3, 512, 256, 28, False), (5, 256, 1024, 14, False), (5, 1024, 256, 14, False),
+    (5, 1024, 512, 14, False), (19, 512, 2048, 7, False), (19, 2048, 512, 7, False), (10, 1024, 2048, 7, False),
+    (1, 256, 128, 96, False), (2, 512, 2048, 12, False), (1, 128, 512, 48, False),      # planes of a 384 x 384 input
+]
+
+
+@pytest.mark.parametrize("N,C,O,H,small", CONV1X1_CASES)
+def test_conv1x1_on_the_matrix_cores_matches_conv2d(N, C, O, H, small):
+    """dp_conv1x1_fwd (round 5: the backbone's 1x1 / 1 convolutions as an NCHW-in-place GEMM on v_mfma_f32_32x32x2_f32)
+    against F.conv2d, forward and — the same entry point on the transposed weights — input gradient: exact-f32
+    arithmetic, another summation order -> 1e-5 of the output scale; one-hot weights (output channel o copies input channel
+    (5 o + 3) % C) must be EXACT for every pixel of every image, incl. the seams between the images a tile spans and the
+    ragged last tile; `res` (the epilogue add) exact against the sum; in place (out = res) as well."""
+    import os
+    if DEV == "cpu" and not small:
+        pytest.skip("through the fibre emulation this case takes minutes: GPU only")
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(N, C, H, H, generator=g)
+    x[0] += torch.arange(float(H)).view(1, H, 1) * 0.1 + torch.arange(float(H)).view(1, 1, H) * 0.01
+    w = torch.randn(O, C, 1, 1, generator=g) / C ** 0.5
+    want = F.conv2d(x, w)
+    xd = x.to(DEV).contiguous()
+    wt = ops.pack_conv1x1_weights(w).to(DEV)
+    got = ops.conv1x1_fwd(xd, wt)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=1e-5 * float(want.abs().max()))
+    w1 = torch.zeros(O, C, 1, 1)
+    for o in range(O):
+        w1[o, (5 * o + 3) % C] = 1.0
+    got1 = ops.conv1x1_fwd(xd, ops.pack_conv1x1_weights(w1).to(DEV)).cpu()
+    assert torch.equal(got1, F.conv2d(x, w1))
+    # epilogue add: exactly (conv + res) as the kernel alone computes conv; and in place
+    res = torch.randn(N, O, H, H, generator=g)
+    got_r = ops.conv1x1_fwd(xd, wt, res=res.to(DEV))
+    assert torch.equal(got_r.cpu(), got.cpu() + res)
+    acc = res.to(DEV).clone()
+    ops.conv1x1_fwd(xd, wt, res=acc, out=acc)
+    assert torch.equal(acc.cpu(), got_r.cpu())
+    # input gradient = the same kernel on dy with the transposed weights
+    if C % 64 == 0:
+        dy = torch.randn(N, O, H, H, generator=g)
+        want_dx = torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1), (0, 0), (1, 1), False, (0, 0), 1,
+                                                      (True, False, False))[0]
+        got_dx = ops.conv1x1_fwd(dy.to(DEV).contiguous(), ops.pack_conv1x1_weights(w, transpose=True).to(DEV)).cpu()
+        np.testing.assert_allclose(got_dx.numpy(), want_dx.numpy(), rtol=0, atol=1e-5 * float(want_dx.abs().max()))
+
+
+CONV1X1_FOLD_CASES = [   # (N, C, O, H, emulation-sized)
+    (3, 32, 64, 14, True), (1, 64, 64, 28, True),
+    (2, 256, 64, 56, False), (3, 128, 512, 28, False), (5, 1024, 256, 14, False), (1, 256, 128, 96, False),
+]
+
+
+@pytest.mark.parametrize("N,C,O,H,small", CONV1X1_FOLD_CASES)
+def test_conv1x1_with_folded_groupnorm_is_bit_identical_to_the_two_kernels(N, C, O, H, small):
+    """dp_gn_stats + dp_conv1x1_fwd(ab) — GroupNorm-apply + ReLU while staging the operand — must equal
+    dp_gn_relu_fwd followed by the plain dp_conv1x1_fwd BIT FOR BIT (same statistics, same x * a + b, same MFMA walk), with
+    and without the residual add in front of the norm; mean / rstd / the sum are the GroupNorm kernel's own."""
+    if DEV == "cpu" and not small:
+        pytest.skip("through the fibre emulation this case takes minutes: GPU only")
+    G = 32
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(N, C, H, H, generator=g) * 1.5 + 0.3).to(DEV)
+    r = torch.randn(N, C, H, H, generator=g).to(DEV)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(C, generator=g) * 0.2).to(DEV)
+    wt = ops.pack_conv1x1_weights(torch.randn(O, C, 1, 1, generator=g) / C ** 0.5).to(DEV)
+    for res in (None, r):
+        y, mean, rstd, s = ops.gn_relu_fwd(x, gamma, beta, G, 1e-5, res=res)
+        want = ops.conv1x1_fwd(y, wt)
+        mean2, rstd2, ab, s2 = ops.gn_stats(x, gamma, beta, G, 1e-5, res=res)
+        assert torch.equal(mean2, mean) and torch.equal(rstd2, rstd) and torch.equal(s2, s)
+        got = ops.conv1x1_fwd(s2, wt, ab=ab)
+        assert torch.equal(got, want)
+
+
 # ---------------------------------------------------------------- fused GroupNorm + ReLU (backbone, a-8)
 GN_SHAPES = [  # (N, C, H, W): every (V, T) register variant, the HW = 49 per-lane channel path, streaming
     (3, 64, 56, 56),      # L4 = 1568  -> <4,512>
