@@ -92,7 +92,7 @@ def parse(argv=None):
                     help="1: torch.backends.cudnn.benchmark=True (MIOpen exhaustive find: minutes on a fresh box); "
                          "0: MIOpen immediate mode")
     ap.add_argument("--no-fused-gn", action="store_true", help="eager GroupNorm+ReLU instead of dp_gn_relu_*")
-    ap.add_argument("--conv1x1", default="table", choices=["table", "auto", "gemm", "miopen"],
+    ap.add_argument("--conv1x1", default="table", choices=["table", "auto", "gemm", "miopen", "mfma"],
                     help="library route of the backbone's frozen 1x1/1 convolutions: the committed per-shape gfx950 "
                          "table (deterministic, default), measured per shape at first use (auto), always the batched "
                          "GEMM, or always MIOpen (dorpatch_amd/conv1x1.py)")

@@ -42,7 +42,7 @@ import time
 import torch
 import torch.nn.functional as F
 
-MODES = ("table", "auto", "gemm", "miopen")
+MODES = ("table", "auto", "gemm", "miopen", "mfma")
 MODE = os.environ.get("DORPATCH_CONV1X1", "table")
 if MODE not in MODES:
     raise ValueError("DORPATCH_CONV1X1 must be one of %s, got %r" % (", ".join(MODES), MODE))
@@ -265,8 +265,18 @@ def _bwd_miopen(dy, w4d, x):
     return libconv.conv_bwd_data(dy, x, w4d)
 
 
-_IMPL = {("fwd", "gemm"): _fwd_gemm, ("fwd", "miopen"): _fwd_miopen,
-         ("bwd", "gemm"): _bwd_gemm, ("bwd", "miopen"): _bwd_miopen}
+def _fwd_mfma(x, w4d, _=None):
+    from . import libconv, ops
+    return ops.conv1x1_fwd(x, libconv.packed1(w4d, False))
+
+
+def _bwd_mfma(dy, w4d, x=None):
+    from . import libconv, ops
+    return ops.conv1x1_fwd(dy, libconv.packed1(w4d, True))
+
+
+_IMPL = {("fwd", "gemm"): _fwd_gemm, ("fwd", "miopen"): _fwd_miopen, ("fwd", "mfma"): _fwd_mfma,
+         ("bwd", "gemm"): _bwd_gemm, ("bwd", "miopen"): _bwd_miopen, ("bwd", "mfma"): _bwd_mfma}
 
 
 def _time_ms(fn, t, w4d, x):
@@ -300,6 +310,10 @@ def _pick(direction, t, w4d, x):
     HW = t.shape[2] * t.shape[3]
     if MODE in ("gemm", "miopen"):
         algo = MODE
+    elif MODE == "mfma":        # every shape dp_conv1x1_fwd takes on the hand-written kernel, the rest as the table says
+        from . import ops
+        algo = "mfma" if ops.conv1x1_supported(t, w4d if direction == "fwd" else w4d.transpose(0, 1)) else \
+            _from_table(direction, C, O, HW, t.is_cuda, t.shape[0])
     elif MODE == "table":
         algo = _from_table(direction, C, O, HW, t.is_cuda, t.shape[0])
     else:
@@ -389,9 +403,9 @@ def selftest_report():
 def report():
     """{"fwd": {"gemm": n, "miopen": m}, "bwd": {...}} over the distinct shapes routed so far (+ what the
     calibration measured, in auto mode)."""
-    out = {"fwd": {"gemm": 0, "miopen": 0}, "bwd": {"gemm": 0, "miopen": 0}}
+    out = {"fwd": {"gemm": 0, "miopen": 0, "mfma": 0}, "bwd": {"gemm": 0, "miopen": 0, "mfma": 0}}
     for key, algo in _used.items():
-        out[key[0]][algo] += 1
+        out[key[0]][algo] = out[key[0]].get(algo, 0) + 1
     if MODE == "auto":
         saved = 0.0
         for key in _choice:

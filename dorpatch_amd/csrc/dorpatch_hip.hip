@@ -26,6 +26,7 @@
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 typedef int i4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBlock = 256;  // threads per workgroup: 4 waves of 64
@@ -35,6 +36,8 @@ int g_aff_samples_per_block = 0;   // DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK (tools/k
 int g_update_variant = 0;          // DP_DEBUG_UPDATE_VARIANT
 int g_apply_order = 0;             // DP_DEBUG_APPLY_ORDER
 int g_aff_gather = 0;              // DP_DEBUG_AFFINE_GATHER
+int g_conv1x1_variant = 0;         // DP_DEBUG_CONV1X1_VARIANT: bits 0-1 workgroup map, bit 2 non-temporal stores, bit 3 barrier at the chunk's end,
+                                   // bit 4 short prefetch distance
 
 // Register-allocation hint: the compiler must forget what it knows about a lane-private value (so that it re-derives
 // addresses / predicates from it instead of keeping dozens of them alive).  No semantics; empty in the host emulation.
@@ -42,6 +45,15 @@ int g_aff_gather = 0;              // DP_DEBUG_AFFINE_GATHER
 #define DP_LAUNDER(v) ((void)0)
 #else
 #define DP_LAUNDER(v) asm volatile("" : "+v"(v))
+#endif
+
+// Workgroup barrier that waits for this wave's LDS traffic only (lgkmcnt), not for its global loads: __syncthreads()
+// also drains vmcnt, i.e. it would wait for prefetches that are meant to stay in flight ACROSS the barrier (they land in
+// the wave's own registers; the compiler still inserts the vmcnt wait in front of their first use).
+#ifdef HIPEMU_HOST
+#define DP_BARRIER_LDS() __syncthreads()
+#else
+#define DP_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
 #define DP_REQUIRE(cond)                                \
@@ -3110,9 +3122,14 @@ template <> struct CvVec<4> { typedef f4 T; };
 template <> struct CvVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
 template <> struct CvVec<1> { typedef float T; };
 
-template <int S>
+// FOLD (round 5): x is the RAW input of a GroupNorm + ReLU; max(x * a + b, 0) with the (N, C, 2) coefficients `ab` that
+// dp_gn_stats wrote is applied between the global load and the LDS store (dp_gn_relu_fwd's own expression: bit-identical
+// to normalising first).  Halo rows / the rows between images stay exactly zero (their coefficients are (0, 0)): the
+// convolution pads the NORMALISED activation.
+template <int S, bool FOLD>
 __global__ __launch_bounds__(kBlock, 2) void k_conv3x3_mfma(const float *__restrict__ x, const float *__restrict__ wt,
-                                                            float *__restrict__ y, int N, int C, int O) {
+                                                            float *__restrict__ y, int N, int C, int O,
+                                                            const float *__restrict__ ab) {
   typedef CvGeom<S> G;
   typedef typename CvVec<G::VW>::T vec_t;
   __shared__ __attribute__((aligned(16))) float lds[2 * G::BUF];
@@ -3134,6 +3151,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3_mfma(const float *__restr
   }
 
   vec_t pin[G::IT];
+  f2 pab[FOLD ? G::IT : 1];
   f4 pwt[kCvWtIt];
   // (For the planes below 56 x 56, fetch / stash re-derive their element decode from a LAUNDERED copy of the thread index
   // every time: left alone, hipcc keeps the per-iteration global and LDS offsets — 2 x IT values, loop-invariant — alive
@@ -3142,7 +3160,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3_mfma(const float *__restr
   // but 56 x 56 0.880 -> 0.927 (the 256-VGPR schedule with its 8 B of scratch is the faster one there), so not for S = 56.)
   auto fetch = [&](int chunk) {          // global -> registers
     int tl = tid;
-    if (S != 56) DP_LAUNDER(tl);
+    if (S != 56 || FOLD) DP_LAUNDER(tl);
 #pragma unroll
     for (int it = 0; it < G::IT; ++it) {
       const int i = tl + it * kBlock;
@@ -3151,9 +3169,15 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3_mfma(const float *__restr
       const int vr = vr0 + row;
       const int n = vr / (S + 1), h = vr - n * (S + 1);
       vec_t v = {};
-      if (i < G::NV && vr >= 0 && h < S && n < N)
+      const bool ok = i < G::NV && vr >= 0 && h < S && n < N;
+      if (ok)
         v = *reinterpret_cast<const vec_t *>(x + (((size_t)n * C + chunk * kCvCh + ch) * S + h) * S + q * G::VW);
       pin[it] = v;
+      if (FOLD) {       // unconditional load (entry 0 is always there), zero coefficients where there is no pixel
+        f2 c = *reinterpret_cast<const f2 *>(ab + 2 * (ok ? (size_t)n * C + chunk * kCvCh + ch : (size_t)0));
+        if (!ok) c = f2{0.f, 0.f};
+        pab[it] = c;
+      }
     }
     const f4 *wsrc = reinterpret_cast<const f4 *>(wtg + (size_t)chunk * kCvWtFloats);
 #pragma unroll
@@ -3165,13 +3189,20 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3_mfma(const float *__restr
   auto stash = [&](int buf) {            // registers -> LDS
     float *dst = lds + buf * G::BUF;
     int tl = tid;
-    if (S != 56) DP_LAUNDER(tl);
+    if (S != 56 || FOLD) DP_LAUNDER(tl);
 #pragma unroll
     for (int it = 0; it < G::IT; ++it) {
       const int i = tl + it * kBlock;
       const int ch = i / (G::ROWS * G::VPR), rem = i - ch * (G::ROWS * G::VPR);
       const int row = rem / G::VPR, q = rem - row * G::VPR;
-      if (i < G::NV) *reinterpret_cast<vec_t *>(dst + ch * G::CHS + row * G::PITCH + G::X0 + q * G::VW) = pin[it];
+      vec_t v = pin[it];
+      if (FOLD) {
+        const float a = pab[it].x, b = pab[it].y;
+        float *e = reinterpret_cast<float *>(&v);
+#pragma unroll
+        for (int k = 0; k < G::VW; ++k) e[k] = fmaxf(e[k] * a + b, 0.f);
+      }
+      if (i < G::NV) *reinterpret_cast<vec_t *>(dst + ch * G::CHS + row * G::PITCH + G::X0 + q * G::VW) = v;
     }
 #pragma unroll
     for (int it = 0; it < kCvWtIt; ++it) {
@@ -3276,8 +3307,6 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3_mfma(const float *__restr
 // gradient in the epilogue.
 // Workgroup ids are decoded XCD-aware (block b runs on XCD b % 8): the O / 64 channel groups of one pixel tile are
 // consecutive workgroups of ONE XCD, so a tile of x is fetched from HBM once and re-read from that XCD's L2.
-typedef float f2 __attribute__((ext_vector_type(2)));
-
 constexpr int kC1O = 64;                               // output channels per workgroup
 constexpr int kC1Pix = 448;                            // pixels per workgroup (14 fragments)
 constexpr int kC1Ch = 16;                              // input channels per K-chunk
@@ -3297,15 +3326,31 @@ struct C1Args {
   int tiles;            // pixel tiles
   int og;               // O / 64
   int spt;              // flat mode: images per tile (448 / HW)
+  int map;              // workgroup id -> (tile, oc group): 0 XCD-aware (product), 1 oc group fastest, 2 tile fastest (A/B knob)
+  int nt;               // non-temporal result stores (A/B knob)
 };
 
-template <int FHW, bool FOLD, bool RES>
+template <int FHW, bool FOLD, bool RES, bool ROT, bool PF2>
 __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
   __shared__ __attribute__((aligned(16))) float lds[2 * kC1Buf];
   constexpr bool FLAT = FHW != 0;
-  const int wg = blockIdx.x, xcd = wg & 7, slot = wg >> 3;
-  const int tl = slot / A.og, og = slot - tl * A.og;
-  const int tile = tl * 8 + xcd;
+  constexpr int FD = FLAT ? FHW : 1;                         // divisor of the flat-mode decodes (dead code in row mode)
+  int tile, og;
+  {
+    const int wg = blockIdx.x;
+    if (A.map == 0) {
+      const int xcd = wg & 7, slot = wg >> 3, tl = slot / A.og;
+      og = slot - tl * A.og;
+      tile = tl * 8 + xcd;
+    } else if (A.map == 1) {
+      tile = wg / A.og;
+      og = wg - tile * A.og;
+    } else {
+      const int tp = (A.tiles + 7) / 8 * 8;
+      og = wg / tp;
+      tile = wg - og * tp;
+    }
+  }
   if (tile >= A.tiles) return;                               // grid padded to a multiple of 8 tiles
   const int HW = FLAT ? FHW : A.HW;
   const int CHS = FLAT ? FHW : kC1Pix;                       // LDS stride between channels
@@ -3331,7 +3376,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
       xoff[it] = ok ? (n * A.C + ch) * HW + p : -1;
       aoff[it] = n * A.C + ch;
     } else {
-      const int s = j / (kC1Ch / 4 * FHW), f = j - s * (kC1Ch / 4 * FHW);
+      const int s = j / (kC1Ch / 4 * FD), f = j - s * (kC1Ch / 4 * FD);
       const bool ok = s < A.spt && n0 + s < A.N;
       xoff[it] = ok ? (n0 + s) * A.C * FHW + 4 * f : -1;
       aoff[it] = 0;
@@ -3379,7 +3424,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
     if (!FLAT) {
       boff[q] = half * kC1Pix + gl;
     } else {
-      int s = gl / FHW, p = gl - s * FHW;
+      int s = gl / FD, p = gl - s * FD;
       if (s >= A.spt) s = 0, p = 0;
       boff[q] = s * (kC1Ch * FHW) + half * FHW + p;
     }
@@ -3390,35 +3435,52 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
 
+  // Prefetch distance.  PF2 = false: chunk c + 1 is requested at the start of chunk c and stored half-way through it (half
+  // a chunk of MFMAs — ~1.5 us — to cover the load latency).  PF2 = true: chunk c + 2 is requested right after chunk c + 1
+  // went to LDS (the staging registers are free again), i.e. a whole chunk ahead; the loads stay in flight across the
+  // chunk's barrier, which therefore must not wait for vmcnt (DP_BARRIER_LDS).
   fetch(0);
   stash(0);
-  __syncthreads();
-  for (int chunk = 0; chunk < NCH; ++chunk) {
-    if (chunk + 1 < NCH) fetch(chunk + 1);
-    const float *cur = lds + (chunk & 1) * kC1Buf;
-    // the k-step software pipeline of k_conv3x3_mfma: step t + 1's 8 operands are requested before step t's 7 MFMAs
-    auto operands = [&](int t, float &a, float (&bv)[7]) {
-      a = cur[abase + t * 2 * kC1O];
+  if (PF2 && NCH > 1) fetch(1);
+  DP_BARRIER_LDS();
+  // the k-step software pipeline of k_conv3x3_mfma: step t + 1's 8 operands are requested before step t's 7 MFMAs
+  auto operands = [&](const float *cur, int t, float &a, float (&bv)[7]) {
+    a = cur[abase + t * 2 * kC1O];
 #pragma unroll
-      for (int q = 0; q < 7; ++q) bv[q] = cur[boff[q] + t * 2 * CHS];
-    };
-    float a0, b0[7], a1, b1[7];
-    operands(0, a0, b0);
+    for (int q = 0; q < 7; ++q) bv[q] = cur[boff[q] + t * 2 * CHS];
+  };
+  float a0, b0[7], a1, b1[7];
+  if (ROT) operands(lds, 0, a0, b0);
+  for (int chunk = 0; chunk < NCH; ++chunk) {
+    if (!PF2 && chunk + 1 < NCH) fetch(chunk + 1);
+    const float *cur = lds + (chunk & 1) * kC1Buf;
+    if (!ROT) operands(cur, 0, a0, b0);
 #pragma unroll
     for (int t = 0; t < kC1Steps; t += 2) {
-      operands(t + 1, a1, b1);
+      operands(cur, t + 1, a1, b1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[q], acc[q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (t == kC1Steps / 2 && chunk + 1 < NCH) stash((chunk + 1) & 1);     // the other buffer: nobody reads it now
-      if (t + 2 < kC1Steps) operands(t + 2, a0, b0);
+      if (t == kC1Steps / 2 && chunk + 1 < NCH) {
+        stash((chunk + 1) & 1);                                  // the other buffer: nobody reads it now
+        if (PF2 && chunk + 2 < NCH) fetch(chunk + 2);
+      }
+      if (t + 2 < kC1Steps) operands(cur, t + 2, a0, b0);
+      if (ROT && t + 2 == kC1Steps) {
+        // ROT: the chunk's barrier sits BEFORE its last k-step's MFMAs instead of after them.  Every read of this buffer
+        // has been issued (the last step's operands are in a1 / b1: the barrier waits for them) and every wave's store of
+        // the next chunk is done, so the next chunk's first operands can be requested now and land during these 7 MFMAs —
+        // with the barrier at the end, each chunk starts with an exposed LDS round trip.
+        DP_BARRIER_LDS();
+        if (chunk + 1 < NCH) operands(lds + ((chunk + 1) & 1) * kC1Buf, 0, a0, b0);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[q], acc[q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
+    if (!ROT) DP_BARRIER_LDS();
   }
 
   const int oc0 = og * kC1O + ocf * 32 + 4 * half;
@@ -3432,8 +3494,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
       ok = g < total;
       n = g / HW, p = g - n * HW;
     } else {
-      const int s = gl / FHW;
-      p = gl - s * FHW, n = n0 + s;
+      const int s = gl / FD;
+      p = gl - s * FD, n = n0 + s;
       ok = s < A.spt && n < A.N;
     }
     if (!ok) continue;
@@ -3445,7 +3507,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) r[v] = rq[(size_t)((v & 3) + 8 * (v >> 2)) * HW];
 #pragma unroll
-      for (int v = 0; v < 16; ++v) yq[(size_t)((v & 3) + 8 * (v >> 2)) * HW] = acc[q][v] + r[v];
+      for (int v = 0; v < 16; ++v) acc[q][v] += r[v];
+    }
+    if (A.nt) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) __builtin_nontemporal_store(acc[q][v], yq + (size_t)((v & 3) + 8 * (v >> 2)) * HW);
     } else {
 #pragma unroll
       for (int v = 0; v < 16; ++v) yq[(size_t)((v & 3) + 8 * (v >> 2)) * HW] = acc[q][v];
@@ -3453,10 +3519,19 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
   }
 }
 
-int launch_conv1x1(const C1Args &A, bool flat, hipStream_t st) {
+int launch_conv1x1(C1Args A, bool flat, hipStream_t st) {
   const dim3 grid((unsigned)(cdiv(A.tiles, 8) * 8 * A.og)), block(kBlock);
   const bool fold = A.ab != nullptr, res = A.res != nullptr;
-#define DP_LAUNCH_C1(FHW_, FOLD_, RES_) hipLaunchKernelGGL((k_conv1x1_mfma<FHW_, FOLD_, RES_>), grid, block, 0, st, A)
+  A.map = g_conv1x1_variant & 3;
+  A.nt = (g_conv1x1_variant >> 2) & 1;
+  const bool rot = !(g_conv1x1_variant & 8), pf2 = !(g_conv1x1_variant & 16);
+#define DP_LAUNCH_C1(FHW_, FOLD_, RES_)                                                                            \
+  do {                                                                                                             \
+    if (rot && pf2) hipLaunchKernelGGL((k_conv1x1_mfma<FHW_, FOLD_, RES_, true, true>), grid, block, 0, st, A);    \
+    else if (rot) hipLaunchKernelGGL((k_conv1x1_mfma<FHW_, FOLD_, RES_, true, false>), grid, block, 0, st, A);     \
+    else if (pf2) hipLaunchKernelGGL((k_conv1x1_mfma<FHW_, FOLD_, RES_, false, true>), grid, block, 0, st, A);     \
+    else hipLaunchKernelGGL((k_conv1x1_mfma<FHW_, FOLD_, RES_, false, false>), grid, block, 0, st, A);             \
+  } while (0)
   if (flat) {
     if (res) DP_LAUNCH_C1(49, false, true);
     else DP_LAUNCH_C1(49, false, false);
@@ -3515,6 +3590,10 @@ int dp_debug_set(int knob, int value) {
     case DP_DEBUG_AFFINE_GATHER:
       DP_REQUIRE(value == 0 || value == 1);
       g_aff_gather = value;
+      return 0;
+    case DP_DEBUG_CONV1X1_VARIANT:
+      DP_REQUIRE(value >= 0 && value < 32 && (value & 3) != 3);
+      g_conv1x1_variant = value;
       return 0;
     default:
       return (int)hipErrorInvalidValue;
@@ -3773,19 +3852,37 @@ int dp_project_update(const dp_update_cfg_t *cfg, const float *x, const float *a
   return launch_status();
 }
 
-int dp_conv3x3_fwd(const float *x, const float *wt, int N, int C, int O, int H, int W, float *y, dp_stream_t stream) {
+static int conv3x3_launch(const float *x, const float *wt, const float *ab, int N, int C, int O, int H, int W, float *y,
+                          dp_stream_t stream) {
   DP_REQUIRE(x && wt && y && aligned16(x) && aligned16(wt) && aligned16(y));
   DP_REQUIRE(N > 0 && C > 0 && C % kCvCh == 0 && O > 0 && O % kCvO == 0 && O / kCvO <= 65535 && H == W);
   DP_REQUIRE(H == 56 || H == 28 || H == 14 || H == 7);
+  DP_REQUIRE(!ab || (H != 7 && (reinterpret_cast<uintptr_t>(ab) & 7u) == 0));   // no fold on the 7 x 7 planes (17 scalar items per lane)
   DP_REQUIRE((long)N * H * W + kCvPix < (1L << 31));      // 32-bit pixel arithmetic in the kernel
   const long tiles = ((long)N * H * W + kCvPix - 1) / kCvPix;
   const dim3 grid((unsigned)tiles, O / kCvO), block(kBlock);
   hipStream_t st = as_stream(stream);
-  if (H == 56) hipLaunchKernelGGL(k_conv3x3_mfma<56>, grid, block, 0, st, x, wt, y, N, C, O);
-  else if (H == 28) hipLaunchKernelGGL(k_conv3x3_mfma<28>, grid, block, 0, st, x, wt, y, N, C, O);
-  else if (H == 14) hipLaunchKernelGGL(k_conv3x3_mfma<14>, grid, block, 0, st, x, wt, y, N, C, O);
-  else hipLaunchKernelGGL(k_conv3x3_mfma<7>, grid, block, 0, st, x, wt, y, N, C, O);
+  if (ab) {
+    if (H == 56) hipLaunchKernelGGL((k_conv3x3_mfma<56, true>), grid, block, 0, st, x, wt, y, N, C, O, ab);
+    else if (H == 28) hipLaunchKernelGGL((k_conv3x3_mfma<28, true>), grid, block, 0, st, x, wt, y, N, C, O, ab);
+    else hipLaunchKernelGGL((k_conv3x3_mfma<14, true>), grid, block, 0, st, x, wt, y, N, C, O, ab);
+    return launch_status();
+  }
+  if (H == 56) hipLaunchKernelGGL((k_conv3x3_mfma<56, false>), grid, block, 0, st, x, wt, y, N, C, O, ab);
+  else if (H == 28) hipLaunchKernelGGL((k_conv3x3_mfma<28, false>), grid, block, 0, st, x, wt, y, N, C, O, ab);
+  else if (H == 14) hipLaunchKernelGGL((k_conv3x3_mfma<14, false>), grid, block, 0, st, x, wt, y, N, C, O, ab);
+  else hipLaunchKernelGGL((k_conv3x3_mfma<7, false>), grid, block, 0, st, x, wt, y, N, C, O, ab);
   return launch_status();
+}
+
+int dp_conv3x3_fwd(const float *x, const float *wt, int N, int C, int O, int H, int W, float *y, dp_stream_t stream) {
+  return conv3x3_launch(x, wt, nullptr, N, C, O, H, W, y, stream);
+}
+
+int dp_conv3x3_gn_fwd(const float *x, const float *wt, const float *ab, int N, int C, int O, int H, int W, float *y,
+                      dp_stream_t stream) {
+  DP_REQUIRE(ab);
+  return conv3x3_launch(x, wt, ab, N, C, O, H, W, y, stream);
 }
 
 int dp_conv1x1_fwd(const float *x, const float *wt, const float *ab, const float *res, int N, int C, int O, int HW,

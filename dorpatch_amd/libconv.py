@@ -70,21 +70,42 @@ def _conv3x3_route(direction, x, w, stride, padding):
     return use
 
 
-def _packed3(w, transpose):
-    """pack_conv3x3_weights(w[, transposed + flipped]) cached on the weight tensor (dies with it; invalidated by an in-place
-    update or a move to another device)."""
-    from . import ops
-    key = (bool(transpose), w._version, w.data_ptr(), str(w.device))
-    cache = getattr(w, "_dp_conv3x3_pack", None)
-    if cache is None or cache[0] != key[1:]:
-        cache = (key[1:], {})
+def _packed(w, kind, make):
+    """``make()`` cached on the weight tensor under ``kind`` (dies with the tensor; invalidated by an in-place update that
+    bumps its version or by a move to another device).  Only FROZEN weights are routed here (``requires_grad`` False is
+    checked by the callers): a write through ``w.data`` does not bump the version — call ``clear_packs(w)`` after one."""
+    key = (w._version, w.data_ptr(), str(w.device))
+    cache = getattr(w, "_dp_conv_pack", None)
+    if cache is None or cache[0] != key:
+        cache = (key, {})
         try:
-            w._dp_conv3x3_pack = cache
+            w._dp_conv_pack = cache
         except AttributeError:      # a tensor type that refuses attributes: pack every time
             pass
-    if key[0] not in cache[1]:
-        cache[1][key[0]] = ops.pack_conv3x3_weights(w, transpose=transpose)
-    return cache[1][key[0]]
+    if kind not in cache[1]:
+        cache[1][kind] = make()
+    return cache[1][kind]
+
+
+def clear_packs(w):
+    """Forget the packed copies of ``w`` (after editing a frozen weight through ``w.data``)."""
+    if getattr(w, "_dp_conv_pack", None) is not None:
+        try:
+            del w._dp_conv_pack
+        except AttributeError:
+            pass
+
+
+def _packed3(w, transpose):
+    """pack_conv3x3_weights(w[, transposed + flipped]), cached."""
+    from . import ops
+    return _packed(w, ("3x3", bool(transpose)), lambda: ops.pack_conv3x3_weights(w, transpose=transpose))
+
+
+def packed1(w, transpose):
+    """pack_conv1x1_weights(w[, transposed]), cached."""
+    from . import ops
+    return _packed(w, ("1x1", bool(transpose)), lambda: ops.pack_conv1x1_weights(w, transpose=transpose))
 
 
 def report_conv3x3():

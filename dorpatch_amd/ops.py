@@ -364,15 +364,24 @@ def pack_conv3x3_weights(w, transpose=False):
     return w.reshape(O // 64, 64, C // 8, 4, 2, 3, 3).permute(0, 2, 3, 5, 6, 4, 1).contiguous()
 
 
-def conv3x3_fwd(x, wt):
-    """y = conv2d(x, w, stride 1, padding 1) for x (N,C,S,S), wt = pack_conv3x3_weights(w), on v_mfma_f32_32x32x2_f32."""
+CONV3X3_FOLD_SIDES = (56, 28, 14)
+
+
+def conv3x3_fwd(x, wt, ab=None):
+    """y = conv2d(x', w, stride 1, padding 1) for x (N,C,S,S), wt = pack_conv3x3_weights(w), on v_mfma_f32_32x32x2_f32.
+    ``ab`` (N,C,2) from ``gn_stats``: x' = relu(group_norm(x)) applied while staging (x is the RAW tensor; S in 56/28/14)."""
     lib = _lib.load()
     _chk(x, torch.float32, "x"), _chk(wt, torch.float32, "wt")
     N, C, H, W = x.shape
     O = wt.shape[0] * wt.shape[-1]
     assert wt.numel() == C * 9 * O
     y = torch.empty((N, O, H, W), dtype=torch.float32, device=x.device)
-    _lib.check(lib.dp_conv3x3_fwd(_p(x), _p(wt), N, C, O, H, W, _p(y), _stream()), "dp_conv3x3_fwd")
+    if ab is None:
+        _lib.check(lib.dp_conv3x3_fwd(_p(x), _p(wt), N, C, O, H, W, _p(y), _stream()), "dp_conv3x3_fwd")
+    else:
+        _chk(ab, torch.float32, "ab")
+        assert ab.numel() == N * C * 2
+        _lib.check(lib.dp_conv3x3_gn_fwd(_p(x), _p(wt), _p(ab), N, C, O, H, W, _p(y), _stream()), "dp_conv3x3_gn_fwd")
     return y
 
 

@@ -58,11 +58,17 @@ const char *dp_error_string(int err);
  *                                      less HBM traffic, measured 19 % slower); 0: tile-fastest 3-D grid (one ascending
  *                                      output stream)
  *   DP_DEBUG_AFFINE_GATHER             dp_apply_affine_bwd: 1 = branch-free gather loop (same candidates, same order, same
- *                                      bits; measured 34 % slower); 0: a branch per candidate */
+ *                                      bits; measured 34 % slower); 0: a branch per candidate
+ *   DP_DEBUG_CONV1X1_VARIANT           dp_conv1x1_fwd: bits 0-1 workgroup id -> (pixel tile, channel group): 0 XCD-aware
+ *                                      (a tile's channel groups adjacent on one XCD), 1 channel group fastest, 2 tile
+ *                                      fastest; bit 2 non-temporal result stores; bit 3 chunk barrier after (not before) the
+ *                                      chunk's last k-step; bit 4 next chunk requested half a chunk ahead (not a whole one).
+ *                                      Same bits out of every variant */
 #define DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK 1
 #define DP_DEBUG_UPDATE_VARIANT 2
 #define DP_DEBUG_APPLY_ORDER 3
 #define DP_DEBUG_AFFINE_GATHER 4
+#define DP_DEBUG_CONV1X1_VARIANT 5
 int dp_debug_set(int knob, int value);
 
 /* ---- a-2  utils.clip (utils.py:105-110) + adv_x = delta + x (attack.py:184-185) ---- */
@@ -226,6 +232,11 @@ int dp_project_update(const dp_update_cfg_t *cfg, const float *x,
  * (w'[c][o][kh][kw] = w[o][c][2-kh][2-kw]).  Deterministic (fixed summation order: channels ascending, taps row-major).
  * Measured against MIOpen by scripts/conv3x3_vs_miopen.py; routed per shape by dorpatch_amd/libconv.py. */
 int dp_conv3x3_fwd(const float *x, const float *wt, int N, int C, int O, int H, int W, float *y, dp_stream_t stream);
+/* The same convolution of relu(group_norm(x)), the GroupNorm-apply + ReLU folded into the operand staging (round 5): x is
+ * the RAW tensor, ab (N,C,2) the coefficients dp_gn_stats wrote; bit-identical to dp_gn_relu_fwd followed by dp_conv3x3_fwd
+ * (the zero padding pads the normalised activation).  H = W in {56, 28, 14}. */
+int dp_conv3x3_gn_fwd(const float *x, const float *wt, const float *ab, int N, int C, int O, int H, int W, float *y,
+                      dp_stream_t stream);
 
 /* ---- a-8: 1x1 / stride 1 convolutions of the frozen backbone on the matrix cores (round 5) ----
  * (attack.py:222, 247 through the classifier: 33 of ResNetV2-50's 53 convolutions; until round 4 batched library GEMMs /

@@ -400,6 +400,33 @@ def test_conv3x3_on_the_matrix_cores_matches_conv2d(N, C, O, S, small):
         np.testing.assert_allclose(got_dx.numpy(), want_dx.numpy(), rtol=0, atol=1e-5 * float(want_dx.abs().max()))
 
 
+CONV3X3_FOLD_CASES = [   # (N, C, O, S, emulation-sized)
+    (2, 32, 64, 28, True), (3, 32, 64, 14, True), (1, 32, 64, 56, False),
+    (3, 64, 64, 56, False), (5, 128, 128, 28, False), (9, 256, 256, 14, False),
+]
+
+
+@pytest.mark.parametrize("N,C,O,S,small", CONV3X3_FOLD_CASES)
+def test_conv3x3_with_folded_groupnorm_is_bit_identical_to_the_two_kernels(N, C, O, S, small):
+    """dp_gn_stats + dp_conv3x3_gn_fwd == dp_gn_relu_fwd + dp_conv3x3_fwd, bit for bit: the fold applies the
+    GroupNorm kernel's own expression while staging, and the zero padding (image borders, the rows between the images a tile
+    spans) pads the NORMALISED activation — a beta > 0 would leak into the halo if the transform touched it."""
+    if DEV == "cpu" and not small:
+        pytest.skip("through the fibre emulation this case takes minutes: GPU only")
+    G = 32
+    g = torch.Generator().manual_seed(C + S)
+    x = (torch.randn(N, C, S, S, generator=g) * 1.5 + 0.3).to(DEV)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    beta = (torch.randn(C, generator=g) * 0.2 + 1.0).to(DEV)        # mostly positive: relu(beta) != 0 in a polluted halo
+    wt = ops.pack_conv3x3_weights(torch.randn(O, C, 3, 3, generator=g) / (3.0 * C ** 0.5)).to(DEV)
+    y, mean, rstd, _ = ops.gn_relu_fwd(x, gamma, beta, G, 1e-5)
+    want = ops.conv3x3_fwd(y, wt)
+    mean2, rstd2, ab, _ = ops.gn_stats(x, gamma, beta, G, 1e-5)
+    assert torch.equal(mean2, mean) and torch.equal(rstd2, rstd)
+    got = ops.conv3x3_fwd(x, wt, ab=ab)
+    assert torch.equal(got, want)
+
+
 CONV1X1_CASES = [   # (N, C, O, H, emulation-sized)
     (3, 32, 64, 14, True),      # 1.3 tiles of 2.3 planes each, ragged last tile, 2 K-chunks (the double buffer)
     (11, 16, 128, 7, True),     # flat mode: 9 whole images per tile + a ragged second tile, two output-channel groups, ONE chunk
@@ -449,6 +476,25 @@ def test_conv1x1_on_the_matrix_cores_matches_conv2d(N, C, O, H, small):
                                                       (True, False, False))[0]
         got_dx = ops.conv1x1_fwd(dy.to(DEV).contiguous(), ops.pack_conv1x1_weights(w, transpose=True).to(DEV)).cpu()
         np.testing.assert_allclose(got_dx.numpy(), want_dx.numpy(), rtol=0, atol=1e-5 * float(want_dx.abs().max()))
+
+
+def test_conv1x1_launch_variants_are_bit_identical():
+    """dp_debug_set(DP_DEBUG_CONV1X1_VARIANT): the workgroup-id maps, non-temporal stores, the barrier placement and the
+    prefetch distance are A/B knobs for measurements — every combination must produce the same bits (tile count not a multiple of 8, three
+    output-channel groups, 2 K-chunks)."""
+    from dorpatch_amd import _lib
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(5, 32, 14, 14, generator=g).to(DEV)
+    wt = ops.pack_conv1x1_weights(torch.randn(192, 32, 1, 1, generator=g)).to(DEV)
+    try:
+        outs = []
+        for variant in (0, 1, 2, 4, 8, 14, 16, 24, 30):
+            ops.debug_set(_lib.DP_DEBUG_CONV1X1_VARIANT, variant)
+            outs.append(ops.conv1x1_fwd(x, wt).cpu())
+    finally:
+        ops.debug_set(_lib.DP_DEBUG_CONV1X1_VARIANT, 0)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
 
 
 CONV1X1_FOLD_CASES = [   # (N, C, O, H, emulation-sized)
