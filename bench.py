@@ -92,6 +92,10 @@ def parse(argv=None):
                     help="1: torch.backends.cudnn.benchmark=True (MIOpen exhaustive find: minutes on a fresh box); "
                          "0: MIOpen immediate mode")
     ap.add_argument("--no-fused-gn", action="store_true", help="eager GroupNorm+ReLU instead of dp_gn_relu_*")
+    ap.add_argument("--gn-fold", default=None, choices=["on", "off"],
+                    help="round 5: GroupNorm-apply + ReLU folded into the consuming convolution's operand staging and the "
+                         "residual add into the producing convolution's epilogue (default: on, or DORPATCH_GNFOLD=0); off = "
+                         "the round-4 graph (A/B)")
     ap.add_argument("--conv1x1", default="table", choices=["table", "auto", "gemm", "miopen", "mfma"],
                     help="library route of the backbone's frozen 1x1/1 convolutions: the committed per-shape gfx950 "
                          "table (deterministic, default), measured per shape at first use (auto), always the batched "
@@ -523,9 +527,11 @@ def main(argv=None):
 
     from dorpatch_amd.attack import DorPatch, HotLoop
     torch.backends.cudnn.benchmark = bool(args.find)   # reference utils.py:17 sets True (MIOpen find)
+    from dorpatch_amd.resnetv2 import GroupNormAct
     if args.no_fused_gn:
-        from dorpatch_amd.resnetv2 import GroupNormAct
         GroupNormAct.fused = False
+    if args.gn_fold is not None:
+        GroupNormAct.fold = args.gn_fold == "on"
     from dorpatch_amd import conv1x1, libconv as _libconv
     conv1x1.MODE = args.conv1x1
     if args.conv3x3 is not None:
@@ -650,7 +656,7 @@ def main(argv=None):
                                                           args.patch_budget),
                        "images": B, "masks_per_image_per_gpu": S_local, "masks_per_image_total": S,
                        "image_size": H, "micro_batch": args.micro_batch, "miopen_find": bool(args.find),
-                       "fused_gn_relu": not args.no_fused_gn, "trace": loop.phases.mode, "deterministic": "%s: %s" % (args.deterministic, det_report), "deterministic_forced_problems": det_forced,
+                       "fused_gn_relu": not args.no_fused_gn, "gn_fold": bool(GroupNormAct.fold), "trace": loop.phases.mode, "deterministic": "%s: %s" % (args.deterministic, det_report), "deterministic_forced_problems": det_forced,
                        "backward": {"skip_satisfied": args.skip_satisfied == "on", "explicit_tape": bool(loop._taped),
                                     "samples_forward": loop.n_forward, "samples_with_gradient": loop.n_active,
                                     "samples_back_propagated": loop.n_backward, "tape_micro_batches": loop._tape_tabs,

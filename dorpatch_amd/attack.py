@@ -102,6 +102,7 @@ class _ImageState(object):
         self.y = int(y)
         self.failed_idxs = []
         self.certifiable = False
+        self.steps_in_stage = 0
         self.reset_stage()
 
     def reset_stage(self):
@@ -111,7 +112,6 @@ class _ImageState(object):
         self.not_decay = 0
         self.num_failure = np.inf
         self.active = True
-        self.steps_in_stage = 0
 
     def n_from_failure(self, i, sampling_size, start):
         """attack.py:193."""
@@ -699,6 +699,7 @@ class HotLoop(object):
             self.stage = stage
             for s in self.img:
                 s.reset_stage()
+                s.steps_in_stage = 0        # per stage, not per reset: the untargeted -> targeted switch resets mid-stage
             mpath = os.path.join(dir_0, "adv_mask_%d.pt" % self.batch_id)
             # every rank follows rank 0's view of the cache (skipping stage 0 on one rank only would deadlock)
             if stage == 0 and dp_dist.broadcast_object(os.path.exists(mpath), o.pg):   # attack.py:134-141
@@ -824,7 +825,10 @@ class HotLoop(object):
         if stage == 0 and i == self.switch_iteration and not all(self._flags("flag_targeted")):
             preds = self.pred_host
             for b, st in enumerate(self.img):
-                if st.flag_targeted:
+                # an image that early-stopped before the switch has LEFT stage 0, as the reference's one-image loop does at
+                # attack.py:311-316 (no switch is ever reached there): it must not be revived with loss_best = inf — its
+                # saved best mask / pattern would be overwritten; _finish_stage sets its target at the stage's end
+                if st.flag_targeted or not st.active:
                     continue
                 st.flag_targeted = True
                 if self._set_target(b, preds[b]):

@@ -194,22 +194,19 @@ def _agree(pg):
         mine = _local_verdict(selftest=(rank == 0))
     lead = bool(dp_dist.broadcast_object(bool(mine), pg))
     _tuned_verdict = dp_dist.all_true(bool(mine) and lead, pg)
-    _agreed.add(id(pg))
-
-
-_agreed = set()          # ids of the process groups whose ranks have agreed on the verdict
 
 
 def activate(pg=None, device_is_cuda=True):
     """Enter a tuned-solution scope (see the life-cycle note above); -> whether the tuned solutions are in effect.
-    With a process group the first call per group is collective (``_agree``); without one the verdict is this process's
-    own and is cached — a later activate(pg) still runs the agreement."""
+    With a process group every call is collective (``_agree``); without one the verdict is this process's own and is
+    cached — a later activate(pg) still runs the agreement."""
     global _tuned_verdict, _tuned_scope, _tuned_prev
     if not device_is_cuda:
         return False
     if pg is not None:
-        if id(pg) not in _agreed:
-            _agree(pg)
+        # every activate(pg) runs the two (cheap) collectives: a cache keyed on the group object's address could hit on some
+        # ranks and miss on others after a group was destroyed and another created at the same address — a collective mismatch
+        _agree(pg)
     elif _tuned_verdict is None:
         _tuned_verdict = _local_verdict(selftest=True)
     if not _tuned_verdict:

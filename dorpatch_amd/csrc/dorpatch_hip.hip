@@ -36,8 +36,7 @@ int g_aff_samples_per_block = 0;   // DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK (tools/k
 int g_update_variant = 0;          // DP_DEBUG_UPDATE_VARIANT
 int g_apply_order = 0;             // DP_DEBUG_APPLY_ORDER
 int g_aff_gather = 0;              // DP_DEBUG_AFFINE_GATHER
-int g_conv1x1_variant = 0;         // DP_DEBUG_CONV1X1_VARIANT: bits 0-1 workgroup map, bit 2 non-temporal stores, bit 3 barrier at the chunk's end,
-                                   // bit 4 short prefetch distance
+int g_conv1x1_variant = 0;         // DP_DEBUG_CONV1X1_VARIANT: bits 0-1 workgroup map, bit 2 non-temporal stores, bit 3 LDS staging in one lump
 
 // Register-allocation hint: the compiler must forget what it knows about a lane-private value (so that it re-derives
 // addresses / predicates from it instead of keeping dozens of them alive).  No semantics; empty in the host emulation.
@@ -3330,7 +3329,7 @@ struct C1Args {
   int nt;               // non-temporal result stores (A/B knob)
 };
 
-template <int FHW, bool FOLD, bool RES, bool ROT, bool PF2>
+template <int FHW, bool FOLD, bool RES, bool SPREAD>
 __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
   __shared__ __attribute__((aligned(16))) float lds[2 * kC1Buf];
   constexpr bool FLAT = FHW != 0;
@@ -3396,22 +3395,23 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
     }
     pwt = *reinterpret_cast<const f4 *>(wtg + (size_t)chunk * kC1Wt);
   };
-  auto stash = [&](int buf) {            // registers -> LDS (flat copy), with the fused GroupNorm-apply + ReLU
-    float *dst = lds + buf * kC1Buf;
-#pragma unroll
-    for (int it = 0; it < kC1It; ++it) {
-      f4 v = pin[it];
-      if (FOLD) {                        // dp_gn_relu_fwd's own expression: x * a + b (not fused), max 0
-        const float a = pab[it].x, b = pab[it].y;
-        v.x = fmaxf(v.x * a + b, 0.f);
-        v.y = fmaxf(v.y * a + b, 0.f);
-        v.z = fmaxf(v.z * a + b, 0.f);
-        v.w = fmaxf(v.w * a + b, 0.f);
-      }
-      if (xoff[it] < 0) v = f4{0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f4 *>(dst + 4 * (tid + it * kBlock)) = v;
+  auto stash_item = [&](int buf, int it) {   // registers -> LDS (flat copy), with the fused GroupNorm-apply + ReLU
+    f4 v = pin[it];
+    if (FOLD) {                          // dp_gn_relu_fwd's own expression: x * a + b (not fused), max 0
+      const float a = pab[it].x, b = pab[it].y;
+      v.x = fmaxf(v.x * a + b, 0.f);
+      v.y = fmaxf(v.y * a + b, 0.f);
+      v.z = fmaxf(v.z * a + b, 0.f);
+      v.w = fmaxf(v.w * a + b, 0.f);
     }
-    *reinterpret_cast<f4 *>(dst + kC1In + 4 * tid) = pwt;
+    if (xoff[it] < 0) v = f4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f4 *>(lds + buf * kC1Buf + 4 * (tid + it * kBlock)) = v;
+  };
+  auto stash_w = [&](int buf) { *reinterpret_cast<f4 *>(lds + buf * kC1Buf + kC1In + 4 * tid) = pwt; };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < kC1It; ++it) stash_item(buf, it);
+    stash_w(buf);
   };
 
   // lane bases: A = weights [channel][oc]; B = the lane's pixel of each of its 7 fragments, channel parity = half.
@@ -3435,26 +3435,33 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
 
-  // Prefetch distance.  PF2 = false: chunk c + 1 is requested at the start of chunk c and stored half-way through it (half
-  // a chunk of MFMAs — ~1.5 us — to cover the load latency).  PF2 = true: chunk c + 2 is requested right after chunk c + 1
-  // went to LDS (the staging registers are free again), i.e. a whole chunk ahead; the loads stay in flight across the
-  // chunk's barrier, which therefore must not wait for vmcnt (DP_BARRIER_LDS).
+  // Pipeline of one chunk (8 k-steps = 8 groups of 7 MFMAs per wave):
+  //   * step t + 1's 8 operands are requested before step t's MFMAs (the k-step pipeline of k_conv3x3_mfma);
+  //   * chunk c + 1 goes from the staging registers to the other LDS buffer DURING chunk c — SPREAD: one float4 item (with its
+  //     GroupNorm-apply) after each of the MFMA groups 0..6, so every piece hides behind a group; else all of it after group 4;
+  //   * the chunk's barrier sits BEFORE the last group's MFMAs: every read of this buffer has been issued by then (the last
+  //     step's operands are in a1 / b1, and the barrier waits for them) and every wave's store of the next chunk is done, so
+  //     the next chunk's first operands are requested right after it and land during those 7 MFMAs (with the barrier at the
+  //     end every chunk started with an exposed LDS round trip);
+  //   * chunk c + 2 is requested from global memory right after that barrier (the staging registers are free again): a whole
+  //     chunk (~3 us) ahead — requested half a chunk ahead, 512 -> 128 @28^2 ran 13 % and 1024 -> 512 @14^2 15 % slower
+  //     (profiles/r05b_kbench_conv1x1_variants.txt: variants 16 / 24).  The loads stay in flight across the next barrier,
+  //     which therefore waits for LDS traffic only (DP_BARRIER_LDS).
   fetch(0);
   stash(0);
-  if (PF2 && NCH > 1) fetch(1);
+  if (NCH > 1) fetch(1);
   DP_BARRIER_LDS();
-  // the k-step software pipeline of k_conv3x3_mfma: step t + 1's 8 operands are requested before step t's 7 MFMAs
   auto operands = [&](const float *cur, int t, float &a, float (&bv)[7]) {
     a = cur[abase + t * 2 * kC1O];
 #pragma unroll
     for (int q = 0; q < 7; ++q) bv[q] = cur[boff[q] + t * 2 * CHS];
   };
   float a0, b0[7], a1, b1[7];
-  if (ROT) operands(lds, 0, a0, b0);
+  operands(lds, 0, a0, b0);
   for (int chunk = 0; chunk < NCH; ++chunk) {
-    if (!PF2 && chunk + 1 < NCH) fetch(chunk + 1);
     const float *cur = lds + (chunk & 1) * kC1Buf;
-    if (!ROT) operands(cur, 0, a0, b0);
+    const bool more = chunk + 1 < NCH;
+    const int nb = (chunk + 1) & 1;
 #pragma unroll
     for (int t = 0; t < kC1Steps; t += 2) {
       operands(cur, t + 1, a1, b1);
@@ -3462,25 +3469,29 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
 #pragma unroll
       for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[q], acc[q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (t == kC1Steps / 2 && chunk + 1 < NCH) {
-        stash((chunk + 1) & 1);                                  // the other buffer: nobody reads it now
-        if (PF2 && chunk + 2 < NCH) fetch(chunk + 2);
+      if (more) {
+        if (SPREAD) {
+          stash_item(nb, t);
+        } else if (t == kC1Steps / 2) {
+          stash(nb);
+        }
       }
-      if (t + 2 < kC1Steps) operands(cur, t + 2, a0, b0);
-      if (ROT && t + 2 == kC1Steps) {
-        // ROT: the chunk's barrier sits BEFORE its last k-step's MFMAs instead of after them.  Every read of this buffer
-        // has been issued (the last step's operands are in a1 / b1: the barrier waits for them) and every wave's store of
-        // the next chunk is done, so the next chunk's first operands can be requested now and land during these 7 MFMAs —
-        // with the barrier at the end, each chunk starts with an exposed LDS round trip.
+      if (t + 2 < kC1Steps) {
+        operands(cur, t + 2, a0, b0);
+      } else {
         DP_BARRIER_LDS();
-        if (chunk + 1 < NCH) operands(lds + ((chunk + 1) & 1) * kC1Buf, 0, a0, b0);
+        if (more) operands(lds + nb * kC1Buf, 0, a0, b0);
+        if (chunk + 2 < NCH) fetch(chunk + 2);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[q], acc[q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      if (SPREAD && more && t + 2 < kC1Steps) {
+        stash_item(nb, t + 1);
+        if (t == 0) stash_w(nb);
+      }
     }
-    if (!ROT) DP_BARRIER_LDS();
   }
 
   const int oc0 = og * kC1O + ocf * 32 + 4 * half;
@@ -3524,13 +3535,11 @@ int launch_conv1x1(C1Args A, bool flat, hipStream_t st) {
   const bool fold = A.ab != nullptr, res = A.res != nullptr;
   A.map = g_conv1x1_variant & 3;
   A.nt = (g_conv1x1_variant >> 2) & 1;
-  const bool rot = !(g_conv1x1_variant & 8), pf2 = !(g_conv1x1_variant & 16);
-#define DP_LAUNCH_C1(FHW_, FOLD_, RES_)                                                                            \
-  do {                                                                                                             \
-    if (rot && pf2) hipLaunchKernelGGL((k_conv1x1_mfma<FHW_, FOLD_, RES_, true, true>), grid, block, 0, st, A);    \
-    else if (rot) hipLaunchKernelGGL((k_conv1x1_mfma<FHW_, FOLD_, RES_, true, false>), grid, block, 0, st, A);     \
-    else if (pf2) hipLaunchKernelGGL((k_conv1x1_mfma<FHW_, FOLD_, RES_, false, true>), grid, block, 0, st, A);     \
-    else hipLaunchKernelGGL((k_conv1x1_mfma<FHW_, FOLD_, RES_, false, false>), grid, block, 0, st, A);             \
+  const bool spread = !(g_conv1x1_variant & 8);
+#define DP_LAUNCH_C1(FHW_, FOLD_, RES_)                                                                      \
+  do {                                                                                                       \
+    if (spread) hipLaunchKernelGGL((k_conv1x1_mfma<FHW_, FOLD_, RES_, true>), grid, block, 0, st, A);        \
+    else hipLaunchKernelGGL((k_conv1x1_mfma<FHW_, FOLD_, RES_, false>), grid, block, 0, st, A);              \
   } while (0)
   if (flat) {
     if (res) DP_LAUNCH_C1(49, false, true);
@@ -3592,7 +3601,7 @@ int dp_debug_set(int knob, int value) {
       g_aff_gather = value;
       return 0;
     case DP_DEBUG_CONV1X1_VARIANT:
-      DP_REQUIRE(value >= 0 && value < 32 && (value & 3) != 3);
+      DP_REQUIRE(value >= 0 && value < 16 && (value & 3) != 3);
       g_conv1x1_variant = value;
       return 0;
     default:

@@ -45,7 +45,9 @@ try:
         _doc3 = json.load(_f)
     CONV3X3_TABLE = {int(n): {tuple([k.split(":")[0]] + [int(v) for v in k.split(":")[1:]]): v for k, v in t.items()}
                      for n, t in _doc3["routes"].items()}
-except (OSError, ValueError, KeyError):
+except (OSError, ValueError, KeyError) as _e:      # a missing / malformed table is a silent performance regression: say so
+    import warnings
+    warnings.warn("dorpatch_amd: conv3x3_gfx950.json unusable (%r): every 3x3 convolution stays on MIOpen" % (_e,))
     CONV3X3_TABLE = {}
 for _extra in filter(None, os.environ.get("DORPATCH_CONV3X3_ALSO", "").split(",")):     # A/B knob: "fwd:512:7,bwd:512:7"
     _d, _c, _s = _extra.split(":")                                                       # -> also on dp_conv3x3_fwd, at

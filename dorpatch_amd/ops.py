@@ -754,3 +754,142 @@ class DualConv1x1Function(torch.autograd.Function):
                     g = torch.zeros_like(pre)
                 subsample2_add_(g, gs)
         return g, None, None, None
+
+
+# ---------------------------------------------------------------- a-8 (round 5): GroupNorm folded into the consuming convolution
+def _fconv_fwd(kind, x, w, ab, res):
+    from . import libconv
+    if kind == 1:
+        return conv1x1_fwd(x, libconv.packed1(w, False), ab=ab, res=res)
+    assert res is None
+    return conv3x3_fwd(x, libconv._packed3(w, False), ab=ab)
+
+
+def _fconv_bwd(kind, dy, w, res=None):
+    from . import libconv
+    if kind == 1:
+        return conv1x1_fwd(dy, libconv.packed1(w, True), res=res, out=res)
+    assert res is None
+    return conv3x3_fwd(dy, libconv._packed3(w, True))
+
+
+def gn_fold_supported(x, conv_weight, groups, stride=(1, 1), padding=None):
+    """Can ``conv(relu(group_norm(x)))`` run as dp_gn_stats + a convolution that applies the norm while staging?
+    1x1 / stride 1: any plane of H*W % 4 == 0 pixels; 3x3 / stride 1 / pad 1: square planes of side 56 / 28 / 14."""
+    if not gn_relu_supported(x, groups) or x.dim() != 4:
+        return False
+    k = tuple(conv_weight.shape[2:])
+    if k == (1, 1):
+        return tuple(stride) == (1, 1) and (x.shape[2] * x.shape[3]) % 4 == 0 and conv1x1_supported(x, conv_weight)
+    if k == (3, 3):
+        return (conv3x3_supported(x, conv_weight, stride, (1, 1) if padding is None else padding)
+                and x.shape[2] in CONV3X3_FOLD_SIDES)
+    return False
+
+
+class GnConvFunction(torch.autograd.Function):
+    """``out = conv(relu(group_norm(x)), w) [+ add]`` for a frozen 1x1 (``kind`` 1) or 3x3 (``kind`` 3) stride-1 filter,
+    the GroupNorm-apply + ReLU folded into the convolution's operand staging: one statistics pass over x
+    (dp_gn_stats), then dp_conv1x1_fwd / dp_conv3x3_gn_fwd read the RAW x — the normalised activation is never written or
+    re-read.  ``add`` (1x1 only): the residual, added in the convolution's epilogue.  ``passthrough``: also return x itself
+    (as a second output whose gradient comes back into this node's GroupNorm backward as ``dres``: the shortcut of a
+    non-first bottleneck — replaces autograd's accumulation add).  Bit-identical to GnReluFunction + the plain kernel.
+    Backward: input gradient of the convolution (the same MFMA kernel on the transposed weights), then dp_gn_relu_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, w, kind, add, passthrough):
+        x = x.contiguous()
+        mean, rstd, ab, _ = gn_stats(x, gamma, beta, groups, eps)
+        out = _fconv_fwd(kind, x, w, ab, None if add is None else add.contiguous())
+        ctx.save_for_backward(x, gamma, beta, mean, rstd, w)
+        ctx.groups, ctx.kind, ctx.has_add, ctx.passthrough = groups, kind, add is not None, passthrough
+        ctx.set_materialize_grads(False)
+        return (x, out) if passthrough else out
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x, gamma, beta, mean, rstd, w = ctx.saved_tensors
+        d_pass, d_out = grads if ctx.passthrough else (None, grads[0])
+        dx = d_pass
+        if d_out is not None:
+            d_out = d_out.contiguous()
+            dy = _fconv_bwd(ctx.kind, d_out, w)
+            dx = gn_relu_bwd(dy, x, gamma, beta, mean, rstd, ctx.groups, dres=None if d_pass is None else d_pass.contiguous())
+        return dx, None, None, None, None, None, None, (d_out if ctx.has_add else None), None
+
+
+class GnDualConvFunction(torch.autograd.Function):
+    """First block of a stage, folded: ``branch = conv1x1(y, w1)``, ``shortcut = conv1x1(subsample_s(y), wd)`` with
+    ``y = relu(group_norm(x))`` never materialised (both convolutions apply the norm while staging; the coefficients are per
+    (sample, channel), so the subsampled RAW tensor takes the same table).  Backward as DualConv1x1Function (the stride-1
+    downsample accumulates in the kernel's epilogue), then dp_gn_relu_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, w1, wd, stride):
+        x = x.contiguous()
+        mean, rstd, ab, _ = gn_stats(x, gamma, beta, groups, eps)
+        branch = _fconv_fwd(1, x, w1, ab, None)
+        small = x if stride == 1 else subsample2(x)
+        shortcut = _fconv_fwd(1, small, wd, ab, None)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd, w1, wd)
+        ctx.groups, ctx.stride = groups, stride
+        ctx.set_materialize_grads(False)
+        return branch, shortcut
+
+    @staticmethod
+    def backward(ctx, d_branch, d_short):
+        x, gamma, beta, mean, rstd, w1, wd = ctx.saved_tensors
+        g = None
+        if d_branch is not None:
+            g = _fconv_bwd(1, d_branch.contiguous(), w1)
+        if d_short is not None:
+            d_short = d_short.contiguous()
+            if ctx.stride == 1:
+                g = _fconv_bwd(1, d_short, wd, res=g)          # g += W_d^T d_short in the epilogue (plain when g is None)
+            else:
+                gs = _fconv_bwd(1, d_short, wd)
+                if g is None:
+                    g = torch.zeros_like(x)
+                subsample2_add_(g, gs)
+        if g is None:
+            return (None,) * 8
+        return gn_relu_bwd(g, x, gamma, beta, mean, rstd, ctx.groups), None, None, None, None, None, None, None
+
+
+class GnReluPassFunction(torch.autograd.Function):
+    """``x -> (x, relu(group_norm(x)))``: GnReluFunction that also hands x on (the shortcut of a non-first bottleneck) and
+    takes the gradient arriving there as ``dres`` of dp_gn_relu_bwd instead of leaving an accumulation add to autograd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps):
+        x = x.contiguous()
+        y, mean, rstd, _ = gn_relu_fwd(x, weight, bias, groups, eps)
+        ctx.save_for_backward(x, weight, bias, mean, rstd)
+        ctx.groups = groups
+        ctx.set_materialize_grads(False)
+        return x, y
+
+    @staticmethod
+    def backward(ctx, d_pass, dy):
+        x, weight, bias, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            return d_pass, None, None, None, None
+        dx = gn_relu_bwd(dy.contiguous(), x, weight, bias, mean, rstd, ctx.groups,
+                         dres=None if d_pass is None else d_pass.contiguous())
+        return dx, None, None, None, None
+
+
+class Conv1x1AddFunction(torch.autograd.Function):
+    """``conv1x1(y, w) + add`` on dp_conv1x1_fwd with the add in the epilogue (the 7 x 7 planes, where the GroupNorm fold
+    does not apply)."""
+
+    @staticmethod
+    def forward(ctx, y, w, add):
+        ctx.save_for_backward(w)
+        return _fconv_fwd(1, y.contiguous(), w, None, add.contiguous())
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (w,) = ctx.saved_tensors
+        d_out = d_out.contiguous()
+        return _fconv_bwd(1, d_out, w), None, d_out

@@ -21,6 +21,7 @@ The backbone is *frozen* on the hot path, so the per-forward weight
 standardisation of ``StdConv2d`` is folded once (``fold_weight_standardization``).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -68,6 +69,11 @@ class GroupNormAct(nn.GroupNorm):
     ``GroupNormAct.fused = False`` disables the HIP path globally (A/B measurements)."""
 
     fused = True
+    # round 5: on the frozen GPU hot path the norm's APPLY + ReLU are folded into the consuming convolution's operand
+    # staging (ops.GnConvFunction: a statistics-only pass + dp_conv1x1_fwd / dp_conv3x3_gn_fwd on the RAW tensor) and the
+    # residual add into the producing convolution's epilogue, wherever the hand-written MFMA kernels take the shape.
+    # ``GroupNormAct.fold = False`` (or DORPATCH_GNFOLD=0) restores the round-4 graph (A/B measurements).
+    fold = os.environ.get("DORPATCH_GNFOLD", "1") != "0"
 
     def __init__(self, num_channels, num_groups=32, eps=1e-5):
         super().__init__(num_groups, num_channels, eps=eps, affine=True)
@@ -143,6 +149,55 @@ class PreActBottleneck(nn.Module):
     def forward(self, x):
         out, shortcut = self.forward_pair(x)
         return out + shortcut
+
+    def _sum_ok(self, x):
+        """The folded form (``forward_sum``) applies: frozen + folded weights on fp32 NCHW GPU tensors, fused kernels and the
+        fold enabled, and the block's three 1x1 convolutions are shapes dp_conv1x1_fwd takes."""
+        from . import conv1x1, ops
+        convs = [self.conv1, self.conv2, self.conv3] + ([self.downsample.conv] if self.downsample is not None else [])
+        if not (GroupNormAct.fused and GroupNormAct.fold and conv1x1.MODE in ("table", "mfma")
+                and all(c.folded and not c.weight.requires_grad for c in convs)
+                and all(n._use_hip(x) for n in (self.norm1,))):
+            return False
+        s = self.conv2.stride[0]
+        small = x[:, :, ::s, ::s]
+        return (ops.conv1x1_supported(x, self.conv1.weight)
+                and small.shape[0] * self.conv3.weight.shape[0] * small.shape[2] * small.shape[3] < 2 ** 31
+                and self.conv3.weight.shape[1] % 16 == 0 and self.conv3.weight.shape[0] % 64 == 0
+                and ((small.shape[2] * small.shape[3]) % 4 == 0 or small.shape[2] * small.shape[3] == 49)
+                and (self.downsample is None or (self.downsample.conv.stride[0] in (1, 2)
+                                                 and self.downsample.conv.weight.shape[0] % 64 == 0
+                                                 and (s == 1 or ops.subsample2_supported(x)))))
+
+    def forward_sum(self, x):
+        """Folded form: ``x`` is the block's materialised input (the previous block's ``branch + shortcut``, added in that
+        block's last convolution), the result is this block's materialised output.  GroupNorm-apply + ReLU run inside the
+        consuming convolution wherever the MFMA kernels take the shape (``ops.GnConvFunction``); elsewhere (7 x 7 planes,
+        the stride-2 3x3) the norm is materialised as before."""
+        from . import ops
+        n1, n2, n3 = self.norm1, self.norm2, self.norm3
+        G, w1, w2, w3 = n1.num_groups, self.conv1.weight, self.conv2.weight, self.conv3.weight
+        fold1 = ops.gn_fold_supported(x, w1, G)
+        if self.downsample is not None:
+            ds = self.downsample.conv
+            small_hw = (x.shape[2] // ds.stride[0]) * (x.shape[3] // ds.stride[0])
+            if fold1 and small_hw % 4 == 0:
+                out, shortcut = ops.GnDualConvFunction.apply(x, n1.weight, n1.bias, G, n1.eps, w1, ds.weight, ds.stride[0])
+            else:       # e.g. stage 3: the subsampled plane is 7 x 7 — materialise the pre-activation, round-4 dual node
+                out, shortcut = ops.DualConv1x1Function.apply(n1(x), w1, ds.weight, ds.stride[0])
+        elif fold1:
+            shortcut, out = ops.GnConvFunction.apply(x, n1.weight, n1.bias, G, n1.eps, w1, 1, None, True)
+        else:
+            from . import conv1x1
+            shortcut, pre = ops.GnReluPassFunction.apply(x, n1.weight, n1.bias, G, n1.eps)
+            out = conv1x1.Conv1x1Function.apply(pre, w1)
+        if ops.gn_fold_supported(out, w2, n2.num_groups, self.conv2.stride, self.conv2.padding):
+            out = ops.GnConvFunction.apply(out, n2.weight, n2.bias, n2.num_groups, n2.eps, w2, 3, None, False)
+        else:
+            out = self.conv2(n2(out))
+        if ops.gn_fold_supported(out, w3, n3.num_groups):
+            return ops.GnConvFunction.apply(out, n3.weight, n3.bias, n3.num_groups, n3.eps, w3, 1, shortcut, False)
+        return ops.Conv1x1AddFunction.apply(n3(out), w3, shortcut)
 
 
 class _Stage(nn.Module):
@@ -241,7 +296,10 @@ class ResNetV2(nn.Module):
         x, res = self.stem.pool(z), None
         for stage in self.stages:
             for block in stage.blocks:
-                x, res = block.forward_pair(x, res)     # residual adds ride along into the next norm
+                if res is None and block._sum_ok(x):
+                    x = block.forward_sum(x)            # round 5: adds in the conv epilogue, norms in the conv staging
+                else:
+                    x, res = block.forward_pair(x, res)     # residual adds ride along into the next norm
         _, y = self.norm.add_forward(x, res)
         return self.head(y)
 

@@ -61,8 +61,8 @@ const char *dp_error_string(int err);
  *                                      bits; measured 34 % slower); 0: a branch per candidate
  *   DP_DEBUG_CONV1X1_VARIANT           dp_conv1x1_fwd: bits 0-1 workgroup id -> (pixel tile, channel group): 0 XCD-aware
  *                                      (a tile's channel groups adjacent on one XCD), 1 channel group fastest, 2 tile
- *                                      fastest; bit 2 non-temporal result stores; bit 3 chunk barrier after (not before) the
- *                                      chunk's last k-step; bit 4 next chunk requested half a chunk ahead (not a whole one).
+ *                                      fastest; bit 2 non-temporal result stores; bit 3 the next chunk goes to LDS in one
+ *                                      lump half-way through the chunk (0: one item after each MFMA group).
  *                                      Same bits out of every variant */
 #define DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK 1
 #define DP_DEBUG_UPDATE_VARIANT 2

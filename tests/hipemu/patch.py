@@ -66,6 +66,21 @@ def _stem_supported(x, weight, stride, padding):
             and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
 
 
+def _c1_supported(x, weight):
+    if not (isinstance(x, torch.Tensor) and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()):
+        return False
+    HW = x.shape[2] * x.shape[3]
+    return (weight.dim() == 4 and tuple(weight.shape[2:]) == (1, 1) and weight.shape[1] == x.shape[1]
+            and weight.shape[1] % 16 == 0 and weight.shape[0] % 64 == 0 and (HW % 4 == 0 or HW == 49))
+
+
+def _c3_supported(x, weight, stride=(1, 1), padding=(1, 1)):
+    return (isinstance(x, torch.Tensor) and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+            and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
+            and x.shape[2] == x.shape[3] and x.shape[2] in ops.CONV3X3_SIDES and weight.shape[1] == x.shape[1]
+            and weight.shape[1] % 8 == 0 and weight.shape[0] % 64 == 0)
+
+
 def _poisoned(fn):
     """torch.empty / torch.empty_like that hand out NaN (float) or a sentinel (integer) instead of whatever the
     allocator had: an output element a kernel forgets to write then reaches the comparison as NaN / garbage."""
@@ -100,10 +115,14 @@ def emulated_ops():
 
 @contextlib.contextmanager
 def _emulated_ops():
+    import os
     lib = emu_lib()
     assert lib is not None, "no host clang++: cannot build the emulation library"
     saved = dict(lib=_lib._lib, req=ops.require_gpu, chk=ops._chk, stream=ops._stream, gn=ops.gn_relu_supported,
-                 pool=ops.pad_maxpool_supported, stem=ops.stem_dgrad_supported, sub=ops.subsample2_supported)
+                 pool=ops.pad_maxpool_supported, stem=ops.stem_dgrad_supported, sub=ops.subsample2_supported,
+                 c1=ops.conv1x1_supported, c3=ops.conv3x3_supported)
+    if os.environ.get("HIPEMU_MFMA_CONVS", "0") == "1":     # the matrix-core convolutions through the emulation too (slow)
+        ops.conv1x1_supported, ops.conv3x3_supported = _c1_supported, _c3_supported
     _lib._lib = lib
     ops._chk = _chk_cpu
     ops.require_gpu = lambda t, what: t
@@ -117,3 +136,4 @@ def _emulated_ops():
         ops._chk, ops._stream, ops.require_gpu = saved["chk"], saved["stream"], saved["req"]
         ops.gn_relu_supported, ops.pad_maxpool_supported, ops.stem_dgrad_supported = saved["gn"], saved["pool"], saved["stem"]
         ops.subsample2_supported = saved["sub"]
+        ops.conv1x1_supported, ops.conv3x3_supported = saved["c1"], saved["c3"]

@@ -422,6 +422,36 @@ def test_finished_images_leave_the_batch(mb, dual, stage):
         assert torch.equal(on["pattern"][b], off["pattern"][b]) or not exact
 
 
+def test_an_image_that_stopped_before_the_switch_is_not_revived():
+    """the untargeted -> targeted switch (attack.py:169-182) resets lr / loss_best of every image that is still
+    untargeted.  An image that early-stopped BEFORE the switch has left stage 0 (the reference's loop ended at
+    attack.py:311-316 and never reaches its own switch): it must keep its state — a revived image would run on with
+    loss_best = inf and overwrite its saved best mask / pattern — and its per-stage step count must survive the reset."""
+    B, S, H = 3, 4, 56
+    model = _toy(2.0)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 3, H, H, generator=g)
+    loop = _loop(model, x.to(DEV), None, S, dict(switch_iteration=3, retire=True), targeted=False, dropout=1)
+    try:
+        best = None
+        for i in range(5):
+            if i == 1:                       # image 1 early-stops after one step
+                st = loop.img[1]
+                st.active = False
+                st.lr_current = np.float32(1e-4)
+                st.loss_best = np.float32(0.25)
+                best = (loop.best_mask[1].clone(), loop.best_pattern[1].clone())
+            loop.step(i)
+        st = loop.img[1]
+        assert not st.active and not st.flag_targeted
+        assert float(st.lr_current) == np.float32(1e-4) and float(st.loss_best) == np.float32(0.25)
+        assert torch.equal(loop.best_mask[1], best[0]) and torch.equal(loop.best_pattern[1], best[1])
+        assert all(loop.img[b].flag_targeted and loop.img[b].active for b in (0, 2))
+        assert [s_.steps_in_stage for s_ in loop.img] == [5, 1, 5]      # not zeroed by the switch-time reset
+    finally:
+        loop.close()
+
+
 def test_retired_batch_equals_the_batch_of_the_running_images():
     """The dense batch the running images are gathered into is, bit for bit, the batch a loop over only those images
     would build: same rows in the same order, same micro-batch boundaries — whatever the library kernels do with a

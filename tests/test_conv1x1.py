@@ -168,13 +168,12 @@ def test_tuned_scope_is_a_query_outside_activate(monkeypatch):
     # one rank's refusal is every rank's: with a process group the first activate() runs the agreement, whatever this
     # rank has cached (here: its own True from above)
     pg = object()
-    monkeypatch.setattr(conv1x1, "_agreed", set())
     monkeypatch.setattr(dp_dist, "world_rank", lambda g: (2, 0))
     monkeypatch.setattr(dp_dist, "broadcast_object", lambda obj, g: obj)
     monkeypatch.setattr(dp_dist, "all_true", lambda flag, g: False)
     assert conv1x1._tuned_verdict is True
     assert conv1x1.activate(pg, True) is False and not conv1x1.tuned_gemms_active(True) and not fake.enabled
-    assert conv1x1._tuned_verdict is False and id(pg) in conv1x1._agreed
+    assert conv1x1._tuned_verdict is False
 
 
 @pytest.mark.gpu

@@ -479,8 +479,8 @@ def test_conv1x1_on_the_matrix_cores_matches_conv2d(N, C, O, H, small):
 
 
 def test_conv1x1_launch_variants_are_bit_identical():
-    """dp_debug_set(DP_DEBUG_CONV1X1_VARIANT): the workgroup-id maps, non-temporal stores, the barrier placement and the
-    prefetch distance are A/B knobs for measurements — every combination must produce the same bits (tile count not a multiple of 8, three
+    """dp_debug_set(DP_DEBUG_CONV1X1_VARIANT): the workgroup-id maps, non-temporal stores and the placement of the LDS
+    staging are A/B knobs for measurements — every combination must produce the same bits (tile count not a multiple of 8, three
     output-channel groups, 2 K-chunks)."""
     from dorpatch_amd import _lib
     g = torch.Generator().manual_seed(7)
@@ -488,7 +488,7 @@ def test_conv1x1_launch_variants_are_bit_identical():
     wt = ops.pack_conv1x1_weights(torch.randn(192, 32, 1, 1, generator=g)).to(DEV)
     try:
         outs = []
-        for variant in (0, 1, 2, 4, 8, 14, 16, 24, 30):
+        for variant in (0, 1, 2, 4, 8, 14):
             ops.debug_set(_lib.DP_DEBUG_CONV1X1_VARIANT, variant)
             outs.append(ops.conv1x1_fwd(x, wt).cpu())
     finally:

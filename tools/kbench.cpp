@@ -18,6 +18,7 @@
 #include <random>
 #include <string>
 #include <vector>
+#include <array>
 
 // White-box: the product translation unit is compiled INTO this binary so that the kernel
 // variants behind dp_apply_fwd (launch_apply_fwd(variant, ...)) can be swept; every other kernel
@@ -50,6 +51,67 @@ __global__ __launch_bounds__(256) void k_fill(f4 *__restrict__ out, size_t n4, f
 __global__ __launch_bounds__(256) void k_copy(const f4 *__restrict__ in, f4 *__restrict__ out, size_t n4) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
     __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
+}
+
+// Calibration of the matrix-core convolutions' loop structure (round 5): what does the MI355X give a workgroup of 4 waves,
+// 7 accumulators per wave, that does NOTHING but the 1x1 kernel's k-step walk?  MODE 0: operands stay in registers (pure
+// v_mfma_f32_32x32x2_f32 issue); 1: + the 8 LDS operand reads per k-step, requested one step ahead; 2: + one workgroup
+// barrier per 56 MFMAs (before the last group, like the kernel); 3: + 8 ds_write_b128 per chunk spread over the groups.
+// Launched with 2 workgroups per CU (64 KB of LDS each) and with 1.
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_mfma_probe(float *__restrict__ out, int chunks) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * kC1Buf];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
+  for (int i = tid; i < 2 * kC1Buf; i += 256) lds[i] = 1e-3f * (float)((i * 7 + 3) & 63);
+  __syncthreads();
+  const int abase = kC1In + half * kC1O + (wave & 1) * 32 + l32;
+  int boff[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) boff[q] = half * kC1Pix + ((wave >> 1) + 2 * q) * 32 + l32;
+  f16v acc[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
+  auto operands = [&](const float *cur, int t, float &a, float (&bv)[7]) {
+    a = cur[abase + t * 2 * kC1O];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) bv[q] = cur[boff[q] + t * 2 * kC1Pix];
+  };
+  float a0, b0[7], a1, b1[7];
+  operands(lds, 0, a0, b0);
+  operands(lds, 1, a1, b1);
+  f4 junk = {1.f, 2.f, 3.f, 4.f};
+  for (int chunk = 0; chunk < chunks; ++chunk) {
+    const float *cur = lds + (chunk & 1) * kC1Buf;
+    float *nxt = lds + ((chunk + 1) & 1) * kC1Buf;
+#pragma unroll
+    for (int t = 0; t < kC1Steps; t += 2) {
+      if (MODE >= 1) operands(cur, t + 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[q], acc[q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (MODE >= 3) *reinterpret_cast<f4 *>(nxt + 4 * (tid + t * 256)) = junk;
+      if (t + 2 < kC1Steps) {
+        if (MODE >= 1) operands(cur, t + 2, a0, b0);
+      } else {
+        if (MODE >= 2) DP_BARRIER_LDS();
+        if (MODE >= 1) operands(nxt, 0, a0, b0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[q], acc[q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (MODE >= 3 && t + 2 < kC1Steps) *reinterpret_cast<f4 *>(nxt + 4 * (tid + (t + 1) * 256)) = junk;
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 7; ++q)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) s += acc[q][v];
+  out[(size_t)blockIdx.x * 256 + tid] = s;
 }
 
 // write-only fill with the gfx950 store flavours (MI355X_MICROARCH.md, "stores of each flavour"): which one gives the
@@ -336,6 +398,94 @@ int main(int argc, char **argv) {
                Cc, Cc, Sc, Sc, Nc, ms, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 1.573);
       }
       CK(hipFree(cx)); CK(hipFree(cy)); CK(hipFree(cw));
+    }
+    return 0;
+  }
+  if (g_filter && strstr(g_filter, "mfma_probe")) {
+    float *po = (float *)dmalloc((size_t)2048 * 256 * 4);
+    const int chunks = 256;
+    for (int wgs : {512, 256, 1024}) {
+      for (int mode = 0; mode < 4; ++mode) {
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        auto launch = [&]() {
+          if (mode == 0) hipLaunchKernelGGL(k_mfma_probe<0>, dim3(wgs), dim3(256), 0, st, po, chunks);
+          else if (mode == 1) hipLaunchKernelGGL(k_mfma_probe<1>, dim3(wgs), dim3(256), 0, st, po, chunks);
+          else if (mode == 2) hipLaunchKernelGGL(k_mfma_probe<2>, dim3(wgs), dim3(256), 0, st, po, chunks);
+          else hipLaunchKernelGGL(k_mfma_probe<3>, dim3(wgs), dim3(256), 0, st, po, chunks);
+        };
+        launch();
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < iters; ++i) launch();
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= iters;
+        const double flop = (double)wgs * 4 * chunks * 56 * 4096.0;
+        printf("k_mfma_probe mode %d (%s) %4d workgroups x 4 waves x %d chunks x 56 MFMAs  %8.4f ms  %6.1f TFLOP/s (%4.1f%% of 157.3)\n", mode,
+               mode == 0 ? "registers only" : mode == 1 ? "+ LDS operand reads" : mode == 2 ? "+ barrier / chunk" : "+ 8 ds_write_b128 / chunk",
+               wgs, chunks, ms, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 1.573);
+      }
+    }
+    CK(hipFree(po));
+    return 0;
+  }
+  if (g_filter && strstr(g_filter, "conv1x1")) {
+    // Round 5: the 1x1 convolutions of ResNetV2-50 (B here = N of the convolution) on the matrix cores, every launch
+    // variant of DP_DEBUG_CONV1X1_VARIANT named in $DP_C1_VARIANTS (default "0"); $DP_C1_SHAPES = "C:O:S,..." restricts
+    // the shapes (for PMC passes).  `fold` / `res` rows: the GroupNorm fold and the epilogue add on the same shape.
+    const int Nc = B;
+    std::vector<std::array<int, 3>> shapes = {{64, 64, 56}, {64, 256, 56}, {256, 64, 56}, {256, 128, 56}, {128, 512, 28},
+        {256, 512, 28}, {512, 128, 28}, {512, 256, 28}, {256, 1024, 14}, {512, 1024, 14}, {1024, 256, 14}, {1024, 512, 14},
+        {512, 2048, 7}, {1024, 2048, 7}, {2048, 512, 7}};
+    if (const char *e = getenv("DP_C1_SHAPES")) {
+      shapes.clear();
+      int c, o, s2, n = 0;
+      for (const char *p = e; sscanf(p, "%d:%d:%d%n", &c, &o, &s2, &n) == 3; p += n + (p[n] == ',')) shapes.push_back({c, o, s2});
+    }
+    std::vector<int> variants = {0};
+    if (const char *e = getenv("DP_C1_VARIANTS")) {
+      variants.clear();
+      int v, n = 0;
+      for (const char *p = e; sscanf(p, "%d%n", &v, &n) == 1; p += n + (p[n] == ',')) variants.push_back(v);
+    }
+    for (auto &sh : shapes) {
+      const int Cc = sh[0], Oc = sh[1], Sc = sh[2], HWc = Sc * Sc;
+      const size_t ex = (size_t)Nc * Cc * HWc, ey = (size_t)Nc * Oc * HWc;
+      float *cx = (float *)dmalloc(ex * 4), *cy = (float *)dmalloc(ey * 4), *cw = (float *)dmalloc((size_t)Cc * Oc * 4);
+      float *cab = (float *)dmalloc((size_t)Nc * Cc * 2 * 4), *cr = (float *)dmalloc(ey * 4);
+      hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, st, (f4 *)cx, ex / 4, 0.37f);
+      hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, st, (f4 *)cr, ey / 4, 0.11f);
+      hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, st, (f4 *)cw, (size_t)Cc * Oc / 4, 0.01f);
+      hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, st, (f4 *)cab, (size_t)Nc * Cc * 2 / 4, 0.5f);
+      const double flop = 2.0 * Nc * HWc * (double)Cc * Oc, bytes = 4.0 * (ex + ey);
+      for (int v : variants) {
+        for (int mode = 0; mode < 3; ++mode) {     // 0 plain, 1 fold, 2 res
+          if (mode == 1 && (HWc & 3)) continue;
+          if (mode && getenv("DP_C1_PLAIN_ONLY")) continue;
+          DP(dp_debug_set(DP_DEBUG_CONV1X1_VARIANT, v));
+          hipEvent_t e0, e1;
+          CK(hipEventCreate(&e0));
+          CK(hipEventCreate(&e1));
+          const float *ab = mode == 1 ? cab : nullptr, *res = mode == 2 ? cr : nullptr;
+          DP(dp_conv1x1_fwd(cx, cw, ab, res, Nc, Cc, Oc, HWc, cy, st));
+          CK(hipEventRecord(e0, st));
+          for (int i = 0; i < iters; ++i) DP(dp_conv1x1_fwd(cx, cw, ab, res, Nc, Cc, Oc, HWc, cy, st));
+          CK(hipEventRecord(e1, st));
+          CK(hipEventSynchronize(e1));
+          float ms;
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          ms /= iters;
+          printf("dp_conv1x1_fwd %4d->%4d @%2dx%2d N=%d variant %2d %-5s %8.4f ms  %6.1f TFLOP/s (%4.1f%% of 157.3)  %5.2f TB/s algorithmic\n",
+                 Cc, Oc, Sc, Sc, Nc, v, mode == 0 ? "plain" : mode == 1 ? "fold" : "res", ms, flop / (ms * 1e-3) / 1e12,
+                 flop / (ms * 1e-3) / 1e12 / 1.573, (bytes + (mode == 2 ? 4.0 * ey : 0.0)) / (ms * 1e-3) / 1e12);
+          fflush(stdout);
+        }
+      }
+      DP(dp_debug_set(DP_DEBUG_CONV1X1_VARIANT, 0));
+      CK(hipFree(cx)); CK(hipFree(cy)); CK(hipFree(cw)); CK(hipFree(cab)); CK(hipFree(cr));
     }
     return 0;
   }
