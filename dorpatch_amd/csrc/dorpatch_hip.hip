@@ -3384,16 +3384,15 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
 
   f4 pin[kC1It], pwt;
   f2 pab[FOLD ? kC1It : 1];
-  auto fetch = [&](int chunk) {          // global -> registers; every load is issued unconditionally
-    const float *xc = A.x + (size_t)chunk * kC1Ch * HW;
+  auto fetch_item = [&](int chunk, int it) {     // global -> registers; every load is issued unconditionally
+    pin[it] = *reinterpret_cast<const f4 *>(A.x + (size_t)chunk * kC1Ch * HW + (xoff[it] < 0 ? 0 : xoff[it]));
+    if (FOLD) pab[it] = *reinterpret_cast<const f2 *>(A.ab + (size_t)chunk * kC1Ch * 2 + 2 * (size_t)aoff[it]);
+  };
+  auto fetch_w = [&](int chunk) { pwt = *reinterpret_cast<const f4 *>(wtg + (size_t)chunk * kC1Wt); };
+  auto fetch = [&](int chunk) {
 #pragma unroll
-    for (int it = 0; it < kC1It; ++it) pin[it] = *reinterpret_cast<const f4 *>(xc + (xoff[it] < 0 ? 0 : xoff[it]));
-    if (FOLD) {
-      const float *abc = A.ab + (size_t)chunk * kC1Ch * 2;
-#pragma unroll
-      for (int it = 0; it < kC1It; ++it) pab[it] = *reinterpret_cast<const f2 *>(abc + 2 * (size_t)aoff[it]);
-    }
-    pwt = *reinterpret_cast<const f4 *>(wtg + (size_t)chunk * kC1Wt);
+    for (int it = 0; it < kC1It; ++it) fetch_item(chunk, it);
+    fetch_w(chunk);
   };
   auto stash_item = [&](int buf, int it) {   // registers -> LDS (flat copy), with the fused GroupNorm-apply + ReLU
     f4 v = pin[it];
@@ -3437,19 +3436,22 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
 
   // Pipeline of one chunk (8 k-steps = 8 groups of 7 MFMAs per wave):
   //   * step t + 1's 8 operands are requested before step t's MFMAs (the k-step pipeline of k_conv3x3_mfma);
-  //   * chunk c + 1 goes from the staging registers to the other LDS buffer DURING chunk c — SPREAD: one float4 item (with its
-  //     GroupNorm-apply) after each of the MFMA groups 0..6, so every piece hides behind a group; else all of it after group 4;
+  //   * chunk c + 1 goes from the staging registers to the other LDS buffer DURING chunk c, and chunk c + 2 is requested from
+  //     global memory into the registers this frees — SPREAD: one float4 item (its GroupNorm-apply, its LDS store, the load
+  //     that refills its register) after each of the MFMA groups 0..6, so that neither the LDS stores nor the issue of the
+  //     global loads (8 - 15 wave-wide requests per chunk through the CU's one texture-address unit, from all 8 waves at
+  //     once) ever sit between two MFMA groups in one lump; else all of it after group 4 / after the barrier.  Every load has
+  //     a whole chunk (~3 us) to land: requested half a chunk ahead, 512 -> 128 @28^2 ran 13 % and 1024 -> 512 @14^2 15 %
+  //     slower (profiles/r05b_kbench_conv1x1_variants.txt: variants 16 / 24).  The loads stay in flight across the chunk's
+  //     barrier, which therefore waits for LDS traffic only (DP_BARRIER_LDS);
   //   * the chunk's barrier sits BEFORE the last group's MFMAs: every read of this buffer has been issued by then (the last
   //     step's operands are in a1 / b1, and the barrier waits for them) and every wave's store of the next chunk is done, so
-  //     the next chunk's first operands are requested right after it and land during those 7 MFMAs (with the barrier at the
-  //     end every chunk started with an exposed LDS round trip);
-  //   * chunk c + 2 is requested from global memory right after that barrier (the staging registers are free again): a whole
-  //     chunk (~3 us) ahead — requested half a chunk ahead, 512 -> 128 @28^2 ran 13 % and 1024 -> 512 @14^2 15 % slower
-  //     (profiles/r05b_kbench_conv1x1_variants.txt: variants 16 / 24).  The loads stay in flight across the next barrier,
-  //     which therefore waits for LDS traffic only (DP_BARRIER_LDS).
+  //     the next chunk's first operands are requested right after it and land during those 7 MFMAs.
+  // What the loop structure alone reaches on this GPU (tools/kbench mfma_probe: the same walk without global memory):
+  // 146 - 152 TFLOP/s = 93 - 97 % of the fp32 matrix peak (profiles/r05c_kbench_mfma_probe.txt).
   fetch(0);
   stash(0);
-  if (NCH > 1) fetch(1);
+  fetch(NCH > 1 ? 1 : 0);
   DP_BARRIER_LDS();
   auto operands = [&](const float *cur, int t, float &a, float (&bv)[7]) {
     a = cur[abase + t * 2 * kC1O];
@@ -3458,10 +3460,21 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
   };
   float a0, b0[7], a1, b1[7];
   operands(lds, 0, a0, b0);
+  // The loop body is BRANCH-FREE: past the end of K the staging simply repeats the last chunk (loads of valid memory, stores
+  // into the LDS buffer nobody reads any more).  With `if (chunk + 2 < NCH)` around the loads hipcc's wait-count pass merged
+  // the paths conservatively and put s_waitcnt vmcnt(0) in front of every item's store — i.e. it waited for the load issued
+  // one MFMA group earlier; straight-line code gets the exact vmcnt(6 / 7) of a FIFO of in-flight items.
+  const int last = NCH - 1;
   for (int chunk = 0; chunk < NCH; ++chunk) {
     const float *cur = lds + (chunk & 1) * kC1Buf;
-    const bool more = chunk + 1 < NCH;
     const int nb = (chunk + 1) & 1;
+    const int c2 = chunk + 2 < NCH ? chunk + 2 : last;
+    auto piece = [&](int g) {            // after MFMA group g (0..6): item g of chunk c + 1 to LDS, item g of chunk c + 2 requested
+      stash_item(nb, g);
+      if (g == 0) stash_w(nb);
+      fetch_item(c2, g);
+      if (g == 0) fetch_w(c2);
+    };
 #pragma unroll
     for (int t = 0; t < kC1Steps; t += 2) {
       operands(cur, t + 1, a1, b1);
@@ -3469,28 +3482,23 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
 #pragma unroll
       for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[q], acc[q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (more) {
-        if (SPREAD) {
-          stash_item(nb, t);
-        } else if (t == kC1Steps / 2) {
-          stash(nb);
-        }
+      if (SPREAD) {
+        piece(t);
+      } else if (t == kC1Steps / 2) {
+        stash(nb);
       }
       if (t + 2 < kC1Steps) {
         operands(cur, t + 2, a0, b0);
       } else {
         DP_BARRIER_LDS();
-        if (more) operands(lds + nb * kC1Buf, 0, a0, b0);
-        if (chunk + 2 < NCH) fetch(chunk + 2);
+        operands(lds + nb * kC1Buf, 0, a0, b0);
+        if (!SPREAD) fetch(c2);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[q], acc[q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (SPREAD && more && t + 2 < kC1Steps) {
-        stash_item(nb, t + 1);
-        if (t == 0) stash_w(nb);
-      }
+      if (SPREAD && t + 2 < kC1Steps) piece(t + 1);
     }
   }
 

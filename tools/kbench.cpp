@@ -58,8 +58,11 @@ __global__ __launch_bounds__(256) void k_copy(const f4 *__restrict__ in, f4 *__r
 // v_mfma_f32_32x32x2_f32 issue); 1: + the 8 LDS operand reads per k-step, requested one step ahead; 2: + one workgroup
 // barrier per 56 MFMAs (before the last group, like the kernel); 3: + 8 ds_write_b128 per chunk spread over the groups.
 // Launched with 2 workgroups per CU (64 KB of LDS each) and with 1.
+// MODE 4: + 8 global_load_dwordx4 per lane and chunk (32 KB per workgroup: the kernel's staging volume) from an L2-sized
+// region, issued in ONE burst after the barrier and consumed (stored to LDS) a chunk later; 5: the same loads issued one
+// after each MFMA group.
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void k_mfma_probe(float *__restrict__ out, int chunks) {
+__global__ __launch_bounds__(256, 2) void k_mfma_probe(float *__restrict__ out, int chunks, const float *__restrict__ src = nullptr) {
   __shared__ __attribute__((aligned(16))) float lds[2 * kC1Buf];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
   for (int i = tid; i < 2 * kC1Buf; i += 256) lds[i] = 1e-3f * (float)((i * 7 + 3) & 63);
@@ -81,10 +84,22 @@ __global__ __launch_bounds__(256, 2) void k_mfma_probe(float *__restrict__ out, 
   float a0, b0[7], a1, b1[7];
   operands(lds, 0, a0, b0);
   operands(lds, 1, a1, b1);
-  f4 junk = {1.f, 2.f, 3.f, 4.f};
+  f4 junk[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) junk[i] = f4{1.f, 2.f, 3.f, 4.f};
+  // 64 MB region (16 M floats), every workgroup its own 32 KB per chunk, wrapping: mostly L2 / MALL hits like the kernel's x
+  const size_t region = (size_t)16 << 20;
+  size_t goff = ((size_t)blockIdx.x * 8192 + 4 * tid) % region;
+  auto gload = [&](int i) {
+    if (MODE >= 4) junk[i] = *reinterpret_cast<const f4 *>(src + (goff + (size_t)i * 1024) % region);
+  };
+  if (MODE >= 4)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gload(i);
   for (int chunk = 0; chunk < chunks; ++chunk) {
     const float *cur = lds + (chunk & 1) * kC1Buf;
     float *nxt = lds + ((chunk + 1) & 1) * kC1Buf;
+    goff = (goff + (size_t)gridDim.x * 8192) % region;
 #pragma unroll
     for (int t = 0; t < kC1Steps; t += 2) {
       if (MODE >= 1) operands(cur, t + 1, a1, b1);
@@ -92,7 +107,8 @@ __global__ __launch_bounds__(256, 2) void k_mfma_probe(float *__restrict__ out, 
 #pragma unroll
       for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[q], acc[q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (MODE >= 3) *reinterpret_cast<f4 *>(nxt + 4 * (tid + t * 256)) = junk;
+      if (MODE >= 3) *reinterpret_cast<f4 *>(nxt + 4 * (tid + t * 256)) = junk[t];
+      if (MODE == 5) gload(t);
       if (t + 2 < kC1Steps) {
         if (MODE >= 1) operands(cur, t + 2, a0, b0);
       } else {
@@ -103,7 +119,11 @@ __global__ __launch_bounds__(256, 2) void k_mfma_probe(float *__restrict__ out, 
 #pragma unroll
       for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[q], acc[q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (MODE >= 3 && t + 2 < kC1Steps) *reinterpret_cast<f4 *>(nxt + 4 * (tid + (t + 1) * 256)) = junk;
+      if (MODE >= 3) *reinterpret_cast<f4 *>(nxt + 4 * (tid + (t + 1) * 256)) = junk[t + 1];
+      if (MODE == 5) gload(t + 1);
+      if (MODE == 4 && t + 2 == kC1Steps)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gload(i);
     }
   }
   float s = 0.f;
@@ -403,9 +423,11 @@ int main(int argc, char **argv) {
   }
   if (g_filter && strstr(g_filter, "mfma_probe")) {
     float *po = (float *)dmalloc((size_t)2048 * 256 * 4);
+    float *psrc = (float *)dmalloc((size_t)64 << 20);
+    hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, st, (f4 *)psrc, (size_t)(16 << 20) / 4, 0.25f);
     const int chunks = 256;
     for (int wgs : {512, 256, 1024}) {
-      for (int mode = 0; mode < 4; ++mode) {
+      for (int mode = 0; mode < 6; ++mode) {
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0));
         CK(hipEventCreate(&e1));
@@ -413,7 +435,9 @@ int main(int argc, char **argv) {
           if (mode == 0) hipLaunchKernelGGL(k_mfma_probe<0>, dim3(wgs), dim3(256), 0, st, po, chunks);
           else if (mode == 1) hipLaunchKernelGGL(k_mfma_probe<1>, dim3(wgs), dim3(256), 0, st, po, chunks);
           else if (mode == 2) hipLaunchKernelGGL(k_mfma_probe<2>, dim3(wgs), dim3(256), 0, st, po, chunks);
-          else hipLaunchKernelGGL(k_mfma_probe<3>, dim3(wgs), dim3(256), 0, st, po, chunks);
+          else if (mode == 3) hipLaunchKernelGGL(k_mfma_probe<3>, dim3(wgs), dim3(256), 0, st, po, chunks);
+          else if (mode == 4) hipLaunchKernelGGL(k_mfma_probe<4>, dim3(wgs), dim3(256), 0, st, po, chunks, psrc);
+          else hipLaunchKernelGGL(k_mfma_probe<5>, dim3(wgs), dim3(256), 0, st, po, chunks, psrc);
         };
         launch();
         CK(hipEventRecord(e0, st));
@@ -425,11 +449,13 @@ int main(int argc, char **argv) {
         ms /= iters;
         const double flop = (double)wgs * 4 * chunks * 56 * 4096.0;
         printf("k_mfma_probe mode %d (%s) %4d workgroups x 4 waves x %d chunks x 56 MFMAs  %8.4f ms  %6.1f TFLOP/s (%4.1f%% of 157.3)\n", mode,
-               mode == 0 ? "registers only" : mode == 1 ? "+ LDS operand reads" : mode == 2 ? "+ barrier / chunk" : "+ 8 ds_write_b128 / chunk",
+               mode == 0 ? "registers only" : mode == 1 ? "+ LDS operand reads" : mode == 2 ? "+ barrier / chunk" : mode == 3 ? "+ 8 ds_write_b128 / chunk" :
+               mode == 4 ? "+ 8 global_load_dwordx4 / chunk, one burst" : "+ 8 global_load_dwordx4 / chunk, one per MFMA group",
                wgs, chunks, ms, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 1.573);
       }
     }
     CK(hipFree(po));
+    CK(hipFree(psrc));
     return 0;
   }
   if (g_filter && strstr(g_filter, "conv1x1")) {
