@@ -55,6 +55,7 @@ import torch
 
 DEVICE_OVERRIDE = None     # test hook (tests/test_bench_emu.py runs main() on CPU tensors through the HIP emulation)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32) = fp32 vector peak; 155 measured
 
 
 # BASELINE.json `configs` entries that fit one GPU: (images, masks per image per GPU, side, budget)
@@ -65,6 +66,78 @@ PRESETS = {0: (8, 4, 224, 0.0204),          # configs[0]: the reference's own CP
 
 
 CONFIG3_TOTAL_SAMPLES = 512              # configs[3]: "512 EOT samples sharded 64/GPU" on 8 GPUs
+
+
+def conv_roofline(loop, i, ms_per_step, samples):
+    """One extra, UNTIMED step with an event pair around every matrix-core convolution launch (ops.CONV_EVENTS) ->
+    the dominant launch class (kernel, shape, fold / add) as a roofline entry + a per-kernel summary.  Bound: the fp32
+    matrix peak (157.3 TFLOP/s); `achieved` = the class's algorithmic flop / its summed launch time."""
+    from dorpatch_amd import ops
+    ops.CONV_EVENTS = []
+    try:
+        loop.step(i)
+        torch.cuda.synchronize()
+        ev = ops.CONV_EVENTS
+    finally:
+        ops.CONV_EVENTS = None
+    if not ev:
+        return None
+    agg, per_kernel = {}, {}
+    for kernel, key, flop, a, b in ev:
+        ms = a.elapsed_time(b)
+        e = agg.setdefault((kernel, key), [0, 0.0, 0.0])
+        e[0] += 1; e[1] += ms; e[2] += flop
+        k = per_kernel.setdefault(kernel, [0, 0.0, 0.0])
+        k[0] += 1; k[1] += ms; k[2] += flop
+    (kernel, key), (n, ms, flop) = max(agg.items(), key=lambda kv: kv[1][1])
+    N, C, O, HW, fold, add = key
+    tf = flop / (ms * 1e-3) / 1e12
+    total_ms = sum(v[1] for v in per_kernel.values())
+    return {"kernel": "%s (%s)" % (kernel, "dp_conv1x1_fwd" if "1x1" in kernel else "dp_conv3x3_fwd"),
+            "launch_class": "N=%d %d->%d @%d pixels%s%s" % (N, C, O, HW, ", GroupNorm folded" if fold else "",
+                                                           ", epilogue add" if add else ""),
+            "bound": "mfma_f32", "achieved": round(tf, 1), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / F32_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms / n, 4), "launches_per_step": n,
+            "class_ms_per_step": round(ms, 2), "timing": "torch events around each launch on the launch stream, one extra "
+                                                         "untimed step (in the step's own order and cache state)",
+            "own_conv_kernels": {k: {"launches_per_step": v[0], "ms_per_step": round(v[1], 2),
+                                     "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1),
+                                     "frac_of_peak": round(v[2] / (v[1] * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4)}
+                                 for k, v in sorted(per_kernel.items())},
+            "own_conv_share_of_step": round(total_ms / ms_per_step, 4)}
+
+
+def comm_only(loop, pg, world, rank, json_fd, reps=50):
+    """bench.py --comm-only: the step's one collective, alone."""
+    from dorpatch_amd import dist as dp_dist
+    view = loop._comm[:loop._n_g + loop._n_tail]
+    for _ in range(5):
+        dp_dist.allreduce_sum_(view, pg)
+    if view.is_cuda:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dp_dist.allreduce_sum_(view, pg)
+    if view.is_cuda:
+        torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / reps * 1e6
+    if pg is not None:
+        import torch.distributed as dist
+        t = torch.tensor([us], dtype=torch.float64, device=view.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        us = float(t.item())
+    if rank == 0:
+        nbytes = view.numel() * 4
+        out = {"metric": "all-reduce of the step's message", "value": round(us, 1), "unit": "us per call", "n_gpus": world,
+               "higher_is_better": False, "calls": reps, "bytes": nbytes,
+               "algbw_GBs": round(nbytes / (us * 1e-6) / 1e9, 2),
+               "message": "HotLoop._comm[:n_g + n_tail] = patch gradient (B,3,H,W) + one loss slab + one prediction slab + one "
+                          "draw checksum per rank, fp32, SUM",
+               "backend": "none (single rank: the collective is skipped)" if pg is None else "process group"}
+        if json_fd is None:
+            print(json.dumps(out))
+        else:
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 def parse(argv=None):
@@ -84,6 +157,13 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 PMC passes (roofline.traffic = null)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the separately-timed collect_failure sweep")
+    ap.add_argument("--no-conv-roofline", action="store_true",
+                    help="skip the extra untimed step that stamps every matrix-core convolution launch with events "
+                         "(roofline_conv)")
+    ap.add_argument("--comm-only", action="store_true",
+                    help="no steps: build the loop, then time 50 all-reduces of the step's REAL message (HotLoop._comm: patch "
+                         "gradient + loss / prediction slabs) on the process group and report us per call and bytes — the "
+                         "collective's cost next to the step, for the first multi-GPU lease")
     ap.add_argument("--no-update-roofline", action="store_true",
                     help="skip the dp_project_update roofline pass after the timed steps (for kernel-trace runs: its 13 "
                          "launches on a 256-image working set would mix into the step's per-kernel statistics)")
@@ -571,6 +651,13 @@ def main(argv=None):
             torch.cuda.synchronize()
 
     note("model + loop ready (B=%d S=%d H=%d world=%d)" % (B, S, H, world))
+    if args.comm_only:
+        comm_only(loop, pg, world, rank, json_fd)
+        loop.close()
+        if pg is not None:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return 0
     i = 1
     for k in range(args.warmup):
         loop.step(i)
@@ -600,6 +687,11 @@ def main(argv=None):
          % (dt, args.steps, step_ms, active_each))
     events = loop.kernel_events
     loop.kernel_events = None
+    conv_roof = None
+    if rank == 0 and dev.type == "cuda" and not args.no_conv_roofline:
+        conv_roof = conv_roofline(loop, i, dt / args.steps * 1e3, B * S_local)
+        i += 1
+        note("matrix-core convolution pass done: %s" % (conv_roof or {}).get("kernel"))
     apply_ms = float(np.mean([t.ms() for t in events]))   # kernel-begin -> kernel-end (dp_apply_fwd_timed)
     for t in events:
         t.close()
@@ -677,6 +769,13 @@ def main(argv=None):
         }
         if roof2 is not None:
             out["roofline_project_update"] = roof2
+        # what the step IS: the frozen backbone's forward + input-gradient backward, 16.36 GFLOP per 224 x 224 sample
+        # (x (H / 224)^2), against the fp32 matrix / vector peak of the MI355X (the same 157.3 TFLOP/s)
+        step_tflops = B * S_local * 16.36e9 * (H / 224.0) ** 2 / (dt / args.steps) / 1e12
+        out["step_tflops"] = round(step_tflops, 1)
+        out["step_frac_of_peak"] = round(step_tflops / F32_PEAK_TFLOPS, 4)
+        if conv_roof is not None:
+            out["roofline_conv"] = conv_roof
         if dt_sweep is not None:
             out["collect_failure_sweep_ms"] = round(dt_sweep * 1e3, 1)
             out["value_with_sweep_amortised"] = round(B * S * 100 / (100 * dt / args.steps + dt_sweep), 2)

@@ -341,6 +341,22 @@ def project_update(x, adv_x, lv_x, g_adv, scale, structured, pattern, mask, *, s
 # ---------------------------------------------------------------- a-8: 3x3 convolutions on the matrix cores
 CONV3X3_SIDES = (56, 28, 14, 7)
 
+# bench.py's "roofline_conv": set to a list for ONE extra, untimed step and every matrix-core convolution launch appends
+# (kernel, shape key, flop, start event, stop event) — torch events on the launch stream (the kernels run on torch's current
+# stream).  None (always, in the product): no events, no overhead.
+CONV_EVENTS = None
+
+
+def _timed_conv(kernel, key, flop, launch):
+    if CONV_EVENTS is None:
+        return launch()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    out = launch()
+    b.record()
+    CONV_EVENTS.append((kernel, key, flop, a, b))
+    return out
+
 
 def conv3x3_supported(x, weight, stride=(1, 1), padding=(1, 1)):
     """Shapes dp_conv3x3_fwd takes: fp32 GPU NCHW, 3x3 / stride 1 / pad 1, square planes of side 56 / 28 / 14 / 7,
@@ -376,13 +392,17 @@ def conv3x3_fwd(x, wt, ab=None):
     O = wt.shape[0] * wt.shape[-1]
     assert wt.numel() == C * 9 * O
     y = torch.empty((N, O, H, W), dtype=torch.float32, device=x.device)
-    if ab is None:
-        _lib.check(lib.dp_conv3x3_fwd(_p(x), _p(wt), N, C, O, H, W, _p(y), _stream()), "dp_conv3x3_fwd")
-    else:
+    if ab is not None:
         _chk(ab, torch.float32, "ab")
         assert ab.numel() == N * C * 2
-        _lib.check(lib.dp_conv3x3_gn_fwd(_p(x), _p(wt), _p(ab), N, C, O, H, W, _p(y), _stream()), "dp_conv3x3_gn_fwd")
-    return y
+
+    def launch():
+        if ab is None:
+            _lib.check(lib.dp_conv3x3_fwd(_p(x), _p(wt), N, C, O, H, W, _p(y), _stream()), "dp_conv3x3_fwd")
+        else:
+            _lib.check(lib.dp_conv3x3_gn_fwd(_p(x), _p(wt), _p(ab), N, C, O, H, W, _p(y), _stream()), "dp_conv3x3_gn_fwd")
+        return y
+    return _timed_conv("k_conv3x3_mfma", (N, C, O, H * W, ab is not None, False), 18.0 * N * H * W * C * O, launch)
 
 
 # ---------------------------------------------------------------- a-8: 1x1 convolutions on the matrix cores (round 5)
@@ -429,8 +449,10 @@ def conv1x1_fwd(x, wt, ab=None, res=None, out=None):
     else:
         _chk(out, torch.float32, "out")
         assert tuple(out.shape) == (N, O, H, W)
-    _lib.check(lib.dp_conv1x1_fwd(_p(x), _p(wt), _p(ab), _p(res), N, C, O, H * W, _p(out), _stream()), "dp_conv1x1_fwd")
-    return out
+    def launch():
+        _lib.check(lib.dp_conv1x1_fwd(_p(x), _p(wt), _p(ab), _p(res), N, C, O, H * W, _p(out), _stream()), "dp_conv1x1_fwd")
+        return out
+    return _timed_conv("k_conv1x1_mfma", (N, C, O, H * W, ab is not None, res is not None), 2.0 * N * H * W * C * O, launch)
 
 
 def gn_stats(x, weight, bias, groups, eps, res=None):

@@ -133,6 +133,19 @@ def test_plain_command_strong_scaling_mode():
         bench.parse(["--samples", "10", "--scaling", "strong", "--gpus", "4"])
 
 
+def test_comm_only_mode_times_the_steps_real_message():
+    """`bench.py --gpus N --comm-only` = 50 all-reduces of HotLoop's own message (patch gradient + one
+    loss / prediction slab + checksum per rank), one JSON line with us per call and the byte count — here 2 gloo ranks."""
+    res = _plain(["--gpus", "2", "--samples", "2", "--micro-batch", "2", "--comm-only"] + TINY)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["unit"] == "us per call" and out["calls"] == 50 and out["value"] > 0
+    # (1,3,32,32) gradient + per rank: 2 loss + 2 prediction floats + 1 checksum
+    assert out["bytes"] == 4 * (3 * 32 * 32 + 2 * (2 * 2 + 1)) and out["higher_is_better"] is False
+
+
 def test_plain_command_without_enough_gpus_fails_loudly():
     """No GPU in the build container: the launcher must say so and exit non-zero BEFORE starting any rank."""
     import torch
