@@ -61,6 +61,17 @@ def _parse(choices):
     return {tuple([k.split(":")[0]] + [int(v) for v in k.split(":")[1:]]): v for k, v in choices.items()}
 
 
+# Round 5: shapes that run on the hand-written fp32-MFMA kernel dp_conv1x1_fwd instead (measured per (batch, direction, shape)
+# against the faster library route by scripts/conv1x1_vs_lib.py; scripts/make_conv1x1_mfma_table.py).  Applies to the 1x1
+# convolutions that are NOT part of a folded GroupNorm -> convolution node (those always run on the kernel: ops.GnConvFunction).
+try:
+    with open(os.path.join(_HERE, "conv1x1_mfma_gfx950.json")) as _f:
+        MFMA = {int(n): set(_parse(c)) for n, c in json.load(_f)["routes"].items()}
+except (OSError, ValueError, KeyError) as _e:
+    import warnings
+    warnings.warn("dorpatch_amd: conv1x1_mfma_gfx950.json unusable (%r): the un-folded 1x1 convolutions stay on the libraries" % (_e,))
+    MFMA = {}
+
 PLAIN = {int(n): _parse(c) for n, c in _doc["plain"].items()}   # routes with the BLAS libraries' default GEMM solutions
 TUNED = {int(n): _parse(c) for n, c in _doc["tuned"].items()}   # routes when the tuned GEMM solutions below are active
 TUNED_BATCH = 512        # DorPatch's default micro-batch: the GEMM batch of the headline configuration
@@ -297,6 +308,10 @@ def _from_table(direction, C, O, HW, cuda=False, N=None):
     tuned for (other batches run the libraries' default solutions even with the file loaded); batches without their own
     plain column use the 512-sample one; shapes nobody measured go to MIOpen."""
     key = (direction, C, O, HW)
+    if cuda and N is not None:
+        cols = [n for n in MFMA if n <= N]
+        if cols and key in MFMA[max(cols)]:
+            return "mfma"
     if N in TUNED and tuned_gemms_active(cuda):
         return TUNED[N].get(key, "miopen")
     return PLAIN.get(N, PLAIN[TUNED_BATCH]).get(key, "miopen")

@@ -455,15 +455,21 @@ def conv1x1_fwd(x, wt, ab=None, res=None, out=None):
     return _timed_conv("k_conv1x1_mfma", (N, C, O, H * W, ab is not None, res is not None), 2.0 * N * H * W * C * O, launch)
 
 
-def gn_stats(x, weight, bias, groups, eps, res=None):
+def gn_stats(x, weight, bias, groups, eps, res=None, stats_out=None):
     """Statistics-only GroupNorm pass: (mean, rstd, ab, s) with s = x (+ res) and ab (N,C,2) the affine coefficients of
-    ``relu(group_norm(s))`` for a consumer that applies them itself (``conv1x1_fwd(..., ab=ab)``)."""
+    ``relu(group_norm(s))`` for a consumer that applies them itself (``conv1x1_fwd(..., ab=ab)``).
+    ``stats_out`` = (mean, rstd) views of N*groups floats to write the statistics into."""
     lib = _lib.load()
     _chk(x, torch.float32, "x"), _chk(weight, torch.float32, "weight"), _chk(bias, torch.float32, "bias")
     N, C = x.shape[0], x.shape[1]
     HW = int(np.prod(x.shape[2:]))
-    mean = torch.empty((N * groups,), dtype=torch.float32, device=x.device)
-    rstd = torch.empty_like(mean)
+    if stats_out is None:
+        mean = torch.empty((N * groups,), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+    else:
+        mean, rstd = stats_out
+        _chk(mean, torch.float32, "mean"), _chk(rstd, torch.float32, "rstd")
+        assert mean.numel() == N * groups and rstd.numel() == N * groups
     ab = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
     ssum = None
     if res is not None:

@@ -74,6 +74,10 @@ class GroupNormAct(nn.GroupNorm):
     # residual add into the producing convolution's epilogue, wherever the hand-written MFMA kernels take the shape.
     # ``GroupNormAct.fold = False`` (or DORPATCH_GNFOLD=0) restores the round-4 graph (A/B measurements).
     fold = os.environ.get("DORPATCH_GNFOLD", "1") != "0"
+    # ... for batches of at least this many samples: the MFMA kernels work in 448-pixel x 64-channel tiles, and below ~256
+    # samples the deep layers have too few of them for 512 workgroup slots — measured (profiles/r05e_*): the folded graph is
+    # 2.6 % FASTER than the round-4 graph at 512 samples, 2.5 % slower at 128, 17 % slower at 64, 40 % slower at 32
+    fold_min_batch = int(os.environ.get("DORPATCH_GNFOLD_MIN_BATCH", "256"))
 
     def __init__(self, num_channels, num_groups=32, eps=1e-5):
         super().__init__(num_groups, num_channels, eps=eps, affine=True)
@@ -155,7 +159,8 @@ class PreActBottleneck(nn.Module):
         fold enabled, and the block's three 1x1 convolutions are shapes dp_conv1x1_fwd takes."""
         from . import conv1x1, ops
         convs = [self.conv1, self.conv2, self.conv3] + ([self.downsample.conv] if self.downsample is not None else [])
-        if not (GroupNormAct.fused and GroupNormAct.fold and conv1x1.MODE in ("table", "mfma")
+        if not (GroupNormAct.fused and GroupNormAct.fold and x.shape[0] >= GroupNormAct.fold_min_batch
+                and conv1x1.MODE in ("table", "mfma")
                 and all(c.folded and not c.weight.requires_grad for c in convs)
                 and all(n._use_hip(x) for n in (self.norm1,))):
             return False

@@ -81,7 +81,7 @@ class _Cursor(object):
         self.tape, self.n, self.j = tape, n, 0
         self.k = len(tape.rows)
 
-    def gn(self, norm, x, res):
+    def gn(self, norm, x, res, stats_only=False):
         tape, G = self.tape, norm.num_groups
         _need(ops.gn_relu_supported(x, G), "GroupNorm shape %s" % (tuple(x.shape),))
         if self.k == 0:
@@ -93,6 +93,10 @@ class _Cursor(object):
         self.j += 1
         lo = self.k * tape.tab_rows * G
         stats = (e["mean"][lo:lo + self.n * G], e["rstd"][lo:lo + self.n * G])
+        if stats_only:       # the consuming convolution applies the norm while staging (round 5): keep x + statistics only
+            _, _, ab, s = ops.gn_stats(x.contiguous(), norm.weight, norm.bias, G, norm.eps, stats_out=stats)
+            e["x"].append(s)
+            return ab, s
         y, _, _, s = ops.gn_relu_fwd(x.contiguous(), norm.weight, norm.bias, G, norm.eps,
                                      res=None if res is None else res.contiguous(), stats_out=stats)
         e["x"].append(s)
@@ -108,6 +112,54 @@ def _conv_fwd(tape, conv, x):
     if routed:
         return conv1x1._run("fwd", x, conv.weight)
     return libconv.conv_fwd(x, conv.weight, conv.stride, conv.padding)
+
+
+def _block_sum(tape, it, block, x):
+    """``PreActBottleneck.forward_sum`` (the folded form: norms inside the consuming convolution's staging, the residual add
+    in conv3's epilogue), kernel for kernel, minus autograd."""
+    n1, n2, n3 = block.norm1, block.norm2, block.norm3
+    c1, c2, c3 = block.conv1, block.conv2, block.conv3
+    x = x.contiguous()
+    fold1 = ops.gn_fold_supported(x, c1.weight, n1.num_groups)
+    tape.conv_in[id(c1)] = tuple(x.shape[1:])
+    if block.downsample is not None:
+        ds = block.downsample.conv
+        st = ds.stride[0]
+        tape.dual[id(block)] = True
+        if fold1 and ((x.shape[2] // st) * (x.shape[3] // st)) % 4 == 0:       # ops.GnDualConvFunction.forward
+            ab, _ = it.gn(n1, x, None, stats_only=True)
+            branch = ops._fconv_fwd(1, x, c1.weight, ab, None)
+            small = x if st == 1 else ops.subsample2(x)
+            shortcut = ops._fconv_fwd(1, small, ds.weight, ab, None)
+            tape.conv_route[id(c1)] = tape.conv_route[id(ds)] = "mfma"
+        else:                                                                   # ops.DualConv1x1Function.forward
+            pre, _ = it.gn(n1, x, None)
+            branch = conv1x1._run("fwd", pre, c1.weight)
+            small = pre if st == 1 else ops.subsample2(pre)
+            shortcut = conv1x1._run("fwd", small, ds.weight)
+            tape.conv_route[id(c1)] = tape.conv_route[id(ds)] = True
+        tape.conv_in[id(ds)] = tuple(small.shape[1:])
+    elif fold1:
+        ab, shortcut = it.gn(n1, x, None, stats_only=True)
+        branch = ops._fconv_fwd(1, x, c1.weight, ab, None)
+        tape.conv_route[id(c1)] = "mfma"
+    else:
+        pre, shortcut = it.gn(n1, x, None)
+        branch = conv1x1._run("fwd", pre, c1.weight)
+        tape.conv_route[id(c1)] = True
+    if ops.gn_fold_supported(branch, c2.weight, n2.num_groups, c2.stride, c2.padding):
+        ab, _ = it.gn(n2, branch, None, stats_only=True)
+        tape.conv_in[id(c2)], tape.conv_route[id(c2)] = tuple(branch.shape[1:]), "mfma3"
+        b = ops._fconv_fwd(3, branch.contiguous(), c2.weight, ab, None)
+    else:
+        y2, _ = it.gn(n2, branch, None)
+        b = _conv_fwd(tape, c2, y2)
+    tape.conv_in[id(c3)], tape.conv_route[id(c3)] = tuple(b.shape[1:]), "mfma"
+    if ops.gn_fold_supported(b, c3.weight, n3.num_groups):
+        ab, _ = it.gn(n3, b, None, stats_only=True)
+        return ops._fconv_fwd(1, b.contiguous(), c3.weight, ab, shortcut.contiguous())
+    y3, _ = it.gn(n3, b, None)
+    return ops._fconv_fwd(1, y3, c3.weight, None, shortcut.contiguous())
 
 
 @torch.no_grad()
@@ -129,6 +181,9 @@ def forward(net, x, tape, z=None):
     cur, res = p, None
     for stage in net.stages:
         for block in stage.blocks:
+            if res is None and block._sum_ok(cur):
+                cur = _block_sum(tape, cur_it, block, cur)
+                continue
             pre, s = cur_it.gn(block.norm1, cur, res)
             if block.downsample is not None:
                 ds = block.downsample.conv
@@ -174,8 +229,13 @@ class _Refs(object):
 def _conv_bwd(tape, conv, dy, refs):
     """Input gradient of a frozen convolution for the M rows of ``dy``."""
     dy = dy.contiguous()
+    route = tape.conv_route[id(conv)]
+    if route == "mfma":                     # the folded form's convolutions: always the hand-written kernels
+        return ops._fconv_bwd(1, dy, conv.weight)
+    if route == "mfma3":
+        return ops._fconv_bwd(3, dy, conv.weight)
     ref = refs.get((dy.shape[0],) + tape.conv_in[id(conv)])
-    if tape.conv_route[id(conv)]:
+    if route:
         return conv1x1._run("bwd", dy, conv.weight, ref)
     return libconv.conv_bwd_data(dy, ref, conv.weight, conv.stride, conv.padding)
 
@@ -215,7 +275,13 @@ def backward(net, tape, dlogits, sel=None, through_stem=True):
             d_a = gn_bwd(_conv_bwd(tape, block.conv2, d_b, refs))
             if block.downsample is not None:
                 ds = block.downsample.conv
-                if tape.dual[id(block)]:        # ops.DualConv1x1Function.backward
+                if tape.dual[id(block)] and tape.conv_route.get(id(ds)) == "mfma":      # ops.GnDualConvFunction.backward
+                    g = ops._fconv_bwd(1, d_a.contiguous(), block.conv1.weight)
+                    if ds.stride[0] == 1:
+                        g = ops._fconv_bwd(1, d_short.contiguous(), ds.weight, res=g)
+                    else:
+                        ops.subsample2_add_(g, ops._fconv_bwd(1, d_short.contiguous(), ds.weight))
+                elif tape.dual[id(block)]:      # ops.DualConv1x1Function.backward
                     g = conv1x1._run("bwd", d_a.contiguous(), block.conv1.weight,
                                      refs.get((M,) + tape.conv_in[id(block.conv1)]))
                     if ds.stride[0] == 1:

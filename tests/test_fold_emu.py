@@ -41,6 +41,7 @@ def _run(net, x, dl):
 def mfma_convs(monkeypatch):
     monkeypatch.setenv("HIPEMU_MFMA_CONVS", "1")
     monkeypatch.setattr(conv1x1, "MODE", "mfma")
+    monkeypatch.setattr(resnetv2.GroupNormAct, "fold_min_batch", 1)
     yield
 
 

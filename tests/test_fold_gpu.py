@@ -25,6 +25,9 @@ def test_folded_graph_equals_round4_graph_on_resnetv2_50(N, side, monkeypatch):
     from dorpatch_amd import libconv
     monkeypatch.setattr(conv1x1, "MODE", "mfma")
     monkeypatch.setattr(libconv, "CONV3X3", "on")       # the round-4 graph on the same 3x3 kernel whatever the batch size
+    monkeypatch.setattr(resnetv2.GroupNormAct, "fold_min_batch", 1)
+    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)    # the stride-2 3x3 convolutions stay on MIOpen: at
+    # small batches its default kernels accumulate with float atomics (dorpatch_amd/libconv.py), which would differ run to run
     net = resnetv2.seeded_init_(resnetv2.resnetv2_50x1_bit(), gn_bias=resnetv2.WELL_CONDITIONED_GN_BIAS)
     net = net.fold_weight_standardization().freeze().to(DEV)
     gen = torch.Generator().manual_seed(N)
