@@ -172,6 +172,9 @@ def parse(argv=None):
                     help="1: torch.backends.cudnn.benchmark=True (MIOpen exhaustive find: minutes on a fresh box); "
                          "0: MIOpen immediate mode")
     ap.add_argument("--no-fused-gn", action="store_true", help="eager GroupNorm+ReLU instead of dp_gn_relu_*")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="DorPatch(streams=N): the step's independent micro-batches enqueued round-robin on N HIP streams "
+                         "(default: the product's, DORPATCH_STREAMS or 1)")
     ap.add_argument("--gn-fold", default=None, choices=["on", "off"],
                     help="round 5: GroupNorm-apply + ReLU folded into the consuming convolution's operand staging and the "
                          "residual add into the producing convolution's epilogue (default: on, or DORPATCH_GNFOLD=0); off = "
@@ -629,7 +632,7 @@ def main(argv=None):
     with torch.no_grad():
         clean = torch.cat([model(x[i:i + 64]).argmax(-1) for i in range(0, B, 64)])
     y = (clean + 1 + torch.randint(0, 998, (B,), generator=torch.Generator().manual_seed(7)).to(dev)) % 1000
-    owner = DorPatch(micro_batch=args.micro_batch, process_group=pg, verbose=False,
+    owner = DorPatch(micro_batch=args.micro_batch, process_group=pg, verbose=False, streams=args.streams,
                      deterministic={"auto": "auto", "on": True, "off": False}[args.deterministic])
     # failure_refresh: the every-100-steps collect_failure sweep is timed apart below, never inside the timed steps
     extras = dict(failure_refresh=10 ** 12, stem_split=args.stem_split, skip_satisfied=args.skip_satisfied == "on")
@@ -747,7 +750,7 @@ def main(argv=None):
                                    "patch_budget %.4f" % (args.config_label, B, S_local, B * S_local, H, H, args.stage,
                                                           args.patch_budget),
                        "images": B, "masks_per_image_per_gpu": S_local, "masks_per_image_total": S,
-                       "image_size": H, "micro_batch": args.micro_batch, "miopen_find": bool(args.find),
+                       "image_size": H, "micro_batch": args.micro_batch, "streams": owner.streams, "miopen_find": bool(args.find),
                        "fused_gn_relu": not args.no_fused_gn, "gn_fold": bool(GroupNormAct.fold), "trace": loop.phases.mode, "deterministic": "%s: %s" % (args.deterministic, det_report), "deterministic_forced_problems": det_forced,
                        "backward": {"skip_satisfied": args.skip_satisfied == "on", "explicit_tape": bool(loop._taped),
                                     "samples_forward": loop.n_forward, "samples_with_gradient": loop.n_active,

@@ -32,6 +32,7 @@ Differences from the reference, all deliberate and documented in DESIGN.md:
 * two latent reference bugs on the untargeted path (``set_target`` called with a
   missing argument, ``attack.py:155, 359``) are implemented as evidently intended.
 """
+import contextlib
 import os
 
 import numpy as np
@@ -225,8 +226,13 @@ class DorPatch(object):
     MIOpen's one-off kernel loading for that size.
     """
 
-    def __init__(self, micro_batch=512, process_group=None, verbose=True, deterministic="auto", skip_satisfied=False):
+    def __init__(self, micro_batch=512, process_group=None, verbose=True, deterministic="auto", skip_satisfied=False,
+                 streams=None):
         self.micro_batch = int(micro_batch)
+        # round 5: the step's micro-batches are independent (disjoint images); enqueued round-robin on this many HIP streams
+        # the device overlaps one micro-batch's HBM-bound kernels (GroupNorm, pooling) and launch tails with another's
+        # matrix-core kernels.  Results do not depend on the schedule (no atomics anywhere).  1 = one stream, as before.
+        self.streams = int(os.environ.get("DORPATCH_STREAMS", "1")) if streams is None else int(streams)
         self.skip_satisfied = bool(skip_satisfied)
         if not (deterministic is True or deterministic is False or deterministic == "auto"):
             raise ValueError("deterministic must be True, False or 'auto' (got %r)" % (deterministic,))
@@ -585,6 +591,7 @@ class HotLoop(object):
         n_g, n_slab = B * 3 * H * W, B * self.S_local
         self._n_g, self._n_slab = n_g, n_slab
         self._n_tail = self.world * (2 * n_slab + 1)
+        self._streams = []                  # side streams of the micro-batch loop (DorPatch(streams=...) > 1)
         self._comm = torch.zeros((n_g + self._n_tail + 3 * B,), dtype=torch.float32, device=dev)
         self.g_adv = self._comm[:n_g].view(B, 3, H, W)
         self._tail = self._comm[n_g:n_g + self._n_tail].view(self.world, 2 * n_slab + 1)
@@ -1032,11 +1039,24 @@ class HotLoop(object):
                 self.o._log(">> selected-sample backward not available here (%s): back-propagating every sample" % why)
                 self._taped = False
         if not self._taped:
-            for c in chunks:
+            # image-disjoint micro-batches (no chunk accumulates into another's rows) may run on several streams
+            n_str = min(self.o.streams, len(chunks)) if dev.type == "cuda" and not any(c[6] for c in chunks) else 1
+            if n_str > 1:
+                if len(self._streams) < n_str:
+                    self._streams += [torch.cuda.Stream(device=dev) for _ in range(n_str - len(self._streams))]
+                main = torch.cuda.current_stream(dev)
+                for st in self._streams[:n_str]:
+                    st.wait_stream(main)                  # adv_x / inp_all / idx were produced on the step's stream
+            for k, c in enumerate(chunks):
                 n0, n1, b0, b1, s0, s1, _ = c
-                G = self._fb_chunk(inp_all[n0:n1], y[b0:b1], crit_flags[b0:b1], s1 - s0,
-                                   upstream, loss_flat[n0:n1], pred[n0:n1])
-                self._reduce_chunk(G, c, idx, idx2)
+                with (torch.cuda.stream(self._streams[k % n_str]) if n_str > 1 else contextlib.nullcontext()):
+                    G = self._fb_chunk(inp_all[n0:n1], y[b0:b1], crit_flags[b0:b1], s1 - s0,
+                                       upstream, loss_flat[n0:n1], pred[n0:n1])
+                    self._reduce_chunk(G, c, idx, idx2)
+                    del G
+            if n_str > 1:
+                for st in self._streams[:n_str]:
+                    main.wait_stream(st)
             self.n_active += B * Sl
             self.n_backward += B * Sl
         if compact:                                # scatter the dense batch's results to the images' own rows

@@ -88,7 +88,13 @@ def test_micro_batch_with_shipped_routes_matches_fp64_oracle_and_miopen(n, oracl
     lg, gx = _run_gpu(gpu_net, n)
     routes = conv1x1.report()
     print("batch %d: %s; routes %s; %s" % (n, conv1x1.report_tuned(), routes, libconv.summary()))
-    assert routes["fwd"]["gemm"] + routes["bwd"]["gemm"] >= 10        # the GEMM route really ran at this batch size
+    from dorpatch_amd.resnetv2 import GroupNormAct
+    if GroupNormAct.fold and n >= GroupNormAct.fold_min_batch:
+        # round 5: at this batch the graph is the FOLDED one — nearly every 1x1 convolution runs inside ops.GnConvFunction on
+        # dp_conv1x1_fwd; what is left for the route table (the 7 x 7 planes, stage 3's first block) is on the MFMA kernel too
+        assert routes["fwd"]["mfma"] + routes["bwd"]["mfma"] >= 4 and routes["fwd"]["gemm"] + routes["bwd"]["gemm"] <= 4
+    else:
+        assert routes["fwd"]["gemm"] + routes["bwd"]["gemm"] >= 8     # the GEMM route really ran at this batch size
     want_lg, want_gx = oracle_rows
     _check(lg[ROWS].cpu().numpy(), want_lg, "batch %d logits vs fp64" % n)
     _check(gx[ROWS].cpu().numpy(), want_gx, "batch %d input gradient vs fp64" % n)
