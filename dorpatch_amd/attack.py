@@ -229,10 +229,12 @@ class DorPatch(object):
     def __init__(self, micro_batch=512, process_group=None, verbose=True, deterministic="auto", skip_satisfied=False,
                  streams=None):
         self.micro_batch = int(micro_batch)
-        # round 5: the step's micro-batches are independent (disjoint images); enqueued round-robin on this many HIP streams
-        # the device overlaps one micro-batch's HBM-bound kernels (GroupNorm, pooling) and launch tails with another's
-        # matrix-core kernels.  Results do not depend on the schedule (no atomics anywhere).  1 = one stream, as before.
-        self.streams = int(os.environ.get("DORPATCH_STREAMS", "1")) if streams is None else int(streams)
+        # round 5: the step's micro-batches (and the failure sweep's forwards) are independent (disjoint images / masks);
+        # enqueued round-robin on this many HIP streams the device overlaps one micro-batch's HBM-bound kernels (GroupNorm,
+        # pooling) and launch tails with another's matrix-core kernels.  Results do not depend on the schedule (no atomics
+        # anywhere; every micro-batch writes its own rows).  Default 2: 393 -> 369 ms per configs[1] step, 4 streams 373
+        # (profiles/r05g_*); 1 = one stream, as before round 5.  Costs one more micro-batch of live activations.
+        self.streams = int(os.environ.get("DORPATCH_STREAMS", "2")) if streams is None else int(streams)
         self.skip_satisfied = bool(skip_satisfied)
         if not (deterministic is True or deterministic is False or deterministic == "auto"):
             raise ValueError("deterministic must be True, False or 'auto' (got %r)" % (deterministic,))
@@ -399,8 +401,20 @@ def sweep_plan(B, rows):
     return plan
 
 
+def _side_streams(pool, n, dev):
+    """``n`` side streams on ``dev`` from the caller's ``pool`` (a list that keeps them across calls), all waiting for the
+    current stream; -> (streams, current stream)."""
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    main = torch.cuda.current_stream(dev)
+    for st in pool[:n]:
+        st.wait_stream(main)
+    return pool[:n], main
+
+
 @torch.no_grad()
-def _collect_failure(net, norm, adv_x, y_img, table, targeted_flags, batch_size, pg=None, plan=None):
+def _collect_failure(net, norm, adv_x, y_img, table, targeted_flags, batch_size, pg=None, plan=None, streams=1,
+                     stream_pool=None):
     """Per-image failed-mask lists (attack.py:384-406).  ``y_img`` (B,) int64 device tensor,
     ``targeted_flags`` bool or (B,) bool array.  Ranks of ``pg`` each sweep a slice of the
     universe and exchange a (B, n_mask) failure bitmap.  ``plan``: [(first image, end image, masks per forward)]
@@ -419,20 +433,32 @@ def _collect_failure(net, norm, adv_x, y_img, table, targeted_flags, batch_size,
     pad_tail = plan is not None       # the reference's own loop (public collect_failure) runs its short last batch as is
     if plan is None:
         plan = [(0, B, max(1, int(batch_size)))]
+    # the forwards are independent (disjoint slices of `fail`): round-robin over `streams` HIP streams, like the step's
+    # micro-batches (DorPatch(streams=...)), so one forward's HBM-bound kernels overlap another's matrix-core kernels
+    n_str = int(streams) if dev.type == "cuda" and streams and streams > 1 else 1
+    if n_str > 1:
+        side, main = _side_streams([] if stream_pool is None else stream_pool, n_str, dev)
+    k = 0
     for b0, b1, chunk in plan:
         chunk = max(1, min(chunk, hi - lo))          # a universe (slice) smaller than one forward: no padding beyond it
         g = b1 - b0
         xg, yg, tg = adv_x[b0:b1], y_img[b0:b1].view(g, 1).to(torch.int32), tflag[b0:b1].view(g, 1)
         for j0 in range(lo, hi, chunk):
             j1 = min(hi, j0 + chunk)
-            idx = torch.arange(j0, j1, dtype=torch.int32, device=dev)
-            if pad_tail and j1 - j0 < chunk:      # the last, short chunk: repeat its last mask so the classifier sees
-                idx = torch.cat([idx, idx[-1:].expand(chunk - (j1 - j0))])     # the row count it has seen all along
-            inp = ops.apply_fwd(xg, table, idx, None, dn)
-            pred = ops.argmax(net(inp).float().contiguous()).view(g, idx.numel())[:, :j1 - j0]
-            same = pred == yg
-            # untargeted: still classified as y => failure; targeted: not (yet) the target => failure
-            fail[b0:b1, j0:j1] = torch.where(tg, ~same, same).to(torch.int32)
+            with (torch.cuda.stream(side[k % n_str]) if n_str > 1 else contextlib.nullcontext()):
+                idx = torch.arange(j0, j1, dtype=torch.int32, device=dev)
+                if pad_tail and j1 - j0 < chunk:      # the last, short chunk: repeat its last mask so the classifier sees
+                    idx = torch.cat([idx, idx[-1:].expand(chunk - (j1 - j0))])     # the row count it has seen all along
+                inp = ops.apply_fwd(xg, table, idx, None, dn)
+                pred = ops.argmax(net(inp).float().contiguous()).view(g, idx.numel())[:, :j1 - j0]
+                same = pred == yg
+                # untargeted: still classified as y => failure; targeted: not (yet) the target => failure
+                fail[b0:b1, j0:j1] = torch.where(tg, ~same, same).to(torch.int32)
+                del inp, pred, same
+            k += 1
+    if n_str > 1:
+        for st in side:
+            main.wait_stream(st)
     dp_dist.allreduce_max_(fail, pg)
     fail_np = fail.cpu().numpy().astype(bool)
     return [np.nonzero(fail_np[b])[0].tolist() for b in range(B)]
@@ -790,7 +816,8 @@ class HotLoop(object):
             sel = torch.as_tensor(act, dtype=torch.int64, device=self.dev)
             adv_x, y, flags = adv_x.index_select(0, sel), y.index_select(0, sel), flags[act]
         lists = _collect_failure(self.net, self.norm, adv_x.contiguous(), y, self.table, flags, None, pg=self.o.pg,
-                                 plan=sweep_plan(len(act), self.o.micro_batch))
+                                 plan=sweep_plan(len(act), self.o.micro_batch), streams=self.o.streams,
+                                 stream_pool=self._streams)
         for b, l in zip(act, lists):
             if self.img[b].active:
                 self.img[b].failed_idxs = l
@@ -1041,12 +1068,8 @@ class HotLoop(object):
         if not self._taped:
             # image-disjoint micro-batches (no chunk accumulates into another's rows) may run on several streams
             n_str = min(self.o.streams, len(chunks)) if dev.type == "cuda" and not any(c[6] for c in chunks) else 1
-            if n_str > 1:
-                if len(self._streams) < n_str:
-                    self._streams += [torch.cuda.Stream(device=dev) for _ in range(n_str - len(self._streams))]
-                main = torch.cuda.current_stream(dev)
-                for st in self._streams[:n_str]:
-                    st.wait_stream(main)                  # adv_x / inp_all / idx were produced on the step's stream
+            if n_str > 1:                                 # adv_x / inp_all / idx were produced on the step's stream
+                _, main = _side_streams(self._streams, n_str, dev)
             for k, c in enumerate(chunks):
                 n0, n1, b0, b1, s0, s1, _ = c
                 with (torch.cuda.stream(self._streams[k % n_str]) if n_str > 1 else contextlib.nullcontext()):

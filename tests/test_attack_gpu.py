@@ -338,6 +338,35 @@ def test_micro_batching_does_not_change_the_step(mb):
     np.testing.assert_allclose(outs[0]["g_adv"].numpy(), outs[1]["g_adv"].numpy(), rtol=1e-4, atol=1e-5 * scale)
 
 
+@pytest.mark.parametrize("streams", [2, 3])
+def test_side_streams_do_not_change_the_step_or_the_sweep(streams):
+    """DorPatch(streams=N): image-disjoint micro-batches (and the failure sweep's forwards) enqueued round-robin on N HIP
+    streams — every micro-batch writes its own rows, nothing accumulates across streams: bit-identical to one stream."""
+    H, S, B = 56, 8, 4
+    model = _toy(2.0)
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(B, 3, H, H, generator=g)
+    m0, p0 = torch.rand(B, 1, H, H, generator=g), torch.rand(B, 3, H, H, generator=g)
+    rows = [np.random.RandomState(b).choice(2520, S, replace=False) for b in range(B)]
+    outs, fails = [], []
+    for n_str in (1, streams):
+        got = {}
+        loop = HotLoop(DorPatch(micro_batch=S, verbose=False, streams=n_str), model, x.to(DEV), 0.12, 10, "t/cfg/sub", 0,
+                       torch.tensor([2, 3, 4, 5], device=DEV), True, 1e-2, 1e-1, 0, 1, 10 ** 6, 7, 'topk', 2, S, 1e-3, 1e-3,
+                       4.0, False, dict(failure_refresh=10 ** 9, init_mask=m0, init_pattern=p0, step_hook=_grab(got),
+                                        rngs=[FixedDraw([rows[b], rows[b][::-1]]) for b in range(B)]))
+        assert loop.o.streams == n_str
+        loop.step(1)
+        loop.step(2)
+        loop._refresh_failures()
+        fails.append([list(st.failed_idxs) for st in loop.img])
+        outs.append(dict(got, mask=loop.adv_mask.detach().cpu().clone(), pattern=loop.adv_pattern.detach().cpu().clone()))
+        loop.close()
+    for k in ("g_adv", "loss_adv", "mask", "pattern"):
+        assert torch.equal(torch.as_tensor(outs[0][k]), torch.as_tensor(outs[1][k])), k
+    assert fails[0] == fails[1] and any(len(f) for f in fails[0])
+
+
 def _retire_run(retire, *, mb, dropout=1, S=6, B=4, H=56, steps=6, stop_at=(2, 3), dual=False, stage=0):
     """`steps` steps of a B-image loop; image 1 is marked finished after step stop_at[0]-1, image 3 after stop_at[1]-1
     (what `_ImageState.step` does at attack.py:311-316).  The failure sweep runs at steps 0, 2, 4."""
