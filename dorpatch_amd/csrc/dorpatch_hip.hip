@@ -3281,6 +3281,215 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3_mfma(const float *__restr
 }
 
 // ----------------------------------------------------------------------------
+// a-8 (round 5): the backbone's three 3 x 3 / STRIDE 2 / pad 1 convolutions (the second convolution of
+// the first bottleneck of stages 2-4: 128 @56^2 -> 28^2, 256 @28^2 -> 14^2, 512 @14^2 -> 7^2) on the matrix cores, NCHW in
+// place.  MIOpen runs them as NHWC implicit GEMMs wrapped in batched_transpose_* / SubTensorOpWithScalar1d kernels, and the
+// first one as a stride-2 Winograd at 51 TFLOP/s (profiles/r05b_kernel_stats_timed_fold.txt: 2.32 ms per 512 samples).
+// Same MFMA walk, tile (448 batch-linear OUTPUT pixels x 64 output channels) and packed weights as k_conv3x3_mfma.  What
+// differs is the LDS image of the input: an output pixel (h, w) reads input rows 2h - 1 .. 2h + 1 and columns 2w - 1 ..
+// 2w + 1, so the input is stored DE-INTERLEAVED — per channel and per output row h four sub-rows (row parity pr, column
+// parity pc): sub-row 2 pr + pc holds x[2h + pr][2w + pc] at column X0 + w.  Tap (kh, kw) of pixel (h, w) is then the lane's
+// base + (2 (kh - 1) + (kw != 1)) PITCH - (kw == 0): a compile-time immediate, consecutive lanes on consecutive words.
+// Padding: only above and to the left (2 S - 1 is the last input row / column): the zero row between images of the
+// "virtual row" stack n (S + 1) + h is the top padding of image n + 1, column X0 - 1 of every sub-row is zero.
+// The input of a tile is 4 x its output pixels, so a K-chunk is ONE channel pair (2 channels x <= 3000 floats + 1152
+// weights: 2 buffers x <= 32 KB, 2 workgroups per CU) = the 9 taps = 63 MFMAs per wave and barrier; staging as in
+// k_conv1x1_mfma: chunk c + 1 goes from registers to the other buffer one item per MFMA group during chunk c while chunk
+// c + 2 is requested into the registers this frees (a whole chunk in flight), branch-free, barrier on LDS traffic only and
+// placed before the last group's MFMAs.  FOLD as in k_conv3x3_mfma (the GroupNorm + ReLU in front of conv2 never written).
+constexpr int kCv2Ch = 2;                               // input channels per K-chunk (one channel pair)
+constexpr int kCv2Steps = 9;                            // MFMA k-steps per chunk: the 9 taps
+constexpr int kCv2WtFloats = kCv2Steps * 2 * kCvO;      // 1152 floats of packed weights per (oc group, chunk)
+constexpr int kCv2WtF4 = kCv2WtFloats / 4;              // 288 float4
+constexpr int kCv2WtIt = (kCv2WtF4 + kBlock - 1) / kBlock;   // 2 per thread; the LDS region is padded to 2 x kBlock float4
+
+template <int SO>
+struct Cv2Geom {
+  static constexpr int SI = 2 * SO;                                        // input side
+  static constexpr int VW = (SI % 4 == 0) ? 4 : 2;                         // floats per staging load
+  static constexpr int X0 = 2;                                             // LDS column of output column 0 (even: aligned f2)
+  static constexpr int PITCH = ((X0 + SO + 1) / 2) * 2;                    // 30 / 16 / 10
+  // output rows of a tile (448 / SO) + one zero row per image boundary it can cross + the row above
+  static constexpr int ROWS = SO == 28 ? 18 : SO == 14 ? 36 : 75;
+  static constexpr int CHS = ROWS * 4 * PITCH;                             // floats per channel
+  static constexpr int IN = kCv2Ch * CHS;
+  static constexpr int BUF = IN + kCv2WtIt * kBlock * 4;
+  static constexpr int VPR = SI / VW;                                      // staging vectors per input row
+  static constexpr int NV = kCv2Ch * ROWS * 2 * VPR, IT = (NV + kBlock - 1) / kBlock;     // 4 / 4 / 9 items per thread
+  static_assert(IT <= 16 && IN % 4 == 0, "item schedule / float4 alignment of the weights");
+};
+
+template <int SO, bool FOLD>
+__global__ __launch_bounds__(kBlock, 2) void k_conv3x3s2_mfma(const float *__restrict__ x, const float *__restrict__ wt,
+                                                              float *__restrict__ y, int N, int C, int O,
+                                                              const float *__restrict__ ab) {
+  typedef Cv2Geom<SO> G;
+  typedef typename CvVec<G::VW>::T vec_t;
+  __shared__ __attribute__((aligned(16))) float lds[2 * G::BUF];
+  constexpr int HW = SO * SO, SI = G::SI;
+  const int NCH = C / kCv2Ch;
+  const int total = N * HW;                                  // < 2^31 (checked by the launcher)
+  const int g0 = blockIdx.x * kCvPix;                        // first OUTPUT pixel of the tile (batch-linear)
+  const int n0 = g0 / HW, h0 = (g0 - n0 * HW) / SO;
+  const int vr0 = n0 * (SO + 1) + h0 - 1;                    // virtual row of LDS row 0 (the row above the tile)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int ocf = wave & 1, pf0 = wave >> 1;
+  const float *wtg = wt + (size_t)blockIdx.y * NCH * kCv2WtFloats;
+
+  // zero column X0 - 1 of every sub-row of both buffers (never written again; item stores of lanes without an item write
+  // zeros over word 0 / 1 of sub-rows 0 / 1, which keeps it zero)
+  for (int i = tid; i < 2 * kCv2Ch * G::ROWS * 4; i += kBlock) {
+    const int buf = i / (kCv2Ch * G::ROWS * 4), r = i - buf * (kCv2Ch * G::ROWS * 4);
+    lds[buf * G::BUF + r * G::PITCH + G::X0 - 1] = 0.f;
+  }
+
+  // staging items: (channel, LDS row, input-row parity, vector of the input row) -> element offset at chunk 0 (-1: zeros),
+  // LDS offset of the even-column half (the odd-column half is one PITCH further), coefficient index
+  int gofs[G::IT], lofs[G::IT], aofs[FOLD ? G::IT : 1];
+#pragma unroll
+  for (int it = 0; it < G::IT; ++it) {
+    const int i = tid + it * kBlock;
+    const int ch = i / (G::ROWS * 2 * G::VPR), rem = i - ch * (G::ROWS * 2 * G::VPR);
+    const int row = rem / (2 * G::VPR), rem2 = rem - row * (2 * G::VPR);
+    const int pr = rem2 / G::VPR, q = rem2 - pr * G::VPR;
+    const int vr = vr0 + row;
+    const int n = vr / (SO + 1), h = vr - n * (SO + 1);
+    const bool ok = i < G::NV && vr >= 0 && h < SO && n < N;
+    gofs[it] = ok ? ((n * C + ch) * SI + 2 * h + pr) * SI + q * G::VW : -1;
+    lofs[it] = i < G::NV ? ch * G::CHS + (row * 4 + pr * 2) * G::PITCH + G::X0 + q * (G::VW / 2) : 0;
+    if (FOLD) aofs[it] = ok ? n * C + ch : 0;
+  }
+
+  vec_t pin[G::IT];
+  f2 pab[FOLD ? G::IT : 1];
+  f4 pwt[kCv2WtIt];
+  auto fetch_item = [&](int chunk, int it) {     // global -> registers; every load is issued unconditionally
+    pin[it] = *reinterpret_cast<const vec_t *>(x + (size_t)chunk * (kCv2Ch * SI * SI) + (gofs[it] < 0 ? 0 : gofs[it]));
+    if (FOLD) pab[it] = *reinterpret_cast<const f2 *>(ab + 2 * ((size_t)chunk * kCv2Ch + aofs[it]));
+  };
+  auto fetch_w = [&](int chunk, int k) {
+    const int i = tid + k * kBlock;
+    pwt[k] = *reinterpret_cast<const f4 *>(wtg + (size_t)chunk * kCv2WtFloats + 4 * (i < kCv2WtF4 ? i : 0));
+  };
+  auto stash_item = [&](int buf, int it) {       // registers -> LDS, de-interleaving the columns
+    vec_t v = pin[it];
+    float *e = reinterpret_cast<float *>(&v);
+    if (FOLD) {                                  // dp_gn_relu_fwd's own expression: x * a + b (not fused), max 0
+      const float a = pab[it].x, b = pab[it].y;
+#pragma unroll
+      for (int k = 0; k < G::VW; ++k) e[k] = fmaxf(e[k] * a + b, 0.f);
+    }
+    if (gofs[it] < 0) {
+#pragma unroll
+      for (int k = 0; k < G::VW; ++k) e[k] = 0.f;
+    }
+    float *dst = lds + buf * G::BUF + lofs[it];
+    if (G::VW == 4) {
+      *reinterpret_cast<f2 *>(dst) = f2{e[0], e[2]};
+      *reinterpret_cast<f2 *>(dst + G::PITCH) = f2{e[1], e[3]};
+    } else {
+      dst[0] = e[0];
+      dst[G::PITCH] = e[1];
+    }
+  };
+  auto stash_w = [&](int buf, int k) {
+    *reinterpret_cast<f4 *>(lds + buf * G::BUF + G::IN + 4 * (tid + k * kBlock)) = pwt[k];
+  };
+  auto fetch = [&](int chunk) {
+#pragma unroll
+    for (int it = 0; it < G::IT; ++it) fetch_item(chunk, it);
+#pragma unroll
+    for (int k = 0; k < kCv2WtIt; ++k) fetch_w(chunk, k);
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < G::IT; ++it) stash_item(buf, it);
+#pragma unroll
+    for (int k = 0; k < kCv2WtIt; ++k) stash_w(buf, k);
+  };
+
+  // lane bases: A = weights [tap][half][oc]; B = sub-row 0, column X0 + w of the lane's pixel, channel parity = half.
+  // A pixel past the end of the batch (last tile only) reads the tile's first pixel and is never stored.
+  const int abase = G::IN + half * kCvO + ocf * 32 + l32;
+  int boff[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    int g = g0 + (pf0 + 2 * q) * 32 + l32;
+    if (g >= total) g = g0;
+    const int n = g / HW, p = g - n * HW;
+    const int h = p / SO, w = p - h * SO;
+    boff[q] = half * G::CHS + (n * (SO + 1) + h - vr0) * 4 * G::PITCH + G::X0 + w;
+  }
+  f16v acc[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
+
+  auto operands = [&](const float *cur, int t, float &a, float (&bv)[7]) {
+    const int kh = t / 3, kw = t - 3 * kh;
+    const int koff = (2 * (kh - 1) + (kw != 1 ? 1 : 0)) * G::PITCH - (kw == 0 ? 1 : 0);
+    a = cur[abase + t * 2 * kCvO];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) bv[q] = cur[boff[q] + koff];
+  };
+
+  fetch(0);
+  stash(0);
+  fetch(NCH > 1 ? 1 : 0);
+  DP_BARRIER_LDS();
+  float an, bn[7];                     // step 0 of the next chunk, requested behind the chunk's barrier
+  operands(lds, 0, an, bn);
+  const int last = NCH - 1;
+  for (int chunk = 0; chunk < NCH; ++chunk) {
+    const float *cur = lds + (chunk & 1) * G::BUF;
+    const int nb = (chunk + 1) & 1;
+    const int c2 = chunk + 2 < NCH ? chunk + 2 : last;    // past the end of K the staging repeats the last chunk (branch-free)
+    float a[2], b[2][7];
+    a[0] = an;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) b[0][q] = bn[q];
+#pragma unroll
+    for (int t = 0; t < kCv2Steps; ++t) {
+      if (t + 1 < kCv2Steps) {
+        operands(cur, t + 1, a[(t + 1) & 1], b[(t + 1) & 1]);
+      } else {
+        // every read of this buffer has been issued and every wave's stores of the next chunk are done
+        DP_BARRIER_LDS();
+        operands(lds + nb * G::BUF, 0, an, bn);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t & 1], b[t & 1][q], acc[q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < kCv2Steps) {         // after MFMA group t (0..7): items t, t + 8 of chunk c + 1 to LDS, of chunk c + 2 requested
+#pragma unroll
+        for (int it = t; it < G::IT; it += kCv2Steps - 1) {
+          stash_item(nb, it);
+          fetch_item(c2, it);
+        }
+        if (t < kCv2WtIt) {
+          stash_w(nb, t);
+          fetch_w(c2, t);
+        }
+      }
+    }
+  }
+
+  const int oc0 = blockIdx.y * kCvO + ocf * 32 + 4 * half;
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const int g = g0 + (pf0 + 2 * q) * 32 + l32;
+    if (g >= total) continue;
+    const int n = g / HW, p = g - n * HW;
+    float *yq = y + ((size_t)n * O + oc0) * HW + p;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) yq[(size_t)((v & 3) + 8 * (v >> 2)) * HW] = acc[q][v];
+  }
+}
+
+// ----------------------------------------------------------------------------
 // a-8 (round 5, VERDICT r4 items 1 + 2): the backbone's 1 x 1 / stride 1 convolutions on the matrix cores — 33 of
 // ResNetV2-50's 53 convolutions, 17.4 of the 33.5 TFLOP of a configs[1] step, until now Tensile / MIOpen NHWC kernels.
 //     forward         y[n]  (O x HW) = W   (O x C) x[n]  (C x HW)
@@ -3900,6 +4109,29 @@ int dp_conv3x3_gn_fwd(const float *x, const float *wt, const float *ab, int N, i
                       dp_stream_t stream) {
   DP_REQUIRE(ab);
   return conv3x3_launch(x, wt, ab, N, C, O, H, W, y, stream);
+}
+
+int dp_conv3x3s2_fwd(const float *x, const float *wt, const float *ab, int N, int C, int O, int H, int W, float *y,
+                     dp_stream_t stream) {
+  DP_REQUIRE(x && wt && y && aligned16(x) && aligned16(wt) && aligned16(y));
+  DP_REQUIRE(N > 0 && C > 0 && C % kCvCh == 0 && O > 0 && O % kCvO == 0 && O / kCvO <= 65535 && H == W);
+  DP_REQUIRE(H == 56 || H == 28 || H == 14);                          // INPUT side; the output is (H / 2) x (H / 2)
+  DP_REQUIRE(!ab || (reinterpret_cast<uintptr_t>(ab) & 7u) == 0);
+  DP_REQUIRE((long)N * C * H * W < (1L << 31));                       // 32-bit element offsets in the kernel
+  const int SO = H / 2;
+  const long tiles = ((long)N * SO * SO + kCvPix - 1) / kCvPix;
+  const dim3 grid((unsigned)tiles, O / kCvO), block(kBlock);
+  hipStream_t st = as_stream(stream);
+#define DP_LAUNCH_CV2(SO_)                                                                                        \
+  do {                                                                                                            \
+    if (ab) hipLaunchKernelGGL((k_conv3x3s2_mfma<SO_, true>), grid, block, 0, st, x, wt, y, N, C, O, ab);        \
+    else hipLaunchKernelGGL((k_conv3x3s2_mfma<SO_, false>), grid, block, 0, st, x, wt, y, N, C, O, ab);          \
+  } while (0)
+  if (SO == 28) DP_LAUNCH_CV2(28);
+  else if (SO == 14) DP_LAUNCH_CV2(14);
+  else DP_LAUNCH_CV2(7);
+#undef DP_LAUNCH_CV2
+  return launch_status();
 }
 
 int dp_conv1x1_fwd(const float *x, const float *wt, const float *ab, const float *res, int N, int C, int O, int HW,

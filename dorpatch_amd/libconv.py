@@ -52,6 +52,12 @@ except (OSError, ValueError, KeyError) as _e:      # a missing / malformed table
 for _extra in filter(None, os.environ.get("DORPATCH_CONV3X3_ALSO", "").split(",")):     # A/B knob: "fwd:512:7,bwd:512:7"
     _d, _c, _s = _extra.split(":")                                                       # -> also on dp_conv3x3_fwd, at
     CONV3X3_TABLE.setdefault(512, {})[(_d, int(_c), int(_s))] = "mfma"                   # batches >= 512
+# The three stride-2 3x3 convolutions (round 5): forward on dp_conv3x3s2_fwd ("on", default: at every batch the kernel was
+# measured at it beats MIOpen's NHWC implicit GEMM + transposes / stride-2 Winograd, profiles/r05h_*), or MIOpen ("off").
+CONV3X3S2 = os.environ.get("DORPATCH_CONV3X3S2", "on")
+if CONV3X3S2 not in ("on", "off"):
+    raise ValueError("DORPATCH_CONV3X3S2 must be on or off, got %r" % CONV3X3S2)
+CONV3X3S2_MIN_BATCH = int(os.environ.get("DORPATCH_CONV3X3S2_MIN_BATCH", "64"))
 _used3 = {}          # (direction, route) -> set of (N, C, S) routed (report_conv3x3())
 
 
@@ -155,6 +161,11 @@ def conv_fwd(x, w, stride=(1, 1), padding=(0, 0)):
     if w.shape[2] == 3 and _conv3x3_route("fwd", x, w, stride, padding):
         from . import ops
         return ops.conv3x3_fwd(x, _packed3(w, False))
+    if w.shape[2] == 3 and tuple(stride) == (2, 2) and CONV3X3S2 == "on" and x.shape[0] >= CONV3X3S2_MIN_BATCH:
+        from . import ops
+        if ops.conv3x3s2_supported(x, w, stride, padding):
+            _used3.setdefault(("fwd", "mfma"), set()).add((int(x.shape[0]), int(w.shape[1]), -int(x.shape[2])))
+            return ops.conv3x3s2_fwd(x, _packed3(w, False))
     if MODE != "auto":
         return F.conv2d(x, w, None, stride, padding)
     return guard(_key("fwd", x.shape[0], w, stride, x.shape[2:], padding), lambda: F.conv2d(x, w, None, stride, padding))

@@ -405,6 +405,40 @@ def conv3x3_fwd(x, wt, ab=None):
     return _timed_conv("k_conv3x3_mfma", (N, C, O, H * W, ab is not None, False), 18.0 * N * H * W * C * O, launch)
 
 
+CONV3X3S2_SIDES = (56, 28, 14)        # INPUT sides of the stride-2 kernel (ResNetV2-50 at 224 x 224)
+
+
+def conv3x3s2_supported(x, weight, stride=(2, 2), padding=(1, 1)):
+    """Shapes dp_conv3x3s2_fwd takes: fp32 GPU NCHW, 3x3 / stride 2 / pad 1, square planes of side 56 / 28 / 14,
+    C % 8 == 0, O % 64 == 0 (conv2 of the first bottleneck of stages 2-4 of ResNetV2-50 at 224 x 224)."""
+    return (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+            and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (2, 2) and tuple(padding) == (1, 1)
+            and x.shape[2] == x.shape[3] and x.shape[2] in CONV3X3S2_SIDES and weight.shape[1] == x.shape[1]
+            and weight.shape[1] % 8 == 0 and weight.shape[0] % 64 == 0
+            and x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] < 2 ** 31)
+
+
+def conv3x3s2_fwd(x, wt, ab=None):
+    """y = conv2d(x', w, stride 2, padding 1) for x (N,C,S,S), S in 56 / 28 / 14, wt = pack_conv3x3_weights(w), on
+    v_mfma_f32_32x32x2_f32 (same summation order as conv3x3_fwd).  ``ab`` (N,C,2) from ``gn_stats``:
+    x' = relu(group_norm(x)) applied while staging (x is the RAW tensor)."""
+    lib = _lib.load()
+    _chk(x, torch.float32, "x"), _chk(wt, torch.float32, "wt")
+    N, C, H, W = x.shape
+    O = wt.shape[0] * wt.shape[-1]
+    assert wt.numel() == C * 9 * O
+    y = torch.empty((N, O, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    if ab is not None:
+        _chk(ab, torch.float32, "ab")
+        assert ab.numel() == N * C * 2
+
+    def launch():
+        _lib.check(lib.dp_conv3x3s2_fwd(_p(x), _p(wt), _p(ab), N, C, O, H, W, _p(y), _stream()), "dp_conv3x3s2_fwd")
+        return y
+    return _timed_conv("k_conv3x3s2_mfma", (N, C, O, H * W // 4, ab is not None, False), 18.0 * N * (H // 2) * (W // 2) * C * O,
+                       launch)
+
+
 # ---------------------------------------------------------------- a-8: 1x1 convolutions on the matrix cores (round 5)
 def conv1x1_supported(x, weight):
     """Shapes dp_conv1x1_fwd takes: fp32 GPU NCHW, (O, C, 1, 1) filter with C % 16 == 0 and O % 64 == 0, planes of
@@ -790,33 +824,42 @@ def _fconv_fwd(kind, x, w, ab, res):
     if kind == 1:
         return conv1x1_fwd(x, libconv.packed1(w, False), ab=ab, res=res)
     assert res is None
+    if kind == 32:          # 3x3 / stride 2
+        return conv3x3s2_fwd(x, libconv._packed3(w, False), ab=ab)
     return conv3x3_fwd(x, libconv._packed3(w, False), ab=ab)
 
 
-def _fconv_bwd(kind, dy, w, res=None):
+def _fconv_bwd(kind, dy, w, res=None, x_ref=None):
     from . import libconv
     if kind == 1:
         return conv1x1_fwd(dy, libconv.packed1(w, True), res=res, out=res)
     assert res is None
+    if kind == 32:          # the input gradient of the strided convolution stays with the library (x_ref: its shape only)
+        return libconv.conv_bwd_data(dy, x_ref, w, (2, 2), (1, 1))
     return conv3x3_fwd(dy, libconv._packed3(w, True))
 
 
 def gn_fold_supported(x, conv_weight, groups, stride=(1, 1), padding=None):
     """Can ``conv(relu(group_norm(x)))`` run as dp_gn_stats + a convolution that applies the norm while staging?
-    1x1 / stride 1: any plane of H*W % 4 == 0 pixels; 3x3 / stride 1 / pad 1: square planes of side 56 / 28 / 14."""
+    1x1 / stride 1: any plane of H*W % 4 == 0 pixels; 3x3 / stride 1 / pad 1: square planes of side 56 / 28 / 14;
+    3x3 / stride 2 / pad 1: the same sides (dp_conv3x3s2_fwd; forward only — its input gradient is the library's)."""
     if not gn_relu_supported(x, groups) or x.dim() != 4:
         return False
     k = tuple(conv_weight.shape[2:])
     if k == (1, 1):
         return tuple(stride) == (1, 1) and (x.shape[2] * x.shape[3]) % 4 == 0 and conv1x1_supported(x, conv_weight)
     if k == (3, 3):
-        return (conv3x3_supported(x, conv_weight, stride, (1, 1) if padding is None else padding)
-                and x.shape[2] in CONV3X3_FOLD_SIDES)
+        padding = (1, 1) if padding is None else padding
+        if tuple(stride) == (2, 2):
+            from . import libconv
+            return libconv.CONV3X3S2 != "off" and conv3x3s2_supported(x, conv_weight, stride, padding)
+        return conv3x3_supported(x, conv_weight, stride, padding) and x.shape[2] in CONV3X3_FOLD_SIDES
     return False
 
 
 class GnConvFunction(torch.autograd.Function):
-    """``out = conv(relu(group_norm(x)), w) [+ add]`` for a frozen 1x1 (``kind`` 1) or 3x3 (``kind`` 3) stride-1 filter,
+    """``out = conv(relu(group_norm(x)), w) [+ add]`` for a frozen 1x1 (``kind`` 1), 3x3 (``kind`` 3) stride-1 or 3x3
+    stride-2 (``kind`` 32: own forward, the library's input gradient) filter,
     the GroupNorm-apply + ReLU folded into the convolution's operand staging: one statistics pass over x
     (dp_gn_stats), then dp_conv1x1_fwd / dp_conv3x3_gn_fwd read the RAW x — the normalised activation is never written or
     re-read.  ``add`` (1x1 only): the residual, added in the convolution's epilogue.  ``passthrough``: also return x itself
@@ -841,7 +884,7 @@ class GnConvFunction(torch.autograd.Function):
         dx = d_pass
         if d_out is not None:
             d_out = d_out.contiguous()
-            dy = _fconv_bwd(ctx.kind, d_out, w)
+            dy = _fconv_bwd(ctx.kind, d_out, w, x_ref=x)
             dx = gn_relu_bwd(dy, x, gamma, beta, mean, rstd, ctx.groups, dres=None if d_pass is None else d_pass.contiguous())
         return dx, None, None, None, None, None, None, (d_out if ctx.has_add else None), None
 

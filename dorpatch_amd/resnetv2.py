@@ -177,8 +177,8 @@ class PreActBottleneck(nn.Module):
     def forward_sum(self, x):
         """Folded form: ``x`` is the block's materialised input (the previous block's ``branch + shortcut``, added in that
         block's last convolution), the result is this block's materialised output.  GroupNorm-apply + ReLU run inside the
-        consuming convolution wherever the MFMA kernels take the shape (``ops.GnConvFunction``); elsewhere (7 x 7 planes,
-        the stride-2 3x3) the norm is materialised as before."""
+        consuming convolution wherever the MFMA kernels take the shape (``ops.GnConvFunction``, incl. the stride-2 3x3 on
+        dp_conv3x3s2_fwd); elsewhere (7 x 7 planes) the norm is materialised as before."""
         from . import ops
         n1, n2, n3 = self.norm1, self.norm2, self.norm3
         G, w1, w2, w3 = n1.num_groups, self.conv1.weight, self.conv2.weight, self.conv3.weight
@@ -197,7 +197,8 @@ class PreActBottleneck(nn.Module):
             shortcut, pre = ops.GnReluPassFunction.apply(x, n1.weight, n1.bias, G, n1.eps)
             out = conv1x1.Conv1x1Function.apply(pre, w1)
         if ops.gn_fold_supported(out, w2, n2.num_groups, self.conv2.stride, self.conv2.padding):
-            out = ops.GnConvFunction.apply(out, n2.weight, n2.bias, n2.num_groups, n2.eps, w2, 3, None, False)
+            out = ops.GnConvFunction.apply(out, n2.weight, n2.bias, n2.num_groups, n2.eps, w2,
+                                           3 if self.conv2.stride[0] == 1 else 32, None, False)
         else:
             out = self.conv2(n2(out))
         if ops.gn_fold_supported(out, w3, n3.num_groups):

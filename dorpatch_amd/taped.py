@@ -149,8 +149,9 @@ def _block_sum(tape, it, block, x):
         tape.conv_route[id(c1)] = True
     if ops.gn_fold_supported(branch, c2.weight, n2.num_groups, c2.stride, c2.padding):
         ab, _ = it.gn(n2, branch, None, stats_only=True)
-        tape.conv_in[id(c2)], tape.conv_route[id(c2)] = tuple(branch.shape[1:]), "mfma3"
-        b = ops._fconv_fwd(3, branch.contiguous(), c2.weight, ab, None)
+        kind = 3 if c2.stride[0] == 1 else 32
+        tape.conv_in[id(c2)], tape.conv_route[id(c2)] = tuple(branch.shape[1:]), "mfma%d" % kind
+        b = ops._fconv_fwd(kind, branch.contiguous(), c2.weight, ab, None)
     else:
         y2, _ = it.gn(n2, branch, None)
         b = _conv_fwd(tape, c2, y2)
@@ -235,6 +236,8 @@ def _conv_bwd(tape, conv, dy, refs):
     if route == "mfma3":
         return ops._fconv_bwd(3, dy, conv.weight)
     ref = refs.get((dy.shape[0],) + tape.conv_in[id(conv)])
+    if route == "mfma32":                   # stride-2 3x3: own forward, the library's input gradient
+        return ops._fconv_bwd(32, dy, conv.weight, x_ref=ref)
     if route:
         return conv1x1._run("bwd", dy, conv.weight, ref)
     return libconv.conv_bwd_data(dy, ref, conv.weight, conv.stride, conv.padding)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DP_ABI_VERSION 9
+#define DP_ABI_VERSION 10
 #define DP_MAX_RECTS 4 /* occlusion windows per mask-table entry */
 
 typedef void *dp_stream_t; /* hipStream_t */
@@ -237,6 +237,17 @@ int dp_conv3x3_fwd(const float *x, const float *wt, int N, int C, int O, int H, 
  * (the zero padding pads the normalised activation).  H = W in {56, 28, 14}. */
 int dp_conv3x3_gn_fwd(const float *x, const float *wt, const float *ab, int N, int C, int O, int H, int W, float *y,
                       dp_stream_t stream);
+
+/* ---- a-8: the 3x3 / STRIDE 2 / pad 1 convolutions of the frozen backbone on the matrix cores (round 5) ----
+ * (attack.py:222 through the classifier: conv2 of the first bottleneck of stages 2-4; MIOpen runs them as NHWC implicit
+ * GEMMs between batched_transpose_* kernels, the 56 -> 28 one as a stride-2 Winograd.)  Same exact-f32 MFMA walk, same
+ * packed weights (pack_conv3x3_weights) and the same summation order as dp_conv3x3_fwd:
+ *   y[n][o][h][w] = sum_{c,kh,kw} w[o][c][kh][kw] * x'[n][c][2h+kh-1][2w+kw-1],   x (N,C,H,W) -> y (N,O,H/2,W/2).
+ * H = W in {56, 28, 14} (the INPUT side), C % 8 == 0, O % 64 == 0.  ab == NULL: x' = x; else x' = relu(group_norm(x)) with
+ * the (N,C,2) coefficients dp_gn_stats wrote, applied while staging (bit-identical to dp_gn_relu_fwd first).  Forward
+ * only: the input gradient of a strided convolution stays with the library (dorpatch_amd/libconv.py). */
+int dp_conv3x3s2_fwd(const float *x, const float *wt, const float *ab, int N, int C, int O, int H, int W, float *y,
+                     dp_stream_t stream);
 
 /* ---- a-8: 1x1 / stride 1 convolutions of the frozen backbone on the matrix cores (round 5) ----
  * (attack.py:222, 247 through the classifier: 33 of ResNetV2-50's 53 convolutions; until round 4 batched library GEMMs /

@@ -5,7 +5,8 @@ MIOpen's route for the same convolution, on the GPU box, same process, same tens
 
 Prints one JSON line per (batch, shape) — the four stride-1 3x3 convolutions of ResNetV2-50 at 224 x 224: ms and effective
 TFLOP/s of both routes, forward and input gradient (= the same kernel on transposed + flipped weights), and the max abs
-difference relative to the output scale.  The route table dorpatch_amd/conv3x3_gfx950.json is derived from this output."""
+difference relative to the output scale.  The route table dorpatch_amd/conv3x3_gfx950.json is derived from this output.
+``--stride2``: the three stride-2 3x3 convolutions on dp_conv3x3s2_fwd instead (round 5; forward only)."""
 import json
 import os
 import sys
@@ -56,10 +57,47 @@ def one(N, C, S):
                 max_rel_diff_fwd=err, max_rel_diff_bwd_data=err_b)
 
 
+SHAPES_S2 = ((128, 56), (256, 28), (512, 14))      # (channels, INPUT side) of the three stride-2 3x3 convolutions @224
+
+
+def one_s2(N, C, S):
+    """dp_conv3x3s2_fwd (round 5) against F.conv2d(stride 2): plain, and with the GroupNorm + ReLU in front of it folded
+    in (against dp_gn_relu_fwd + F.conv2d = what the round-4 graph runs)."""
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(N, C, S, S, generator=g).cuda()
+    w = (torch.randn(C, C, 3, 3, generator=g) / (3.0 * C ** 0.5)).cuda()
+    wt = ops.pack_conv3x3_weights(w)
+    gamma, beta = torch.rand(C, generator=g).cuda() + 0.5, torch.randn(C, generator=g).cuda() * 0.2
+    flop = 2.0 * N * (S // 2) ** 2 * C * C * 9
+    want = F.conv2d(x, w, stride=2, padding=1)
+    err = float((ops.conv3x3s2_fwd(x, wt) - want).abs().max() / want.abs().max())
+
+    def lib_gn():
+        return F.conv2d(ops.gn_relu_fwd(x, gamma, beta, 32, 1e-5)[0], w, stride=2, padding=1)
+
+    def own_gn():
+        return ops.conv3x3s2_fwd(x, wt, ab=ops.gn_stats(x, gamma, beta, 32, 1e-5)[2])
+
+    err_gn = float((own_gn() - lib_gn()).abs().max() / want.abs().max())
+    ms = dict(miopen_fwd=timed(lambda: F.conv2d(x, w, stride=2, padding=1)), mfma_fwd=timed(lambda: ops.conv3x3s2_fwd(x, wt)),
+              gn_then_miopen_fwd=timed(lib_gn), stats_then_mfma_fold_fwd=timed(own_gn))
+    return dict(shape="N=%d %d->%d 3x3/2 @%dx%d fp32" % (N, C, C, S, S), gflop=round(flop / 1e9, 2),
+                ms={k: round(v, 4) for k, v in ms.items()},
+                tflops_effective={k: round(flop / (v * 1e-3) / 1e12, 1) for k, v in ms.items()},
+                speedup=dict(fwd=round(ms["miopen_fwd"] / ms["mfma_fwd"], 3),
+                             gn_fwd=round(ms["gn_then_miopen_fwd"] / ms["stats_then_mfma_fold_fwd"], 3)),
+                max_rel_diff_fwd=err, max_rel_diff_gn_fwd=err_gn)
+
+
 def main():
     torch.backends.cudnn.benchmark = False          # the product's setting: MIOpen immediate mode
-    batches = [int(a) for a in sys.argv[1:]] or [512]
+    args = [a for a in sys.argv[1:] if a != "--stride2"]
+    batches = [int(a) for a in args] or [512]
     for N in batches:
+        if "--stride2" in sys.argv:
+            for C, S in SHAPES_S2:
+                print(json.dumps(one_s2(N, C, S)), flush=True)
+            continue
         for C, S in SHAPES:
             print(json.dumps(one(N, C, S)), flush=True)
 

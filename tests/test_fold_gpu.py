@@ -26,8 +26,10 @@ def test_folded_graph_equals_round4_graph_on_resnetv2_50(N, side, monkeypatch):
     monkeypatch.setattr(conv1x1, "MODE", "mfma")
     monkeypatch.setattr(libconv, "CONV3X3", "on")       # the round-4 graph on the same 3x3 kernel whatever the batch size
     monkeypatch.setattr(resnetv2.GroupNormAct, "fold_min_batch", 1)
-    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)    # the stride-2 3x3 convolutions stay on MIOpen: at
-    # small batches its default kernels accumulate with float atomics (dorpatch_amd/libconv.py), which would differ run to run
+    monkeypatch.setattr(libconv, "CONV3X3S2_MIN_BATCH", 1)   # ... and on the same stride-2 forward kernel (dp_conv3x3s2_fwd)
+    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)    # the stride-2 3x3 INPUT GRADIENTS stay on MIOpen (and
+    # at 384 x 384 the forwards too): at small batches its default kernels accumulate with float atomics
+    # (dorpatch_amd/libconv.py), which would differ run to run
     net = resnetv2.seeded_init_(resnetv2.resnetv2_50x1_bit(), gn_bias=resnetv2.WELL_CONDITIONED_GN_BIAS)
     net = net.fold_weight_standardization().freeze().to(DEV)
     gen = torch.Generator().manual_seed(N)
@@ -49,7 +51,7 @@ def test_folded_graph_equals_round4_graph_on_resnetv2_50(N, side, monkeypatch):
     finally:
         resnetv2.GroupNormAct.fold = True
         ops.GnConvFunction.forward = staticmethod(orig)
-    assert calls.count(1) >= 20 and (side != 224 or calls.count(3) >= 10)     # the folded nodes really ran
+    assert calls.count(1) >= 20 and (side != 224 or (calls.count(3) >= 10 and calls.count(32) == 3))   # the folded nodes really ran
     assert torch.equal(got, want)
     scale = float(g_want.abs().max())
     assert scale > 0 and float((g_got - g_want).abs().max()) <= 2e-6 * scale

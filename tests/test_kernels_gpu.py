@@ -427,6 +427,50 @@ def test_conv3x3_with_folded_groupnorm_is_bit_identical_to_the_two_kernels(N, C,
     assert torch.equal(got, want)
 
 
+CONV3X3S2_CASES = [   # (N, C, O, INPUT side, emulation-sized)
+    (2, 16, 64, 28, True),      # 392 output pixels: one ragged tile spanning both images, float4 staging, 8 K-chunks
+    (10, 8, 128, 14, True),     # 490 output pixels = 1.1 tiles of 9.1 planes each (float2 staging), two output-channel groups
+    (1, 8, 64, 56, False),      # one plane = 1.75 tiles (a tile that starts mid-plane)
+    (3, 128, 128, 56, False), (5, 256, 256, 28, False), (20, 512, 512, 14, False),      # ResNetV2-50's three
+]
+
+
+@pytest.mark.parametrize("N,C,O,S,small", CONV3X3S2_CASES)
+def test_conv3x3_stride2_on_the_matrix_cores_matches_conv2d(N, C, O, S, small):
+    """dp_conv3x3s2_fwd (round 5: conv2 of the first bottleneck of stages 2-4, 3x3 / stride 2 / pad 1, de-interleaved LDS
+    image) against F.conv2d at 1e-5 of the output scale; one-hot weights exact (padding above / left of every image, the
+    seams between the images a tile spans, no padding below / right); bit-identical to the even pixels of the stride-1
+    kernel's result (same summation order); with the GroupNorm fold bit-identical to normalising first."""
+    import os
+    if DEV == "cpu" and not small and not (os.environ.get("DORPATCH_EMU_FULL", "0") == "1" and C <= 16):
+        pytest.skip("through the fibre emulation this case takes minutes: GPU (or DORPATCH_EMU_FULL=1 for the narrow ones)")
+    g = torch.Generator().manual_seed(C + S)
+    x = torch.randn(N, C, S, S, generator=g)
+    x[0] += torch.arange(float(S)).view(1, S, 1) * 0.1 + torch.arange(float(S)).view(1, 1, S) * 0.01
+    w = torch.randn(O, C, 3, 3, generator=g) / (3.0 * C ** 0.5)
+    want = F.conv2d(x, w, stride=2, padding=1)
+    xd, wt = x.to(DEV).contiguous(), ops.pack_conv3x3_weights(w).to(DEV)
+    got = ops.conv3x3s2_fwd(xd, wt)
+    assert tuple(got.shape) == (N, O, S // 2, S // 2)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=1e-5 * float(want.abs().max()))
+    w1 = torch.zeros(O, C, 3, 3)
+    for o in range(O):
+        w1[o, (5 * o + 3) % C, o % 3, (o // 3) % 3] = 1.0
+    got1 = ops.conv3x3s2_fwd(xd, ops.pack_conv3x3_weights(w1).to(DEV)).cpu()
+    assert torch.equal(got1, F.conv2d(x, w1, stride=2, padding=1))
+    if DEV != "cpu" or small:        # the stride-1 kernel on the same input: its even pixels, bit for bit
+        full = ops.conv3x3_fwd(xd, wt)
+        assert torch.equal(got, full[:, :, ::2, ::2])
+    if C % 32 == 0 or C == 16:       # GroupNorm fold (groups of 32, or of 16 channels in the emulation-sized case)
+        G = 32 if C % 32 == 0 else 16
+        xr = (x * 1.5 + 0.3).to(DEV).contiguous()
+        gamma = (torch.rand(C, generator=g) + 0.5).to(DEV)
+        beta = (torch.randn(C, generator=g) * 0.2 + 1.0).to(DEV)
+        y, mean, rstd, _ = ops.gn_relu_fwd(xr, gamma, beta, G, 1e-5)
+        _, _, ab, _ = ops.gn_stats(xr, gamma, beta, G, 1e-5)
+        assert torch.equal(ops.conv3x3s2_fwd(xr, wt, ab=ab), ops.conv3x3s2_fwd(y, wt))
+
+
 CONV1X1_CASES = [   # (N, C, O, H, emulation-sized)
     (3, 32, 64, 14, True),      # 1.3 tiles of 2.3 planes each, ragged last tile, 2 K-chunks (the double buffer)
     (11, 16, 128, 7, True),     # flat mode: 9 whole images per tile + a ragged second tile, two output-channel groups, ONE chunk

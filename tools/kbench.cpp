@@ -421,6 +421,41 @@ int main(int argc, char **argv) {
     }
     return 0;
   }
+  if (g_filter && strstr(g_filter, "conv3s2")) {
+    // round 5: the three stride-2 3x3 convolutions (conv2 of the first bottleneck of stages 2-4), plain and with the
+    // GroupNorm fold (coefficients = a constant table: the kernel's work does not depend on their values)
+    const int Nc = B;
+    const int shapes[3][2] = {{128, 56}, {256, 28}, {512, 14}};
+    for (auto &sh : shapes) {
+      const int Cc = sh[0], Sc = sh[1], So = Sc / 2;
+      const size_t ex = (size_t)Nc * Cc * Sc * Sc, ey = (size_t)Nc * Cc * So * So;
+      float *cx = (float *)dmalloc(ex * 4), *cy = (float *)dmalloc(ey * 4), *cw = (float *)dmalloc((size_t)Cc * Cc * 9 * 4);
+      float *cab = (float *)dmalloc((size_t)Nc * Cc * 2 * 4);
+      hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, st, (f4 *)cx, ex / 4, 0.37f);
+      hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, st, (f4 *)cw, (size_t)Cc * Cc * 9 / 4, 0.01f);
+      hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, st, (f4 *)cab, (size_t)Nc * Cc * 2 / 4, 0.5f);
+      const double flop = 2.0 * Nc * So * So * (double)Cc * Cc * 9;
+      for (int fold = 0; fold < 2; ++fold) {
+        for (int rep = 0; rep < 2; ++rep) {
+          hipEvent_t e0, e1;
+          CK(hipEventCreate(&e0));
+          CK(hipEventCreate(&e1));
+          DP(dp_conv3x3s2_fwd(cx, cw, fold ? cab : nullptr, Nc, Cc, Cc, Sc, Sc, cy, st));
+          CK(hipEventRecord(e0, st));
+          for (int i = 0; i < iters; ++i) DP(dp_conv3x3s2_fwd(cx, cw, fold ? cab : nullptr, Nc, Cc, Cc, Sc, Sc, cy, st));
+          CK(hipEventRecord(e1, st));
+          CK(hipEventSynchronize(e1));
+          float ms;
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          ms /= iters;
+          printf("dp_conv3x3s2_fwd %3d->%3d @%2dx%2d -> %2dx%2d N=%d %s  %8.4f ms  %7.1f TFLOP/s  (%.1f%% of the 157.3 TFLOP/s f32 peak)\n",
+                 Cc, Cc, Sc, Sc, So, So, Nc, fold ? "fold " : "plain", ms, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 1.573);
+        }
+      }
+      CK(hipFree(cx)); CK(hipFree(cy)); CK(hipFree(cw)); CK(hipFree(cab));
+    }
+    return 0;
+  }
   if (g_filter && strstr(g_filter, "mfma_probe")) {
     float *po = (float *)dmalloc((size_t)2048 * 256 * 4);
     float *psrc = (float *)dmalloc((size_t)64 << 20);
