@@ -28,6 +28,6 @@ PY
 }
 run s2_on X=1
 run s2_off DORPATCH_CONV3X3S2=off
-run s2_on_b X=1
+run s2_on_s1 X=1 --streams 1
 ( timeout 900 python -m pytest tests/test_headline_parity_gpu.py -m gpu -q -rs -p no:cacheprovider 2>&1 | tail -8 ) > $O/pytest_headline.log 2>&1; echo "pytest headline rc=${PIPESTATUS[0]}" | tee -a $O/rc.txt
 tail -5 $O/pytest_headline.log
