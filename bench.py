@@ -175,6 +175,9 @@ def parse(argv=None):
     ap.add_argument("--streams", type=int, default=None,
                     help="DorPatch(streams=N): the step's independent micro-batches enqueued round-robin on N HIP streams "
                          "(default: the product's, DORPATCH_STREAMS or 1)")
+    ap.add_argument("--conv3x3-kernel", default="default", choices=["default", "rows", "flat"],
+                    help="A/B: dp_debug_set(DP_DEBUG_CONV3X3_VARIANT): which of the two stride-1 3x3 MFMA kernels runs "
+                         "(rows: k_conv3x3_mfma wherever it applies; flat: k_conv3x3_flat everywhere; default: per side)")
     ap.add_argument("--gn-fold", default=None, choices=["on", "off"],
                     help="round 5: GroupNorm-apply + ReLU folded into the consuming convolution's operand staging and the "
                          "residual add into the producing convolution's epilogue (default: on, or DORPATCH_GNFOLD=0); off = "
@@ -627,6 +630,9 @@ def main(argv=None):
         S = S_local * world
     torch.manual_seed(1234)
     np.random.seed(1234)
+    if args.conv3x3_kernel != "default":
+        from dorpatch_amd import _lib as _dp_lib, ops as _dp_ops
+        _dp_ops.debug_set(_dp_lib.DP_DEBUG_CONV3X3_VARIANT, {"rows": 1, "flat": 2}[args.conv3x3_kernel])
     model = build_model(dev)
     x = torch.rand(B, 3, H, H, generator=torch.Generator().manual_seed(1234)).to(dev)
     with torch.no_grad():

@@ -37,6 +37,7 @@ int g_update_variant = 0;          // DP_DEBUG_UPDATE_VARIANT
 int g_apply_order = 0;             // DP_DEBUG_APPLY_ORDER
 int g_aff_gather = 0;              // DP_DEBUG_AFFINE_GATHER
 int g_conv1x1_variant = 0;         // DP_DEBUG_CONV1X1_VARIANT: bits 0-1 workgroup map, bit 2 non-temporal stores, bit 3 LDS staging in one lump
+int g_conv3x3_variant = 0;         // DP_DEBUG_CONV3X3_VARIANT: 0 per-side default, 1 k_conv3x3_mfma wherever it applies, 2 k_conv3x3_flat everywhere
 
 // Register-allocation hint: the compiler must forget what it knows about a lane-private value (so that it re-derives
 // addresses / predicates from it instead of keeping dozens of them alive).  No semantics; empty in the host emulation.
@@ -3772,6 +3773,665 @@ int launch_conv1x1(C1Args A, bool flat, hipStream_t st) {
   return launch_status();
 }
 
+// ----------------------------------------------------------------------------
+// a-8 (round 5): the 3 x 3 MFMA walk over a FLAT LDS image with MASKED taps.
+// k_conv3x3_mfma lays the input rows out in LDS with explicit zero rows / columns, which ties it to planes that tile 448
+// pixels (56 / 28 / 14 / 7) and costs the small planes their staging (float2 / scalar items, 9 - 17 per lane and chunk,
+// a dozen integer operations of decode each: 113 / 102 TFLOP/s at 14^2 / 7^2 against 134 at 56^2).  Here the LDS image of a
+// K-chunk is what lies in memory: per channel the tile's 448 batch-linear pixels plus HL pixels before and HR after
+// (row mode, any plane with H*W % 4 == 0: float4 items, one division per item, done once), or whole images
+// [image][channel][49] (the 7 x 7 planes, as k_conv1x1_mfma's flat mode).  A tap (dh, dw) of a pixel is then the word
+// dh S + dw further on — a compile-time immediate — and is WRONG exactly where the convolution pads: in row 0 / S - 1 for
+// dh = -1 / +1, in column 0 / S - 1 for dw = -1 / +1 (the flat neighbour is the previous / next row's pixel, or another
+// image's).  Those lanes take 0 instead (one v_cndmask per operand on per-fragment lane masks): the result is the zero-
+// padded convolution, bit for bit what k_conv3x3_mfma computes (same k-walk: channels ascending, taps row-major).
+// The same walk with other tap sets is the INPUT GRADIENT of the three stride-2 3 x 3 convolutions (until now MIOpen's
+// NHWC implicit GEMM between batched_transpose_* kernels): dx[2a + pr][2b + pc] depends on dy[a + dh][b + dw] with
+//   pr = 0: (dh, kh) = (0, 1);   pr = 1: (0, 2), (+1, 0);   the same for columns —
+// four parity classes with 1 / 2 / 2 / 4 taps over the dy plane (9 per 4 input pixels: the forward's flops), each a masked
+// flat walk with K = (dy channel, tap) whose result is scattered to its parity positions.  K-chunks hold 16 / T channels,
+// so every class runs 8 k-steps = 56 MFMAs per wave and barrier (k_conv1x1_mfma's rhythm) on 1024 packed weights.
+// Pipeline as k_conv3x3s2_mfma: a whole chunk in flight in registers, one staging item per MFMA group, branch-free, the
+// barrier on LDS traffic only and before the last group's MFMAs.  The masks are applied to step t's operands after step
+// t - 1's MFMAs have been issued (the loads have had a whole group to land), before step t + 1's operands are requested.
+struct TapsS1 {                  // stride 1: t = 3 kh + kw, (dh, dw) = (kh - 1, kw - 1), offsets counted from (h - 1, w - 1)
+  static constexpr int T = 9;
+  static constexpr int dh(int t) { return t / 3 - 1; }
+  static constexpr int dw(int t) { return t % 3 - 1; }
+};
+template <int PR, int PC>
+struct TapsS2 {                  // class (PR, PC) of the stride-2 input gradient: t = th (1 + PC) + tw, (dh, dw) = (th, tw)
+  static constexpr int T = (1 + PR) * (1 + PC);
+  static constexpr int dh(int t) { return t / (1 + PC); }
+  static constexpr int dw(int t) { return t % (1 + PC); }
+};
+
+template <int S_, int T_, int CH_, int BACK_, int FWD_>
+struct CfGeom {
+  static constexpr int S = S_, HW = S_ * S_, T = T_, CH = CH_;
+  static constexpr bool FLAT = (HW % 4) != 0;                              // 7 x 7: whole-image tiles
+  static constexpr int KS = CH / 2 * T;                                    // MFMA k-steps per chunk
+  static constexpr int BACK = BACK_;                                       // words a tap reaches back / forward from its pixel
+  static constexpr int HL = FLAT ? 0 : (BACK_ + 3) / 4 * 4, HR = FLAT ? 0 : (FWD_ + 3) / 4 * 4;
+  static constexpr int RL = HL + kCvPix + HR;                              // row mode: floats per channel
+  static constexpr int SPT = FLAT ? kCvPix / HW : 1;                       // flat mode: images per tile
+  static constexpr int CHS = FLAT ? HW : RL;                               // LDS stride between channels
+  static constexpr int NV = FLAT ? SPT * CH * HW / 4 : CH * RL / 4;        // float4 items per chunk
+  static constexpr int IT = (NV + kBlock - 1) / kBlock;
+  static constexpr int PAD = FLAT ? (BACK_ + 3) / 4 * 4 : 0;               // in front of buffer 0 (flat mode: image 0 reaches back)
+  static constexpr int DUMMY = NV * 4;                                     // where the idle lanes of the last item store
+  static constexpr int WOFF = NV * 4 + 4;                                  // packed weights of the chunk
+  static constexpr int WT = KS * 2 * kCvO, WF4 = WT / 4, WIT = (WF4 + kBlock - 1) / kBlock;
+  static constexpr int WDUMMY = WOFF + WT;
+  static constexpr int BUF = WOFF + WT + 4;
+  static constexpr int LDS = PAD + 2 * BUF + (FLAT ? (FWD_ + 3) / 4 * 4 : 0);
+  static_assert(!FLAT || (CH * HW) % 4 == 0, "flat mode: an image's chunk is a whole number of float4");
+  static_assert(KS >= 2 && IT + WIT <= 2 * (KS - 1), "staging items fit the MFMA groups of a chunk");
+};
+
+struct CfArgs {
+  const float *x, *wt;
+  const float *ab;      // FOLD: (N, C, 2) coefficients of the fused GroupNorm + ReLU on the input
+  float *y;
+  int N, C, O;          // C channels of x (the K dimension), O channels of y
+  int tiles, og;        // pixel tiles, O / 64
+};
+
+// MODE 0: y (N, O, S, S) plain;  MODE 1: y (N, O, 2S, 2S), the tile's pixel (a, b) goes to (2a + PR, 2b + PC)
+template <class G, class TAPS, bool FOLD, int MODE, int PR, int PC>
+__device__ __forceinline__ void cf_body(float *lds, const CfArgs &A, const float *wtg, int tile, int og) {
+  constexpr int S = G::S, HW = G::HW, KS = G::KS, T = G::T;
+  static_assert(!(FOLD && G::FLAT), "the GroupNorm fold needs H*W % 4 == 0");
+  const int NCH = A.C / G::CH;
+  const int total = A.N * HW;                                  // < 2^31 (checked by the launcher)
+  const int g0 = G::FLAT ? 0 : tile * kCvPix;                  // row mode: first pixel of the tile (batch-linear)
+  const int n0 = G::FLAT ? tile * G::SPT : 0;                  // flat mode: first image of the tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int ocf = wave & 1, pf0 = wave >> 1;
+  wtg += (size_t)og * NCH * G::WT;
+
+  // staging items: element offset of the item's float4 at chunk 0 (-1: zeros) and, FOLD, of its coefficients
+  int xoff[G::IT], aoff[FOLD ? G::IT : 1];
+#pragma unroll
+  for (int it = 0; it < G::IT; ++it) {
+    const int j = tid + it * kBlock;
+    if (!G::FLAT) {
+      const int ch = j / (G::RL / 4), quad = j - ch * (G::RL / 4);
+      const int g = g0 - G::HL + 4 * quad;
+      const bool ok = j < G::NV && g >= 0 && g < total;
+      const int n = ok ? g / HW : 0, p = ok ? g - n * HW : 0;
+      xoff[it] = ok ? (n * A.C + ch) * HW + p : -1;
+      if (FOLD) aoff[it] = n * A.C + (ok ? ch : 0);
+    } else {
+      const int s = j / (G::CH * HW / 4), f = j - s * (G::CH * HW / 4);
+      const bool ok = j < G::NV && n0 + s < A.N;
+      xoff[it] = ok ? (n0 + s) * A.C * HW + 4 * f : -1;
+    }
+  }
+
+  f4 pin[G::IT], pwt[G::WIT];
+  f2 pab[FOLD ? G::IT : 1];
+  auto fetch_item = [&](int chunk, int it) {     // global -> registers; every load is issued unconditionally
+    pin[it] = *reinterpret_cast<const f4 *>(A.x + (size_t)chunk * (G::CH * HW) + (xoff[it] < 0 ? 0 : xoff[it]));
+    if (FOLD) pab[it] = *reinterpret_cast<const f2 *>(A.ab + (size_t)chunk * (G::CH * 2) + 2 * (size_t)aoff[it]);
+  };
+  auto fetch_w = [&](int chunk, int k) {
+    const int i = tid + k * kBlock;
+    pwt[k] = *reinterpret_cast<const f4 *>(wtg + (size_t)chunk * G::WT + 4 * (i < G::WF4 ? i : 0));
+  };
+  auto stash_item = [&](float *buf, int it) {    // registers -> LDS (flat copy), with the fused GroupNorm-apply + ReLU
+    f4 v = pin[it];
+    if (FOLD) {                                  // dp_gn_relu_fwd's own expression: x * a + b (not fused), max 0
+      const float a = pab[it].x, b = pab[it].y;
+      v.x = fmaxf(v.x * a + b, 0.f);
+      v.y = fmaxf(v.y * a + b, 0.f);
+      v.z = fmaxf(v.z * a + b, 0.f);
+      v.w = fmaxf(v.w * a + b, 0.f);
+    }
+    if (xoff[it] < 0) v = f4{0.f, 0.f, 0.f, 0.f};
+    const int j = tid + it * kBlock;
+    *reinterpret_cast<f4 *>(buf + ((it + 1) * kBlock <= G::NV || j < G::NV ? 4 * j : G::DUMMY)) = v;
+  };
+  auto stash_w = [&](float *buf, int k) {
+    const int i = tid + k * kBlock;
+    *reinterpret_cast<f4 *>(buf + ((k + 1) * kBlock <= G::WF4 || i < G::WF4 ? G::WOFF + 4 * i : G::WDUMMY)) = pwt[k];
+  };
+  // slot i of a chunk's IT + WIT staging items goes after MFMA group i (KS - 1) / (IT + WIT)
+  constexpr int NI = G::IT + G::WIT;
+  auto piece = [&](float *buf, int c2, int t) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (i * (KS - 1) / NI != t) continue;
+      if (i < G::IT) {
+        stash_item(buf, i);
+        fetch_item(c2, i);
+      } else {
+        stash_w(buf, i - G::IT);
+        fetch_w(c2, i - G::IT);
+      }
+    }
+  };
+
+  // lane bases: A = weights [k-step][half][oc]; B = word `BACK` before the lane's pixel of each of its 7 fragments, channel
+  // parity = half.  Lanes without a pixel (past the end of the batch / of the tile's images) read valid LDS and never store.
+  // Masks: the lane's pixel is not in the first / last row / column of its plane.
+  const int abase = G::WOFF + half * kCvO + ocf * 32 + l32;
+  int boff[7];
+  bool mT[7], mB[7], mL[7], mR[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const int gl = (pf0 + 2 * q) * 32 + l32;
+    int p;
+    if (!G::FLAT) {
+      boff[q] = half * G::CHS + G::HL + gl - G::BACK;
+      int g = g0 + gl;
+      if (g >= total) g = g0;
+      p = g % HW;
+    } else {
+      int s = gl / HW;
+      p = gl - s * HW;
+      if (s >= G::SPT) s = 0, p = 0;
+      boff[q] = s * (G::CH * HW) + half * HW + p - G::BACK;
+    }
+    const int a = p / S, b = p - a * S;
+    mT[q] = a > 0, mB[q] = a < S - 1, mL[q] = b > 0, mR[q] = b < S - 1;
+  }
+  f16v acc[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
+
+  auto operands = [&](const float *cur, int t, float &a, float (&bv)[7]) {
+    const int cp = t / T, tap = t - cp * T;
+    const int koff = cp * 2 * G::CHS + G::BACK + TAPS::dh(tap) * S + TAPS::dw(tap);
+    a = cur[abase + t * 2 * kCvO];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) bv[q] = cur[boff[q] + koff];
+  };
+  auto masked = [&](int t, float (&bv)[7]) {
+    const int tap = t % T;
+    const int dh = TAPS::dh(tap), dw = TAPS::dw(tap);
+    if (dh == 0 && dw == 0) return;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      bool m = true;
+      if (dh < 0) m = m && mT[q];
+      if (dh > 0) m = m && mB[q];
+      if (dw < 0) m = m && mL[q];
+      if (dw > 0) m = m && mR[q];
+      bv[q] = m ? bv[q] : 0.f;
+    }
+  };
+
+  float *buf0 = lds + G::PAD, *buf1 = buf0 + G::BUF;
+#pragma unroll
+  for (int it = 0; it < G::IT; ++it) fetch_item(0, it);
+#pragma unroll
+  for (int k = 0; k < G::WIT; ++k) fetch_w(0, k);
+#pragma unroll
+  for (int it = 0; it < G::IT; ++it) stash_item(buf0, it);
+#pragma unroll
+  for (int k = 0; k < G::WIT; ++k) stash_w(buf0, k);
+  const int c1 = NCH > 1 ? 1 : 0;
+#pragma unroll
+  for (int it = 0; it < G::IT; ++it) fetch_item(c1, it);
+#pragma unroll
+  for (int k = 0; k < G::WIT; ++k) fetch_w(c1, k);
+  DP_BARRIER_LDS();
+  float an, bn[7];                     // step 0 of the next chunk, requested behind the chunk's barrier
+  operands(buf0, 0, an, bn);
+  const int last = NCH - 1;
+  for (int chunk = 0; chunk < NCH; ++chunk) {
+    const float *cur = (chunk & 1) ? buf1 : buf0;
+    float *nxt = (chunk & 1) ? buf0 : buf1;
+    const int c2 = chunk + 2 < NCH ? chunk + 2 : last;    // past the end of K the staging repeats the last chunk (branch-free)
+    float a[2], b[2][7];
+    a[0] = an;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) b[0][q] = bn[q];
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+      masked(t, b[t & 1]);
+      if (t + 1 < KS) {
+        operands(cur, t + 1, a[(t + 1) & 1], b[(t + 1) & 1]);
+      } else {
+        // every read of this buffer has been issued and every wave's stores of the next chunk are done
+        DP_BARRIER_LDS();
+        operands(nxt, 0, an, bn);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t & 1], b[t & 1][q], acc[q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < KS) piece(nxt, c2, t);
+    }
+  }
+
+  const int oc0 = og * kCvO + ocf * 32 + 4 * half;
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const int gl = (pf0 + 2 * q) * 32 + l32;
+    int n, p;
+    bool ok;
+    if (!G::FLAT) {
+      const int g = g0 + gl;
+      ok = g < total;
+      n = g / HW, p = g - n * HW;
+    } else {
+      const int s = gl / HW;
+      p = gl - s * HW, n = n0 + s;
+      ok = s < G::SPT && n < A.N;
+    }
+    if (!ok) continue;
+    if (MODE == 0) {
+      float *yq = A.y + ((size_t)n * A.O + oc0) * HW + p;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) yq[(size_t)((v & 3) + 8 * (v >> 2)) * HW] = acc[q][v];
+    } else {
+      const int a = p / S, b = p - a * S;
+      float *yq = A.y + ((size_t)n * A.O + oc0) * (4 * HW) + (2 * a + PR) * (2 * S) + 2 * b + PC;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) yq[(size_t)((v & 3) + 8 * (v >> 2)) * (4 * HW)] = acc[q][v];
+    }
+  }
+}
+
+// workgroup id -> (pixel tile, channel group): block b runs on XCD b % 8; the O / 64 channel groups of one pixel tile are
+// consecutive workgroups of ONE XCD (k_conv1x1_mfma's map), so a tile of x is fetched from HBM once
+__device__ __forceinline__ void cf_decode(int slot, int xcd, int ogs, int &tile, int &og) {
+  const int tl = slot / ogs;
+  og = slot - tl * ogs;
+  tile = tl * 8 + xcd;
+}
+
+template <int S, bool FOLD>
+__global__ __launch_bounds__(kBlock, 2) void k_conv3x3_flat(CfArgs A) {
+  typedef CfGeom<S, 9, kCvCh, S + 1, S + 1> G;
+  __shared__ __attribute__((aligned(16))) float lds[G::LDS];
+  int tile, og;
+  cf_decode(blockIdx.x >> 3, blockIdx.x & 7, A.og, tile, og);
+  if (tile >= A.tiles) return;                               // grid padded to a multiple of 8 tiles
+  cf_body<G, TapsS1, FOLD, 0, 0, 0>(lds, A, A.wt, tile, og);
+}
+
+// The four parity classes in ONE launch, heaviest first within every group of four consecutive slots of an XCD: the
+// classes of a (tile, channel group) run at the same time on the same XCD, so the 4-byte stores of classes (pr, 0) and
+// (pr, 1) — the even and odd words of the same rows — meet in that XCD's L2 before they go to memory.
+// A.wt = the four packed classes back to back in the order 11, 01, 10, 00 (pack_conv3x3s2_dgrad_weights).
+template <int S>
+struct CfS2 {
+  typedef CfGeom<S, 4, 4, 0, S + 1> G11;
+  typedef CfGeom<S, 2, 8, 0, 1> G01;
+  typedef CfGeom<S, 2, 8, 0, S> G10;
+  typedef CfGeom<S, 1, 16, 0, 0> G00;
+  static constexpr int m2(int a, int b) { return a > b ? a : b; }
+  static constexpr int LDS = m2(m2(G11::LDS, G01::LDS), m2(G10::LDS, G00::LDS));
+};
+
+template <int S>
+__global__ __launch_bounds__(kBlock, 2) void k_conv3x3s2_dgrad(CfArgs A) {
+  typedef CfS2<S> K;
+  __shared__ __attribute__((aligned(16))) float lds[K::LDS];
+  const int slot = blockIdx.x >> 3, cls = slot & 3;
+  int tile, og;
+  cf_decode(slot >> 2, blockIdx.x & 7, A.og, tile, og);
+  if (tile >= A.tiles) return;
+  const size_t per_tap = (size_t)A.C * A.O;                  // floats of one tap's (dy channel, dx channel) matrix
+  if (cls == 0) cf_body<typename K::G11, TapsS2<1, 1>, false, 1, 1, 1>(lds, A, A.wt, tile, og);
+  else if (cls == 1) cf_body<typename K::G01, TapsS2<0, 1>, false, 1, 0, 1>(lds, A, A.wt + 4 * per_tap, tile, og);
+  else if (cls == 2) cf_body<typename K::G10, TapsS2<1, 0>, false, 1, 1, 0>(lds, A, A.wt + 6 * per_tap, tile, og);
+  else cf_body<typename K::G00, TapsS2<0, 0>, false, 1, 0, 0>(lds, A, A.wt + 8 * per_tap, tile, og);
+}
+
+// The same input gradient with the two COLUMN classes of a row parity in one workgroup (round 5, second form).  The four-class
+// launch above stores 4-byte words 8 bytes apart (74 TFLOP/s at N = 512, no better than MIOpen: profiles/r05j_*): class
+// (pr, 0) and (pr, 1) interleave in memory.  Here a workgroup owns 256 dy pixels x 64 dx channels x BOTH pc: a wave holds
+// 4 pixel fragments x 2 classes (8 accumulators), per (channel pair, th) it reads the operands dy[a + th][b] and
+// dy[a + th][b + 1] once and issues 12 MFMAs — class 0: w[kh][1] x dy[b]; class 1: w[kh][2] x dy[b], then w[kh][0] x dy[b + 1]
+// (each class's own k-walk order: bit-identical to the four-class kernel) — and the epilogue stores (class 0, class 1) of
+// a pixel as ONE 8-byte word: 32 lanes = 256 contiguous bytes.  K-chunks of 8 dy channels = 4 (pr = 0) / 8 (pr = 1) steps of
+// 12 MFMAs; weights packed [og][chunk][cp][th][j][half][c'], j = (kw 1, kw 2, kw 0).
+constexpr int kC2Pix = 256;                            // dy pixels per workgroup (8 fragments)
+
+template <int S_, int PR_>
+struct Cf2Geom {
+  static constexpr int S = S_, HW = S_ * S_, PR = PR_, CH = 8;
+  static constexpr bool FLAT = (HW % 4) != 0;
+  static constexpr int NS = CH / 2 * (1 + PR);                             // steps (channel pair, th) per chunk
+  static constexpr int HR = FLAT ? 0 : (PR * S + 1 + 3) / 4 * 4;
+  static constexpr int RL = kC2Pix + HR;
+  static constexpr int SPT = FLAT ? kC2Pix / HW : 1;
+  static constexpr int CHS = FLAT ? HW : RL;
+  static constexpr int NV = FLAT ? SPT * CH * HW / 4 : CH * RL / 4;
+  static constexpr int IT = (NV + kBlock - 1) / kBlock;
+  static constexpr int DUMMY = NV * 4, WOFF = NV * 4 + 4;
+  static constexpr int WT = NS * 3 * 2 * kCvO, WF4 = WT / 4, WIT = (WF4 + kBlock - 1) / kBlock;
+  static constexpr int WDUMMY = WOFF + WT;
+  static constexpr int BUF = WOFF + WT + 4;
+  static constexpr int LDS = 2 * BUF + (FLAT ? (PR * S + 1 + 3) / 4 * 4 : 0);
+  static_assert(IT + WIT <= 2 * (NS - 1), "staging items fit the MFMA groups of a chunk");
+};
+
+template <class G>
+__device__ __forceinline__ void cf2_body(float *lds, const CfArgs &A, const float *wtg, int tile, int og) {
+  constexpr int S = G::S, HW = G::HW, NS = G::NS, PR = G::PR;
+  const int NCH = A.C / G::CH;
+  const int total = A.N * HW;
+  const int g0 = G::FLAT ? 0 : tile * kC2Pix;
+  const int n0 = G::FLAT ? tile * G::SPT : 0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int ocf = wave & 1, pf0 = wave >> 1;
+  wtg += (size_t)og * NCH * G::WT;
+
+  int xoff[G::IT];
+#pragma unroll
+  for (int it = 0; it < G::IT; ++it) {
+    const int j = tid + it * kBlock;
+    if (!G::FLAT) {
+      const int ch = j / (G::RL / 4), quad = j - ch * (G::RL / 4);
+      const int g = g0 + 4 * quad;
+      const bool ok = j < G::NV && g < total;
+      const int n = ok ? g / HW : 0, p = ok ? g - n * HW : 0;
+      xoff[it] = ok ? (n * A.C + ch) * HW + p : -1;
+    } else {
+      const int s = j / (G::CH * HW / 4), f = j - s * (G::CH * HW / 4);
+      const bool ok = j < G::NV && n0 + s < A.N;
+      xoff[it] = ok ? (n0 + s) * A.C * HW + 4 * f : -1;
+    }
+  }
+  f4 pin[G::IT], pwt[G::WIT];
+  auto fetch_item = [&](int chunk, int it) {
+    pin[it] = *reinterpret_cast<const f4 *>(A.x + (size_t)chunk * (G::CH * HW) + (xoff[it] < 0 ? 0 : xoff[it]));
+  };
+  auto fetch_w = [&](int chunk, int k) {
+    const int i = tid + k * kBlock;
+    pwt[k] = *reinterpret_cast<const f4 *>(wtg + (size_t)chunk * G::WT + 4 * (i < G::WF4 ? i : 0));
+  };
+  auto stash_item = [&](float *buf, int it) {
+    f4 v = pin[it];
+    if (xoff[it] < 0) v = f4{0.f, 0.f, 0.f, 0.f};
+    const int j = tid + it * kBlock;
+    *reinterpret_cast<f4 *>(buf + ((it + 1) * kBlock <= G::NV || j < G::NV ? 4 * j : G::DUMMY)) = v;
+  };
+  auto stash_w = [&](float *buf, int k) {
+    const int i = tid + k * kBlock;
+    *reinterpret_cast<f4 *>(buf + ((k + 1) * kBlock <= G::WF4 || i < G::WF4 ? G::WOFF + 4 * i : G::WDUMMY)) = pwt[k];
+  };
+  constexpr int NI = G::IT + G::WIT;
+  auto piece = [&](float *buf, int c2, int t) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (i * (NS - 1) / NI != t) continue;
+      if (i < G::IT) {
+        stash_item(buf, i);
+        fetch_item(c2, i);
+      } else {
+        stash_w(buf, i - G::IT);
+        fetch_w(c2, i - G::IT);
+      }
+    }
+  };
+
+  const int abase = G::WOFF + half * kCvO + ocf * 32 + l32;
+  int boff[4];
+  bool mB[4], mR[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int gl = (pf0 + 2 * q) * 32 + l32;
+    int p;
+    if (!G::FLAT) {
+      boff[q] = half * G::CHS + gl;
+      int g = g0 + gl;
+      if (g >= total) g = g0;
+      p = g % HW;
+    } else {
+      int s = gl / HW;
+      p = gl - s * HW;
+      if (s >= G::SPT) s = 0, p = 0;
+      boff[q] = s * (G::CH * HW) + half * HW + p;
+    }
+    const int a = p / S, b = p - a * S;
+    mB[q] = a < S - 1, mR[q] = b < S - 1;
+  }
+  f16v acc[2][4];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[c][q][v] = 0.f;
+
+  struct Ops {
+    float a[3], b0[4], b1[4];
+  };
+  auto operands = [&](const float *cur, int t, Ops &o) {       // step t = (cp, th)
+    const int cp = t / (1 + PR), th = t - cp * (1 + PR);
+    const int koff = cp * 2 * G::CHS + th * S;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o.a[j] = cur[abase + (t * 3 + j) * 2 * kCvO];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      o.b0[q] = cur[boff[q] + koff];
+      o.b1[q] = cur[boff[q] + koff + 1];
+    }
+  };
+  auto masked = [&](int t, Ops &o) {
+    const int th = t % (1 + PR);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (th) o.b0[q] = mB[q] ? o.b0[q] : 0.f;
+      o.b1[q] = (mR[q] && (!th || mB[q])) ? o.b1[q] : 0.f;
+    }
+  };
+
+  float *buf0 = lds, *buf1 = buf0 + G::BUF;
+#pragma unroll
+  for (int it = 0; it < G::IT; ++it) fetch_item(0, it);
+#pragma unroll
+  for (int k = 0; k < G::WIT; ++k) fetch_w(0, k);
+#pragma unroll
+  for (int it = 0; it < G::IT; ++it) stash_item(buf0, it);
+#pragma unroll
+  for (int k = 0; k < G::WIT; ++k) stash_w(buf0, k);
+  const int c1 = NCH > 1 ? 1 : 0;
+#pragma unroll
+  for (int it = 0; it < G::IT; ++it) fetch_item(c1, it);
+#pragma unroll
+  for (int k = 0; k < G::WIT; ++k) fetch_w(c1, k);
+  DP_BARRIER_LDS();
+  Ops nx;
+  operands(buf0, 0, nx);
+  const int last = NCH - 1;
+  for (int chunk = 0; chunk < NCH; ++chunk) {
+    const float *cur = (chunk & 1) ? buf1 : buf0;
+    float *nxt = (chunk & 1) ? buf0 : buf1;
+    const int c2 = chunk + 2 < NCH ? chunk + 2 : last;
+    Ops o[2];
+    o[0] = nx;
+#pragma unroll
+    for (int t = 0; t < NS; ++t) {
+      masked(t, o[t & 1]);
+      if (t + 1 < NS) {
+        operands(cur, t + 1, o[(t + 1) & 1]);
+      } else {
+        DP_BARRIER_LDS();
+        operands(nxt, 0, nx);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const Ops &c = o[t & 1];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.a[0], c.b0[q], acc[0][q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.a[1], c.b0[q], acc[1][q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.a[2], c.b1[q], acc[1][q], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < NS) piece(nxt, c2, t);
+    }
+  }
+
+  const int oc0 = og * kCvO + ocf * 32 + 4 * half;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int gl = (pf0 + 2 * q) * 32 + l32;
+    int n, p;
+    bool ok;
+    if (!G::FLAT) {
+      const int g = g0 + gl;
+      ok = g < total;
+      n = g / HW, p = g - n * HW;
+    } else {
+      const int s = gl / HW;
+      p = gl - s * HW, n = n0 + s;
+      ok = s < G::SPT && n < A.N;
+    }
+    if (!ok) continue;
+    const int a = p / S, b = p - a * S;
+    float *yq = A.y + ((size_t)n * A.O + oc0) * (4 * HW) + (2 * a + PR) * (2 * S) + 2 * b;
+#pragma unroll
+    for (int v = 0; v < 16; ++v)
+      *reinterpret_cast<f2 *>(yq + (size_t)((v & 3) + 8 * (v >> 2)) * (4 * HW)) = f2{acc[0][q][v], acc[1][q][v]};
+  }
+}
+
+// A.wt = the row class pr = 1 (all of its chunks) followed by pr = 0 (pack_conv3x3s2_dgrad_weights(..., pairs=True))
+template <int S>
+__global__ __launch_bounds__(kBlock, 2) void k_conv3x3s2_dgrad2(CfArgs A) {
+  typedef Cf2Geom<S, 1> G1;
+  typedef Cf2Geom<S, 0> G0;
+  __shared__ __attribute__((aligned(16))) float lds[G1::LDS > G0::LDS ? G1::LDS : G0::LDS];
+  const int slot = blockIdx.x >> 3;
+  int tile, og;
+  cf_decode(slot >> 1, blockIdx.x & 7, A.og, tile, og);
+  if (tile >= A.tiles) return;
+  if ((slot & 1) == 0) cf2_body<G1>(lds, A, A.wt, tile, og);
+  else cf2_body<G0>(lds, A, A.wt + 6 * (size_t)A.C * A.O, tile, og);
+}
+
+// ----------------------------------------------------------------------------
+// a-8 (round 5): the STEM convolution (3 -> 64 channels, 7 x 7 / stride 2 / pad 3, 224 -> 112) on the matrix cores.
+// MIOpen runs it as a stride-2 Winograd (miopenSp3AsmConv_v30_3_1_gfx9_fp32_f3x2_stride2: 2.31 ms per 512 images = 52
+// TFLOP/s, 9.3 ms of a configs[1] step: profiles/r05i_kernel_stats_timed_headline_streams1.txt).  K = 3 x 7 x 7 = 147 is
+// small enough that a workgroup's whole operand set lives in LDS at once — no K loop over chunks:
+//   tile   = 4 output rows of one image (4 x 112 = 448 pixels, 14 fragments) x all 64 output channels;
+//   input  = the 13 input rows 2 h0 - 3 .. 2 h0 + 9 of the 3 channels, DE-INTERLEAVED by column parity as in
+//            k_conv3x3s2_mfma: sub-row ((row, channel), pc) holds x[row][2 (i - 2) + pc] at word i (2 zero words left, 2 right),
+//            rows above / below the image are zero rows;  with the channel INSIDE the row, flattening (kh, c) -> r = 3 kh + c
+//            makes every tap row r of a pixel the sub-row pair 2 PITCH r further on, so the two k of an MFMA k-step are the
+//            rows (2 j, 2 j + 1) of the same kw: the lane's half adds a constant — 11 row pairs (r = 21 is padding: zero
+//            weights) x 7 kw = 77 k-steps x 7 MFMAs per wave, 95 % of them useful;
+//   weights = all 77 x 2 x 64 of them (39 KB), packed by the host in that order.
+// LDS 75.6 KB -> 2 workgroups per CU: one stages (19 16-byte loads per lane) while the other multiplies.  Exact f32, fixed
+// order: deterministic.
+constexpr int kStW = 224, kStWo = kStW / 2;                       // input / output width
+constexpr int kStPitch = kStWo + 4;                               // 116 words per sub-row
+constexpr int kStRows = 13;                                       // input rows of a tile
+constexpr int kStIn = kStRows * 3 * 2 * kStPitch;                 // 9048 floats
+constexpr int kStSteps = 11 * 7;                                  // 77 k-steps
+constexpr int kStWt = kStSteps * 2 * kCvO;                        // 9856 floats
+constexpr int kStIt = (kStRows * 3 * (kStW / 4) + kBlock - 1) / kBlock;      // 9 input float4 per lane
+constexpr int kStWIt = (kStWt / 4 + kBlock - 1) / kBlock;         // 10 weight float4 per lane
+static_assert(kCvPix == 4 * kStWo, "a tile is 4 output rows");
+
+__global__ __launch_bounds__(kBlock, 2) void k_stem_conv_mfma(const float *__restrict__ x, const float *__restrict__ wt,
+                                                              float *__restrict__ y, int N, int H, int tpi) {
+  __shared__ __attribute__((aligned(16))) float lds[kStIn + kStWt];
+  const int Ho = H / 2;
+  const int n = blockIdx.x / tpi, h0 = (blockIdx.x - n * tpi) * 4;       // first output row of the tile
+  const int r0 = 2 * h0 - 3;                                             // input row of LDS row 0
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int ocf = wave & 1, pf0 = wave >> 1;
+
+  // the 4 pad words of every sub-row
+  for (int i = tid; i < kStRows * 3 * 2 * 4; i += kBlock) {
+    const int sub = i >> 2, k = i & 3;
+    lds[sub * kStPitch + (k < 2 ? k : kStWo + k)] = 0.f;
+  }
+  f4 pin[kStIt], pwt[kStWIt];
+#pragma unroll
+  for (int it = 0; it < kStIt; ++it) {
+    const int j = tid + it * kBlock;                         // (row, channel, float4 of the row)
+    const int rc = j / (kStW / 4), q = j - rc * (kStW / 4);
+    const int row = rc / 3, c = rc - row * 3;
+    const int r = r0 + row;
+    const bool ok = j < kStRows * 3 * (kStW / 4) && r >= 0 && r < H;
+    pin[it] = *reinterpret_cast<const f4 *>(x + (ok ? (((size_t)n * 3 + c) * H + r) * kStW + 4 * q : (size_t)0));
+    if (!ok) pin[it] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int k = 0; k < kStWIt; ++k) {
+    const int i = tid + k * kBlock;
+    pwt[k] = *reinterpret_cast<const f4 *>(wt + 4 * (i < kStWt / 4 ? i : 0));
+  }
+#pragma unroll
+  for (int it = 0; it < kStIt; ++it) {
+    const int j = tid + it * kBlock;
+    if (j < kStRows * 3 * (kStW / 4)) {
+      const int rc = j / (kStW / 4), q = j - rc * (kStW / 4);
+      float *dst = lds + rc * 2 * kStPitch + 2 + 2 * q;      // columns 4 q .. 4 q + 3 -> words 2 q, 2 q + 1 of both parities
+      *reinterpret_cast<f2 *>(dst) = f2{pin[it].x, pin[it].z};
+      *reinterpret_cast<f2 *>(dst + kStPitch) = f2{pin[it].y, pin[it].w};
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kStWIt; ++k) {
+    const int i = tid + k * kBlock;
+    if (i < kStWt / 4) *reinterpret_cast<f4 *>(lds + kStIn + 4 * i) = pwt[k];
+  }
+  // (the padding row pair r = 21 of the tile's last output row reads the first words of the weights: finite, times zero)
+
+  const int abase = kStIn + half * kCvO + ocf * 32 + l32;
+  int boff[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const int gl = (pf0 + 2 * q) * 32 + l32;
+    const int hl = gl / kStWo, w = gl - hl * kStWo;
+    boff[q] = (2 * hl * 3 + half) * 2 * kStPitch + w;
+  }
+  f16v acc[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
+  __syncthreads();
+
+  // k-step t = 7 j + kw: rows (2 j, 2 j + 1) of tap column kw; word offset of kw within the sub-row pair:
+  //   kw 0 -> (odd, -2), 1 -> (even, -1), 2 -> (odd, -1), 3 -> (even, 0), 4 -> (odd, 0), 5 -> (even, +1), 6 -> (odd, +1)
+  auto operands = [&](int t, float &a, float (&bv)[7]) {
+    const int j = t / 7, kw = t - 7 * j;
+    const int koff = 2 * j * 2 * kStPitch + ((kw & 1) ? 0 : kStPitch) + (kw + 1) / 2;      // + 2 (left pad) - 2 (kw 0 / -3 columns)
+    a = lds[abase + t * 2 * kCvO];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) bv[q] = lds[boff[q] + koff];
+  };
+  float a[2], b[2][7];
+  operands(0, a[0], b[0]);
+#pragma unroll
+  for (int t = 0; t < kStSteps; ++t) {
+    if (t + 1 < kStSteps) operands(t + 1, a[(t + 1) & 1], b[(t + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t & 1], b[t & 1][q], acc[q], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  const int oc0 = ocf * 32 + 4 * half;
+  const size_t plane = (size_t)Ho * kStWo;
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const int gl = (pf0 + 2 * q) * 32 + l32;
+    const int hl = gl / kStWo;
+    if (h0 + hl >= Ho) continue;
+    float *yq = y + ((size_t)n * kCvO + oc0) * plane + (size_t)h0 * kStWo + gl;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) yq[(size_t)((v & 3) + 8 * (v >> 2)) * plane] = acc[q][v];
+  }
+}
+
 // variant 0: fp32 VALU gather, 2 quads per thread (shipped); 2: the same with 4 quads per thread (measured slower, see
 // k_stem_dgrad); 1: matrix cores (k_stem_dgrad_mfma; needs K % 4 == 0, else the default is used; measured slower)
 constexpr int kStemDefaultVariant = 0;
@@ -3820,6 +4480,10 @@ int dp_debug_set(int knob, int value) {
     case DP_DEBUG_CONV1X1_VARIANT:
       DP_REQUIRE(value >= 0 && value < 16 && (value & 3) != 3);
       g_conv1x1_variant = value;
+      return 0;
+    case DP_DEBUG_CONV3X3_VARIANT:
+      DP_REQUIRE(value >= 0 && value <= 2);
+      g_conv3x3_variant = value;
       return 0;
     default:
       return (int)hipErrorInvalidValue;
@@ -4078,16 +4742,52 @@ int dp_project_update(const dp_update_cfg_t *cfg, const float *x, const float *a
   return launch_status();
 }
 
+// Which kernel runs a stride-1 3x3 problem of side H: k_conv3x3_mfma (explicit zero rows / columns in LDS; sides 56 / 28 / 14 /
+// 7) or k_conv3x3_flat (flat image, masked taps; any of the sides below).  Same packed weights, same summation order, same
+// bits.  Default: the measured winner per side (profiles/r05j_*); DP_DEBUG_CONV3X3_VARIANT forces one for A/B runs.
+static bool conv3x3_side_rows(int H) { return H == 56 || H == 28 || H == 14 || H == 7; }
+static bool conv3x3_side_flat(int H) { return H == 56 || H == 28 || H == 14 || H == 7 || H == 96 || H == 48 || H == 24 || H == 12; }
+static bool conv3x3_flat_default(int H) { return !conv3x3_side_rows(H) || H == 7; }   // 7 x 7: 1.054 vs 1.169 ms at N = 512 (r05j)
+
 static int conv3x3_launch(const float *x, const float *wt, const float *ab, int N, int C, int O, int H, int W, float *y,
                           dp_stream_t stream) {
   DP_REQUIRE(x && wt && y && aligned16(x) && aligned16(wt) && aligned16(y));
   DP_REQUIRE(N > 0 && C > 0 && C % kCvCh == 0 && O > 0 && O % kCvO == 0 && O / kCvO <= 65535 && H == W);
-  DP_REQUIRE(H == 56 || H == 28 || H == 14 || H == 7);
-  DP_REQUIRE(!ab || (H != 7 && (reinterpret_cast<uintptr_t>(ab) & 7u) == 0));   // no fold on the 7 x 7 planes (17 scalar items per lane)
+  DP_REQUIRE(conv3x3_side_rows(H) || conv3x3_side_flat(H));
+  DP_REQUIRE(!ab || (H != 7 && (reinterpret_cast<uintptr_t>(ab) & 7u) == 0));   // no fold on the 7 x 7 planes (rows are not 16-byte multiples)
   DP_REQUIRE((long)N * H * W + kCvPix < (1L << 31));      // 32-bit pixel arithmetic in the kernel
+  hipStream_t st = as_stream(stream);
+  const bool flat = g_conv3x3_variant == 2 ? conv3x3_side_flat(H)
+                    : g_conv3x3_variant == 1 ? !conv3x3_side_rows(H) : conv3x3_flat_default(H);
+  if (flat) {
+    DP_REQUIRE((long)N * C * H * W < (1L << 31));         // 32-bit element offsets in the kernel
+    CfArgs A;
+    A.x = x; A.wt = wt; A.ab = ab; A.y = y;
+    A.N = N; A.C = C; A.O = O; A.og = O / kCvO;
+    const long tiles = H == 7 ? ((long)N + 8) / 9 : ((long)N * H * W + kCvPix - 1) / kCvPix;
+    DP_REQUIRE((tiles + 7) / 8 * 8 * A.og < (1L << 31));
+    A.tiles = (int)tiles;
+    const dim3 grid((unsigned)((tiles + 7) / 8 * 8 * A.og)), block(kBlock);
+#define DP_LAUNCH_CF(S_)                                                                       \
+  do {                                                                                         \
+    if (ab) hipLaunchKernelGGL((k_conv3x3_flat<S_, true>), grid, block, 0, st, A);             \
+    else hipLaunchKernelGGL((k_conv3x3_flat<S_, false>), grid, block, 0, st, A);               \
+  } while (0)
+    switch (H) {
+      case 7: hipLaunchKernelGGL((k_conv3x3_flat<7, false>), grid, block, 0, st, A); break;
+      case 14: DP_LAUNCH_CF(14); break;
+      case 28: DP_LAUNCH_CF(28); break;
+      case 56: DP_LAUNCH_CF(56); break;
+      case 12: DP_LAUNCH_CF(12); break;
+      case 24: DP_LAUNCH_CF(24); break;
+      case 48: DP_LAUNCH_CF(48); break;
+      default: DP_LAUNCH_CF(96); break;
+    }
+#undef DP_LAUNCH_CF
+    return launch_status();
+  }
   const long tiles = ((long)N * H * W + kCvPix - 1) / kCvPix;
   const dim3 grid((unsigned)tiles, O / kCvO), block(kBlock);
-  hipStream_t st = as_stream(stream);
   if (ab) {
     if (H == 56) hipLaunchKernelGGL((k_conv3x3_mfma<56, true>), grid, block, 0, st, x, wt, y, N, C, O, ab);
     else if (H == 28) hipLaunchKernelGGL((k_conv3x3_mfma<28, true>), grid, block, 0, st, x, wt, y, N, C, O, ab);
@@ -4131,6 +4831,58 @@ int dp_conv3x3s2_fwd(const float *x, const float *wt, const float *ab, int N, in
   else if (SO == 14) DP_LAUNCH_CV2(14);
   else DP_LAUNCH_CV2(7);
 #undef DP_LAUNCH_CV2
+  return launch_status();
+}
+
+int dp_conv3x3s2_bwd(const float *dy, const float *wt, int N, int O, int C, int Ho, int Wo, float *dx, int form,
+                     dp_stream_t stream) {
+  DP_REQUIRE(dy && wt && dx && aligned16(dy) && aligned16(wt) && aligned16(dx));
+  DP_REQUIRE(N > 0 && O > 0 && O % 16 == 0 && C > 0 && C % kCvO == 0 && Ho == Wo);
+  DP_REQUIRE(Ho == 28 || Ho == 14 || Ho == 7 || Ho == 48 || Ho == 24 || Ho == 12);      // side of dy; dx is (2 Ho) x (2 Ho)
+  DP_REQUIRE(form == DP_S2BWD_PAIRS || form == DP_S2BWD_CLASSES);
+  DP_REQUIRE((long)N * O * Ho * Wo < (1L << 31) && (long)N * C * Ho * Wo * 4 < (1L << 31));   // 32-bit element offsets
+  DP_REQUIRE((long)N * Ho * Wo + kCvPix < (1L << 31));
+  CfArgs A;
+  A.x = dy; A.wt = wt; A.ab = nullptr; A.y = dx;
+  A.N = N; A.C = O; A.O = C; A.og = C / kCvO;
+  hipStream_t st = as_stream(stream);
+  const dim3 block(kBlock);
+  if (form == DP_S2BWD_PAIRS) {       // 256-pixel tiles (5 whole images of 7 x 7), two row classes
+    const long tiles = Ho == 7 ? ((long)N + 4) / 5 : ((long)N * Ho * Wo + kC2Pix - 1) / kC2Pix;
+    DP_REQUIRE((tiles + 7) / 8 * 8 * A.og * 2 < (1L << 31));
+    A.tiles = (int)tiles;
+    const dim3 grid((unsigned)((tiles + 7) / 8 * 8 * A.og * 2));
+    switch (Ho) {
+      case 28: hipLaunchKernelGGL((k_conv3x3s2_dgrad2<28>), grid, block, 0, st, A); break;
+      case 14: hipLaunchKernelGGL((k_conv3x3s2_dgrad2<14>), grid, block, 0, st, A); break;
+      case 7: hipLaunchKernelGGL((k_conv3x3s2_dgrad2<7>), grid, block, 0, st, A); break;
+      case 48: hipLaunchKernelGGL((k_conv3x3s2_dgrad2<48>), grid, block, 0, st, A); break;
+      case 24: hipLaunchKernelGGL((k_conv3x3s2_dgrad2<24>), grid, block, 0, st, A); break;
+      default: hipLaunchKernelGGL((k_conv3x3s2_dgrad2<12>), grid, block, 0, st, A); break;
+    }
+    return launch_status();
+  }
+  const long tiles = Ho == 7 ? ((long)N + 8) / 9 : ((long)N * Ho * Wo + kCvPix - 1) / kCvPix;
+  DP_REQUIRE((tiles + 7) / 8 * 8 * A.og * 4 < (1L << 31));
+  A.tiles = (int)tiles;
+  const dim3 grid((unsigned)((tiles + 7) / 8 * 8 * A.og * 4));
+  switch (Ho) {
+    case 28: hipLaunchKernelGGL((k_conv3x3s2_dgrad<28>), grid, block, 0, st, A); break;
+    case 14: hipLaunchKernelGGL((k_conv3x3s2_dgrad<14>), grid, block, 0, st, A); break;
+    case 7: hipLaunchKernelGGL((k_conv3x3s2_dgrad<7>), grid, block, 0, st, A); break;
+    case 48: hipLaunchKernelGGL((k_conv3x3s2_dgrad<48>), grid, block, 0, st, A); break;
+    case 24: hipLaunchKernelGGL((k_conv3x3s2_dgrad<24>), grid, block, 0, st, A); break;
+    default: hipLaunchKernelGGL((k_conv3x3s2_dgrad<12>), grid, block, 0, st, A); break;
+  }
+  return launch_status();
+}
+
+int dp_stem_conv_fwd(const float *x, const float *wt, int N, int H, int W, float *y, dp_stream_t stream) {
+  DP_REQUIRE(x && wt && y && aligned16(x) && aligned16(wt) && aligned16(y));
+  DP_REQUIRE(N > 0 && W == kStW && H > 0 && H % 2 == 0);
+  const int tpi = (H / 2 + 3) / 4;
+  DP_REQUIRE((long)N * tpi < (1L << 31) && (long)N * 3 * H * W < (1L << 31));
+  hipLaunchKernelGGL(k_stem_conv_mfma, dim3((unsigned)(N * tpi)), dim3(kBlock), 0, as_stream(stream), x, wt, y, N, H, tpi);
   return launch_status();
 }
 

@@ -58,6 +58,18 @@ CONV3X3S2 = os.environ.get("DORPATCH_CONV3X3S2", "on")
 if CONV3X3S2 not in ("on", "off"):
     raise ValueError("DORPATCH_CONV3X3S2 must be on or off, got %r" % CONV3X3S2)
 CONV3X3S2_MIN_BATCH = int(os.environ.get("DORPATCH_CONV3X3S2_MIN_BATCH", "64"))
+# ... and their input gradients on dp_conv3x3s2_bwd (masked parity-class walks over the dy plane, two column classes per
+# workgroup) instead of MIOpen's NHWC implicit GEMM between batched_transpose_* kernels: "on" | "off".  Measured
+# (profiles/r05k_*): MIOpen / own at N = 512: 1.32 (128 @28 -> 56), 1.08, 1.00; at N = 128: 1.21, 1.00, 0.96; at N = 64: 1.10,
+# 1.01, 0.98 — and no transposes / fills around it; headline step 362.9 / 363.8 -> 361.0 / 361.3 ms on one box.
+CONV3X3S2_BWD = os.environ.get("DORPATCH_CONV3X3S2_BWD", "on")
+if CONV3X3S2_BWD not in ("on", "off"):
+    raise ValueError("DORPATCH_CONV3X3S2_BWD must be on or off, got %r" % CONV3X3S2_BWD)
+# The stem convolution (7x7 / stride 2, 3 -> 64 @224) on dp_stem_conv_fwd instead of MIOpen's stride-2 Winograd: "on" | "off".
+STEM_CONV = os.environ.get("DORPATCH_STEM_CONV", "on")
+if STEM_CONV not in ("on", "off"):
+    raise ValueError("DORPATCH_STEM_CONV must be on or off, got %r" % STEM_CONV)
+STEM_CONV_MIN_BATCH = int(os.environ.get("DORPATCH_STEM_CONV_MIN_BATCH", "16"))
 _used3 = {}          # (direction, route) -> set of (N, C, S) routed (report_conv3x3())
 
 
@@ -108,6 +120,18 @@ def _packed3(w, transpose):
     """pack_conv3x3_weights(w[, transposed + flipped]), cached."""
     from . import ops
     return _packed(w, ("3x3", bool(transpose)), lambda: ops.pack_conv3x3_weights(w, transpose=transpose))
+
+
+def _packed_stem(w):
+    """pack_stem_weights(w), cached."""
+    from . import ops
+    return _packed(w, ("stem",), lambda: ops.pack_stem_weights(w))
+
+
+def _packed3s2b(w):
+    """pack_conv3x3s2_dgrad_weights(w), cached."""
+    from . import ops
+    return _packed(w, ("3x3s2-dgrad",), lambda: ops.pack_conv3x3s2_dgrad_weights(w))
 
 
 def packed1(w, transpose):
@@ -166,6 +190,11 @@ def conv_fwd(x, w, stride=(1, 1), padding=(0, 0)):
         if ops.conv3x3s2_supported(x, w, stride, padding):
             _used3.setdefault(("fwd", "mfma"), set()).add((int(x.shape[0]), int(w.shape[1]), -int(x.shape[2])))
             return ops.conv3x3s2_fwd(x, _packed3(w, False))
+    if w.shape[2] == 7 and STEM_CONV == "on" and x.shape[0] >= STEM_CONV_MIN_BATCH:
+        from . import ops
+        if ops.stem_conv_supported(x, w, stride, padding):
+            _used3.setdefault(("fwd", "mfma"), set()).add((int(x.shape[0]), 3, -7))
+            return ops.stem_conv_fwd(x, _packed_stem(w))
     if MODE != "auto":
         return F.conv2d(x, w, None, stride, padding)
     return guard(_key("fwd", x.shape[0], w, stride, x.shape[2:], padding), lambda: F.conv2d(x, w, None, stride, padding))
@@ -177,6 +206,12 @@ def conv_bwd_data(dy, x_ref, w, stride=(1, 1), padding=(0, 0)):
     if w.shape[2] == 3 and dy.shape[2:] == x_ref.shape[2:] and _conv3x3_route("bwd", dy, w, stride, padding):
         from . import ops
         return ops.conv3x3_fwd(dy, _packed3(w, True))
+    if (w.shape[2] == 3 and tuple(stride) == (2, 2) and CONV3X3S2_BWD == "on" and dy.shape[0] >= CONV3X3S2_MIN_BATCH
+            and x_ref.shape[2] == 2 * dy.shape[2] and x_ref.shape[3] == 2 * dy.shape[3]):
+        from . import ops
+        if ops.conv3x3s2_bwd_supported(dy, w, stride, padding):
+            _used3.setdefault(("bwd", "mfma"), set()).add((int(dy.shape[0]), int(w.shape[1]), -int(dy.shape[2])))
+            return ops.conv3x3s2_bwd(dy, _packed3s2b(w), int(w.shape[1]))
 
     def call():
         return torch.ops.aten.convolution_backward(dy, x_ref, w, None, tuple(stride), tuple(padding), (1, 1), False,

@@ -339,7 +339,7 @@ def project_update(x, adv_x, lv_x, g_adv, scale, structured, pattern, mask, *, s
 
 
 # ---------------------------------------------------------------- a-8: 3x3 convolutions on the matrix cores
-CONV3X3_SIDES = (56, 28, 14, 7)
+CONV3X3_SIDES = (56, 28, 14, 7, 96, 48, 24, 12)      # planes of ResNetV2-50 at 224 x 224 and at 384 x 384
 
 # bench.py's "roofline_conv": set to a list for ONE extra, untimed step and every matrix-core convolution launch appends
 # (kernel, shape key, flop, start event, stop event) — torch events on the launch stream (the kernels run on torch's current
@@ -359,12 +359,13 @@ def _timed_conv(kernel, key, flop, launch):
 
 
 def conv3x3_supported(x, weight, stride=(1, 1), padding=(1, 1)):
-    """Shapes dp_conv3x3_fwd takes: fp32 GPU NCHW, 3x3 / stride 1 / pad 1, square planes of side 56 / 28 / 14 / 7,
-    C % 8 == 0, O % 64 == 0 (every stride-1 3x3 convolution of ResNetV2-50 at 224 x 224)."""
+    """Shapes dp_conv3x3_fwd takes: fp32 GPU NCHW, 3x3 / stride 1 / pad 1, square planes of side 56 / 28 / 14 / 7 or
+    96 / 48 / 24 / 12, C % 8 == 0, O % 64 == 0 (every stride-1 3x3 convolution of ResNetV2-50 at 224 x 224 and 384 x 384)."""
     return (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
             and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
             and x.shape[2] == x.shape[3] and x.shape[2] in CONV3X3_SIDES and weight.shape[1] == x.shape[1]
-            and weight.shape[1] % 8 == 0 and weight.shape[0] % 64 == 0)
+            and weight.shape[1] % 8 == 0 and weight.shape[0] % 64 == 0
+            and x.shape[0] * max(weight.shape[0], weight.shape[1]) * x.shape[2] * x.shape[3] < 2 ** 31)
 
 
 def pack_conv3x3_weights(w, transpose=False):
@@ -380,12 +381,12 @@ def pack_conv3x3_weights(w, transpose=False):
     return w.reshape(O // 64, 64, C // 8, 4, 2, 3, 3).permute(0, 2, 3, 5, 6, 4, 1).contiguous()
 
 
-CONV3X3_FOLD_SIDES = (56, 28, 14)
+CONV3X3_FOLD_SIDES = (56, 28, 14, 96, 48, 24, 12)     # every side but 7 (rows of 7 floats are not 16-byte multiples)
 
 
 def conv3x3_fwd(x, wt, ab=None):
     """y = conv2d(x', w, stride 1, padding 1) for x (N,C,S,S), wt = pack_conv3x3_weights(w), on v_mfma_f32_32x32x2_f32.
-    ``ab`` (N,C,2) from ``gn_stats``: x' = relu(group_norm(x)) applied while staging (x is the RAW tensor; S in 56/28/14)."""
+    ``ab`` (N,C,2) from ``gn_stats``: x' = relu(group_norm(x)) applied while staging (x is the RAW tensor; every side but 7)."""
     lib = _lib.load()
     _chk(x, torch.float32, "x"), _chk(wt, torch.float32, "wt")
     N, C, H, W = x.shape
@@ -437,6 +438,65 @@ def conv3x3s2_fwd(x, wt, ab=None):
         return y
     return _timed_conv("k_conv3x3s2_mfma", (N, C, O, H * W // 4, ab is not None, False), 18.0 * N * (H // 2) * (W // 2) * C * O,
                        launch)
+
+
+CONV3X3S2_BWD_SIDES = (28, 14, 7, 48, 24, 12)      # sides of dy (the OUTPUT of the strided convolution)
+
+
+def conv3x3s2_bwd_supported(dy, weight, stride=(2, 2), padding=(1, 1)):
+    """Shapes dp_conv3x3s2_bwd takes: dy (N,O,Ho,Ho) fp32 GPU NCHW of a 3x3 / stride 2 / pad 1 convolution with an EVEN
+    input side 2 Ho, Ho in 28 / 14 / 7 (224 x 224 inputs) or 48 / 24 / 12 (384 x 384), O % 16 == 0, C % 64 == 0."""
+    return (isinstance(dy, torch.Tensor) and dy.is_cuda and dy.dtype == torch.float32 and dy.dim() == 4 and dy.is_contiguous()
+            and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (2, 2) and tuple(padding) == (1, 1)
+            and dy.shape[2] == dy.shape[3] and dy.shape[2] in CONV3X3S2_BWD_SIDES and weight.shape[0] == dy.shape[1]
+            and weight.shape[0] % 16 == 0 and weight.shape[1] % 64 == 0
+            and dy.shape[0] * max(weight.shape[0], 4 * weight.shape[1]) * dy.shape[2] * dy.shape[3] < 2 ** 31)
+
+
+def pack_conv3x3s2_dgrad_weights(w, pairs=True):
+    """(O, C, 3, 3) frozen weights of a 3x3 / stride 2 / pad 1 convolution -> the parity classes of its INPUT GRADIENT in
+    dp_conv3x3s2_bwd's k-walk order (include/dorpatch_hip.h).  Class (pr, pc) of dx — rows 2a + pr, columns 2b + pc — sums
+    dy[a + th][b + tw] * w[.][.][kh][kw] over th <= pr, tw <= pc with kh = 1 (pr = 0) or (2, 0)[th], kw likewise.
+    ``pairs`` (DP_S2BWD_PAIRS, the default form): both column classes of a row parity share a workgroup — row class 1 then 0,
+    per (chunk of 8 dy channels, channel pair, th) the three weight vectors kw = (1, 2, 0); else (DP_S2BWD_CLASSES) the four
+    classes (1,1), (0,1), (1,0), (0,0) back to back.  Plain tensor reshuffle, once per frozen convolution."""
+    w = w.detach().float()
+    O, C = w.shape[0], w.shape[1]
+    assert w.shape[2:] == (3, 3) and O % 16 == 0 and C % 64 == 0
+    parts = []
+    if pairs:
+        for pr in (1, 0):
+            khs = [2, 0] if pr else [1]
+            ws = w[:, :, khs][:, :, :, [1, 2, 0]]                                  # (O, C, th, j)
+            ws = ws.reshape(O // 8, 4, 2, C // 64, 64, len(khs), 3)                 # chunk, cp, half, og, c', th, j
+            parts.append(ws.permute(3, 0, 1, 5, 6, 2, 4).contiguous().reshape(-1))
+        return torch.cat(parts)
+    for pr, pc in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        khs, kws = ([2, 0] if pr else [1]), ([2, 0] if pc else [1])
+        T = len(khs) * len(kws)
+        CH = 16 // T
+        ws = w[:, :, khs][:, :, :, kws]                                   # (O, C, th, tw)
+        ws = ws.reshape(O // CH, CH // 2, 2, C // 64, 64, len(khs), len(kws))      # chunk, cp, half, og, c', th, tw
+        parts.append(ws.permute(3, 0, 1, 5, 6, 2, 4).contiguous().reshape(-1))
+    return torch.cat(parts)
+
+
+def conv3x3s2_bwd(dy, wt, C, pairs=True):
+    """dx (N,C,2Ho,2Ho) = the input gradient of conv2d(x, w, stride 2, padding 1) for dy (N,O,Ho,Ho) and
+    wt = pack_conv3x3s2_dgrad_weights(w, pairs), on v_mfma_f32_32x32x2_f32 (exact f32, fixed order: deterministic; both
+    forms give the same bits)."""
+    lib = _lib.load()
+    _chk(dy, torch.float32, "dy"), _chk(wt, torch.float32, "wt")
+    N, O, Ho, Wo = dy.shape
+    assert wt.numel() == 9 * C * O, (wt.shape, C, O)
+    dx = torch.empty((N, C, 2 * Ho, 2 * Wo), dtype=torch.float32, device=dy.device)
+    form = _lib.DP_S2BWD_PAIRS if pairs else _lib.DP_S2BWD_CLASSES
+
+    def launch():
+        _lib.check(lib.dp_conv3x3s2_bwd(_p(dy), _p(wt), N, O, C, Ho, Wo, _p(dx), form, _stream()), "dp_conv3x3s2_bwd")
+        return dx
+    return _timed_conv("k_conv3x3s2_dgrad2" if pairs else "k_conv3x3s2_dgrad", (N, O, C, Ho * Wo, False, False),
+                       18.0 * N * Ho * Wo * C * O, launch)
 
 
 # ---------------------------------------------------------------- a-8: 1x1 convolutions on the matrix cores (round 5)
@@ -726,6 +786,39 @@ def stem_dgrad_reduce(dy, weight, table, idx, idx2=None, norm=RAW_NORM, B=None, 
     return out
 
 
+def stem_conv_supported(x, weight, stride=(2, 2), padding=(3, 3)):
+    """Shapes dp_stem_conv_fwd takes: fp32 GPU NCHW (N,3,H,224), H even, filter (64,3,7,7) / stride 2 / pad 3."""
+    return (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+            and tuple(weight.shape) == (64, 3, 7, 7) and tuple(stride) == (2, 2) and tuple(padding) == (3, 3)
+            and x.shape[1] == 3 and x.shape[3] == 224 and x.shape[2] % 2 == 0 and x.numel() < 2 ** 31)
+
+
+def pack_stem_weights(w):
+    """(64, 3, 7, 7) frozen stem filter -> dp_stem_conv_fwd's k-walk: [7 j + kw][half][o] = w[o][r % 3][r // 3][kw] with
+    r = 2 j + half over the 21 (kh, channel) rows, the 22nd is zero padding (include/dorpatch_hip.h)."""
+    w = w.detach().float()
+    assert tuple(w.shape) == (64, 3, 7, 7)
+    rows = w.permute(2, 1, 3, 0).reshape(21, 7, 64)                     # [3 kh + c][kw][o]
+    rows = torch.cat([rows, torch.zeros_like(rows[:1])])                 # r = 21: padding
+    return rows.reshape(11, 2, 7, 64).permute(0, 2, 1, 3).contiguous()   # [j][kw][half][o]
+
+
+def stem_conv_fwd(x, wt):
+    """y (N,64,H/2,112) = conv2d(x, w, stride 2, padding 3) for x (N,3,H,224), wt = pack_stem_weights(w), on
+    v_mfma_f32_32x32x2_f32."""
+    lib = _lib.load()
+    _chk(x, torch.float32, "x"), _chk(wt, torch.float32, "wt")
+    N, C, H, W = x.shape
+    assert C == 3 and wt.numel() == 77 * 2 * 64
+    y = torch.empty((N, 64, H // 2, W // 2), dtype=torch.float32, device=x.device)
+
+    def launch():
+        _lib.check(lib.dp_stem_conv_fwd(_p(x), _p(wt), N, H, W, _p(y), _stream()), "dp_stem_conv_fwd")
+        return y
+    return _timed_conv("k_stem_conv_mfma", (N, 3, 64, (H // 2) * (W // 2), False, False), 2.0 * N * (H // 2) * (W // 2) * 147 * 64,
+                       launch)
+
+
 class StemConvFunction(torch.autograd.Function):
     """Stem convolution with a frozen filter: forward through MIOpen, input gradient through
     dp_stem_dgrad (the 3-channel transposed convolution libraries handle poorly)."""
@@ -834,7 +927,7 @@ def _fconv_bwd(kind, dy, w, res=None, x_ref=None):
     if kind == 1:
         return conv1x1_fwd(dy, libconv.packed1(w, True), res=res, out=res)
     assert res is None
-    if kind == 32:          # the input gradient of the strided convolution stays with the library (x_ref: its shape only)
+    if kind == 32:          # dp_conv3x3s2_bwd where libconv routes it there, else the library (x_ref: its shape only)
         return libconv.conv_bwd_data(dy, x_ref, w, (2, 2), (1, 1))
     return conv3x3_fwd(dy, libconv._packed3(w, True))
 

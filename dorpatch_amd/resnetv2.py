@@ -236,6 +236,9 @@ class _Stem(nn.Module):
             from . import ops
             if ops.stem_dgrad_supported(x, conv.weight, conv.stride, conv.padding):
                 return ops.StemConvFunction.apply(x, conv.weight)    # input gradient via dp_stem_dgrad
+        if GroupNormAct.fused and not x.requires_grad and conv.folded and not conv.weight.requires_grad and x.is_cuda:
+            from . import libconv
+            return libconv.conv_fwd(x.contiguous(), conv.weight, conv.stride, conv.padding)    # forward-only (the failure sweep)
         return conv(x)
 
     def pool(self, x):

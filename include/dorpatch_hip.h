@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DP_ABI_VERSION 10
+#define DP_ABI_VERSION 11
 #define DP_MAX_RECTS 4 /* occlusion windows per mask-table entry */
 
 typedef void *dp_stream_t; /* hipStream_t */
@@ -63,12 +63,16 @@ const char *dp_error_string(int err);
  *                                      (a tile's channel groups adjacent on one XCD), 1 channel group fastest, 2 tile
  *                                      fastest; bit 2 non-temporal result stores; bit 3 the next chunk goes to LDS in one
  *                                      lump half-way through the chunk (0: one item after each MFMA group).
- *                                      Same bits out of every variant */
+ *                                      Same bits out of every variant
+ *   DP_DEBUG_CONV3X3_VARIANT           dp_conv3x3_fwd / dp_conv3x3_gn_fwd: 1 = k_conv3x3_mfma (zero rows / columns laid out
+ *                                      in LDS) on every side it takes (56 / 28 / 14 / 7), 2 = k_conv3x3_flat (flat LDS
+ *                                      image, masked taps) on every side, 0 = the measured winner per side.  Same bits */
 #define DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK 1
 #define DP_DEBUG_UPDATE_VARIANT 2
 #define DP_DEBUG_APPLY_ORDER 3
 #define DP_DEBUG_AFFINE_GATHER 4
 #define DP_DEBUG_CONV1X1_VARIANT 5
+#define DP_DEBUG_CONV3X3_VARIANT 6
 int dp_debug_set(int knob, int value);
 
 /* ---- a-2  utils.clip (utils.py:105-110) + adv_x = delta + x (attack.py:184-185) ---- */
@@ -224,7 +228,9 @@ int dp_project_update(const dp_update_cfg_t *cfg, const float *x,
 /* ---- a-8: 3x3 / stride 1 / pad 1 convolutions of the frozen backbone on the matrix cores ----
  * (attack.py:222, 247 through the classifier; MIOpen runs them as fp32 Winograd on the VALUs.)  Direct implicit GEMM on
  * v_mfma_f32_32x32x2_f32: exact f32, y[n][o] = sum_{c,kh,kw} w[o][c][kh][kw] * x[n][c][.+kh-1][.+kw-1], zero padding.
- * Shapes: H = W in {56, 28, 14, 7} (the planes of ResNetV2-50 at 224 x 224), C % 8 == 0, O % 64 == 0.
+ * Shapes: H = W in {56, 28, 14, 7} (the planes of ResNetV2-50 at 224 x 224) or {96, 48, 24, 12} (at 384 x 384),
+ * C % 8 == 0, O % 64 == 0.  Two kernels, same bits: k_conv3x3_mfma (zero rows / columns laid out in LDS; the first four
+ * sides) and k_conv3x3_flat (flat LDS image + masked taps; all eight) — the measured winner per side runs.
  * x (N,C,H,W), y (N,O,H,W), dense NCHW.  wt = the weights PRE-PACKED for the kernel's k-walk (frozen: packed once by the
  * host, dorpatch_amd/ops.py pack_conv3x3_weights):
  *   wt[og][chunk][cp][kh][kw][half][o] = w[64 og + o][8 chunk + 2 cp + half][kh][kw],   O/64 x C/8 x 4 x 3 x 3 x 2 x 64.
@@ -234,7 +240,7 @@ int dp_project_update(const dp_update_cfg_t *cfg, const float *x,
 int dp_conv3x3_fwd(const float *x, const float *wt, int N, int C, int O, int H, int W, float *y, dp_stream_t stream);
 /* The same convolution of relu(group_norm(x)), the GroupNorm-apply + ReLU folded into the operand staging (round 5): x is
  * the RAW tensor, ab (N,C,2) the coefficients dp_gn_stats wrote; bit-identical to dp_gn_relu_fwd followed by dp_conv3x3_fwd
- * (the zero padding pads the normalised activation).  H = W in {56, 28, 14}. */
+ * (the zero padding pads the normalised activation).  Every side of dp_conv3x3_fwd except 7. */
 int dp_conv3x3_gn_fwd(const float *x, const float *wt, const float *ab, int N, int C, int O, int H, int W, float *y,
                       dp_stream_t stream);
 
@@ -244,10 +250,32 @@ int dp_conv3x3_gn_fwd(const float *x, const float *wt, const float *ab, int N, i
  * packed weights (pack_conv3x3_weights) and the same summation order as dp_conv3x3_fwd:
  *   y[n][o][h][w] = sum_{c,kh,kw} w[o][c][kh][kw] * x'[n][c][2h+kh-1][2w+kw-1],   x (N,C,H,W) -> y (N,O,H/2,W/2).
  * H = W in {56, 28, 14} (the INPUT side), C % 8 == 0, O % 64 == 0.  ab == NULL: x' = x; else x' = relu(group_norm(x)) with
- * the (N,C,2) coefficients dp_gn_stats wrote, applied while staging (bit-identical to dp_gn_relu_fwd first).  Forward
- * only: the input gradient of a strided convolution stays with the library (dorpatch_amd/libconv.py). */
+ * the (N,C,2) coefficients dp_gn_stats wrote, applied while staging (bit-identical to dp_gn_relu_fwd first). */
 int dp_conv3x3s2_fwd(const float *x, const float *wt, const float *ab, int N, int C, int O, int H, int W, float *y,
                      dp_stream_t stream);
+/* The INPUT GRADIENT of the same convolution (attack.py:247 through the classifier; MIOpen: NHWC implicit GEMM between
+ * batched_transpose_* kernels):  dx[n][c][i][j] = sum_{o,kh,kw : i = 2h+kh-1, j = 2w+kw-1} w[o][c][kh][kw] * dy[n][o][h][w],
+ * dy (N,O,Ho,Wo) -> dx (N,C,2Ho,2Wo), Ho = Wo in {28, 14, 7} (224 x 224 inputs) or {48, 24, 12} (384 x 384), O % 16 == 0,
+ * C % 64 == 0.  Four parity classes (i & 1, j & 1) of 1 / 2 / 2 / 4 taps over the dy plane, each an exact-f32 MFMA walk over
+ * K = (o ascending, taps row-major) — deterministic; one launch.  Two forms, same bits, each with its own packing of the
+ * frozen weights (dorpatch_amd/ops.py pack_conv3x3s2_dgrad_weights):
+ *   DP_S2BWD_PAIRS    a workgroup owns both column classes of a row parity pr and stores them interleaved (8-byte words);
+ *                     wt = row class 1 then 0, each  [og][chunk][cp][th][j][half][c'] = w[8 chunk + 2 cp + half][64 og + c']
+ *                     [kh][kw]  with kh = 1 if pr == 0 else (2, 0)[th], kw = (1, 2, 0)[j];   C/64 x O/8 x 4 x (1+pr) x 3 x 2 x 64
+ *   DP_S2BWD_CLASSES  one class per workgroup (4-byte words 8 bytes apart); wt = classes (1,1), (0,1), (1,0), (0,0), each
+ *                     [og][chunk][cp][th][tw][half][c'] with CH = 16 / ((1+pr)(1+pc)) channels per chunk, kw = 1 if pc == 0
+ *                     else (2, 0)[tw];   C/64 x O/CH x CH/2 x (1+pr) x (1+pc) x 2 x 64. */
+#define DP_S2BWD_PAIRS 0
+#define DP_S2BWD_CLASSES 1
+int dp_conv3x3s2_bwd(const float *dy, const float *wt, int N, int O, int C, int Ho, int Wo, float *dx, int form,
+                     dp_stream_t stream);
+
+/* ---- a-8: the stem convolution (3 -> 64, 7x7 / stride 2 / pad 3) on the matrix cores (round 5) ----
+ * (attack.py:222 through the classifier; MIOpen: stride-2 Winograd at 52 TFLOP/s.)  y[n][o][h][w] = sum_{c,kh,kw}
+ * w[o][c][kh][kw] * x[n][c][2h+kh-3][2w+kw-3], zero padding; x (N,3,H,224) -> y (N,64,H/2,112), H even.  Exact f32 on
+ * v_mfma_f32_32x32x2_f32, fixed order (deterministic).  wt = the frozen filter packed for the kernel's 77 k-steps
+ * (dorpatch_amd/ops.py pack_stem_weights):  wt[7 j + kw][half][o] = w[o][r % 3][r / 3][kw] with r = 2 j + half (0 for r = 21). */
+int dp_stem_conv_fwd(const float *x, const float *wt, int N, int H, int W, float *y, dp_stream_t stream);
 
 /* ---- a-8: 1x1 / stride 1 convolutions of the frozen backbone on the matrix cores (round 5) ----
  * (attack.py:222, 247 through the classifier: 33 of ResNetV2-50's 53 convolutions; until round 4 batched library GEMMs /

@@ -88,6 +88,19 @@ def _c3s2_supported(x, weight, stride=(2, 2), padding=(1, 1)):
             and weight.shape[1] % 8 == 0 and weight.shape[0] % 64 == 0)
 
 
+def _stemc_supported(x, weight, stride=(2, 2), padding=(3, 3)):
+    return (isinstance(x, torch.Tensor) and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+            and tuple(weight.shape) == (64, 3, 7, 7) and tuple(stride) == (2, 2) and tuple(padding) == (3, 3)
+            and x.shape[1] == 3 and x.shape[3] == 224 and x.shape[2] % 2 == 0)
+
+
+def _c3s2b_supported(dy, weight, stride=(2, 2), padding=(1, 1)):
+    return (isinstance(dy, torch.Tensor) and dy.dtype == torch.float32 and dy.dim() == 4 and dy.is_contiguous()
+            and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (2, 2) and tuple(padding) == (1, 1)
+            and dy.shape[2] == dy.shape[3] and dy.shape[2] in ops.CONV3X3S2_BWD_SIDES and weight.shape[0] == dy.shape[1]
+            and weight.shape[0] % 16 == 0 and weight.shape[1] % 64 == 0)
+
+
 def _poisoned(fn):
     """torch.empty / torch.empty_like that hand out NaN (float) or a sentinel (integer) instead of whatever the
     allocator had: an output element a kernel forgets to write then reaches the comparison as NaN / garbage."""
@@ -127,10 +140,13 @@ def _emulated_ops():
     assert lib is not None, "no host clang++: cannot build the emulation library"
     saved = dict(lib=_lib._lib, req=ops.require_gpu, chk=ops._chk, stream=ops._stream, gn=ops.gn_relu_supported,
                  pool=ops.pad_maxpool_supported, stem=ops.stem_dgrad_supported, sub=ops.subsample2_supported,
-                 c1=ops.conv1x1_supported, c3=ops.conv3x3_supported, c3s2=ops.conv3x3s2_supported)
+                 c1=ops.conv1x1_supported, c3=ops.conv3x3_supported, c3s2=ops.conv3x3s2_supported,
+                 c3s2b=ops.conv3x3s2_bwd_supported, stemc=ops.stem_conv_supported)
     if os.environ.get("HIPEMU_MFMA_CONVS", "0") == "1":     # the matrix-core convolutions through the emulation too (slow)
         ops.conv1x1_supported, ops.conv3x3_supported = _c1_supported, _c3_supported
         ops.conv3x3s2_supported = _c3s2_supported
+        ops.conv3x3s2_bwd_supported = _c3s2b_supported
+        ops.stem_conv_supported = _stemc_supported
     _lib._lib = lib
     ops._chk = _chk_cpu
     ops.require_gpu = lambda t, what: t
@@ -146,3 +162,5 @@ def _emulated_ops():
         ops.subsample2_supported = saved["sub"]
         ops.conv1x1_supported, ops.conv3x3_supported = saved["c1"], saved["c3"]
         ops.conv3x3s2_supported = saved["c3s2"]
+        ops.conv3x3s2_bwd_supported = saved["c3s2b"]
+        ops.stem_conv_supported = saved["stemc"]

@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from dorpatch_amd import masks, ops  # noqa: E402
+from dorpatch_amd import _lib, masks, ops  # noqa: E402
 from oracle import restatement as R  # noqa: E402
 
 DEV = "cuda:0"
@@ -425,6 +425,128 @@ def test_conv3x3_with_folded_groupnorm_is_bit_identical_to_the_two_kernels(N, C,
     assert torch.equal(mean2, mean) and torch.equal(rstd2, rstd)
     got = ops.conv3x3_fwd(x, wt, ab=ab)
     assert torch.equal(got, want)
+
+
+CONV3X3_FLAT_CASES = [   # (N, C, O, S, fold groups or 0, emulation-sized)
+    (3, 16, 64, 14, 16, True),      # 1.3 tiles of 2.3 planes each: halo items before the batch, seams inside the tile, ragged end
+    (11, 8, 64, 7, 0, True),        # flat mode: 9 whole images + a ragged second tile, ONE chunk
+    (1, 16, 64, 28, 0, True),       # 1.75 tiles inside one plane: the halo is the same image's rows
+    (3, 8, 64, 12, 0, True),        # a 384-input side: 432 pixels, one ragged tile
+    (1, 8, 64, 24, 0, False), (1, 8, 64, 48, 0, False), (1, 32, 64, 96, 32, False), (2, 8, 64, 56, 0, False),
+    (9, 256, 256, 14, 32, False), (37, 512, 512, 7, 0, False), (5, 128, 128, 28, 32, False), (2, 128, 128, 48, 32, False),
+]
+
+
+@pytest.mark.parametrize("N,C,O,S,G,small", CONV3X3_FLAT_CASES)
+def test_conv3x3_flat_kernel_matches_conv2d_and_the_row_kernel(N, C, O, S, G, small):
+    """k_conv3x3_flat (round 5: flat LDS image, masked taps — every side, incl. the 384-input ones) behind dp_conv3x3_fwd
+    with DP_DEBUG_CONV3X3_VARIANT = 2: against F.conv2d at 1e-5 of the output scale; one-hot weights exact (every tap's
+    mask at all four borders, the seams between images, the halo before the first / after the last pixel of the batch);
+    where k_conv3x3_mfma takes the side too: bit-identical to it (same k-walk); GroupNorm fold bit-identical to normalising
+    first (a positive beta would leak through a tap that is not masked)."""
+    if DEV == "cpu" and not small:
+        pytest.skip("through the fibre emulation this case takes minutes: GPU only")
+    g = torch.Generator().manual_seed(C + S)
+    x = torch.randn(N, C, S, S, generator=g)
+    x[0] += torch.arange(float(S)).view(1, S, 1) * 0.1 + torch.arange(float(S)).view(1, 1, S) * 0.01
+    w = torch.randn(O, C, 3, 3, generator=g) / (3.0 * C ** 0.5)
+    want = F.conv2d(x, w, padding=1)
+    xd, wt = x.to(DEV).contiguous(), ops.pack_conv3x3_weights(w).to(DEV)
+    w1 = torch.zeros(O, C, 3, 3)
+    for o in range(O):
+        w1[o, (5 * o + 3) % C, o % 3, (o // 3) % 3] = 1.0
+    try:
+        ops.debug_set(_lib.DP_DEBUG_CONV3X3_VARIANT, 2)
+        got = ops.conv3x3_fwd(xd, wt)
+        got1 = ops.conv3x3_fwd(xd, ops.pack_conv3x3_weights(w1).to(DEV)).cpu()
+        if G:
+            xr = (x * 1.5 + 0.3).to(DEV).contiguous()
+            gamma = (torch.rand(C, generator=g) + 0.5).to(DEV)
+            beta = (torch.randn(C, generator=g) * 0.2 + 1.0).to(DEV)
+            y, mean, rstd, _ = ops.gn_relu_fwd(xr, gamma, beta, G, 1e-5)
+            _, _, ab, _ = ops.gn_stats(xr, gamma, beta, G, 1e-5)
+            assert torch.equal(ops.conv3x3_fwd(xr, wt, ab=ab), ops.conv3x3_fwd(y, wt))
+    finally:
+        ops.debug_set(_lib.DP_DEBUG_CONV3X3_VARIANT, 0)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=1e-5 * float(want.abs().max()))
+    assert torch.equal(got1, F.conv2d(x, w1, padding=1))
+    if S in (56, 28, 14, 7):
+        try:
+            ops.debug_set(_lib.DP_DEBUG_CONV3X3_VARIANT, 1)
+            rows = ops.conv3x3_fwd(xd, wt)
+        finally:
+            ops.debug_set(_lib.DP_DEBUG_CONV3X3_VARIANT, 0)
+        assert torch.equal(got, rows)
+
+
+CONV3X3S2_BWD_CASES = [   # (N, O = channels of dy, C = channels of dx, side of dy, emulation-sized)
+    (2, 16, 64, 14, True),      # 392 pixels: one ragged tile spanning both images; ONE chunk in class (0,0), 4 in class (1,1)
+    (10, 32, 64, 7, True),      # flat mode: 9 whole images + a ragged second tile; 2 - 8 chunks per class
+    (1, 16, 128, 28, False),    # 1.75 tiles inside one plane, two channel groups
+    (3, 16, 64, 12, False),     # a 384-input side
+    (3, 128, 128, 28, False), (5, 256, 256, 14, False), (20, 512, 512, 7, False), (2, 128, 128, 48, False),
+]
+
+
+@pytest.mark.parametrize("N,O,C,S,small", CONV3X3S2_BWD_CASES)
+def test_conv3x3_stride2_input_gradient_on_the_matrix_cores(N, O, C, S, small):
+    """dp_conv3x3s2_bwd (round 5: the input gradient of the three stride-2 3x3 convolutions as masked parity-class walks, both
+    forms: two column classes per workgroup with interleaved 8-byte stores / one class per workgroup) against ATen's
+    convolution_backward at 1e-5 of the gradient scale; one-hot weights exact (each dx channel
+    receives ONE dy channel through ONE tap: the scatter to (2a + pr, 2b + pc), the bottom / right masks and the rows /
+    columns no tap reaches are all visible); every element of dx is written (the output starts as NaN)."""
+    import os
+    if DEV == "cpu" and not small and not (os.environ.get("DORPATCH_EMU_FULL", "0") == "1" and O <= 16):
+        pytest.skip("through the fibre emulation this case takes minutes: GPU (or DORPATCH_EMU_FULL=1 for the narrow ones)")
+    g = torch.Generator().manual_seed(C + S)
+    dy = torch.randn(N, O, S, S, generator=g)
+    dy[0] += torch.arange(float(S)).view(1, S, 1) * 0.1 + torch.arange(float(S)).view(1, 1, S) * 0.01
+    w = torch.randn(O, C, 3, 3, generator=g) / (3.0 * O ** 0.5)
+    x_ref = torch.zeros(N, C, 2 * S, 2 * S)
+
+    def ref(wq):
+        return torch.ops.aten.convolution_backward(dy, x_ref, wq, None, (2, 2), (1, 1), (1, 1), False, (0, 0), 1,
+                                                   (True, False, False))[0]
+    dyd = dy.to(DEV).contiguous()
+    got = ops.conv3x3s2_bwd(dyd, ops.pack_conv3x3s2_dgrad_weights(w).to(DEV), C).cpu()
+    want = ref(w)
+    assert tuple(got.shape) == (N, C, 2 * S, 2 * S) and not torch.isnan(got).any()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=1e-5 * float(want.abs().max()))
+    w1 = torch.zeros(O, C, 3, 3)
+    for c in range(C):
+        w1[(5 * c + 3) % O, c, c % 3, (c // 3) % 3] = 1.0
+    got1 = ops.conv3x3s2_bwd(dyd, ops.pack_conv3x3s2_dgrad_weights(w1).to(DEV), C).cpu()
+    assert torch.equal(got1, ref(w1))
+    # the one-class-per-workgroup form: each class's own k-walk in the same order -> the same bits
+    got4 = ops.conv3x3s2_bwd(dyd, ops.pack_conv3x3s2_dgrad_weights(w, pairs=False).to(DEV), C, pairs=False).cpu()
+    assert not torch.isnan(got4).any() and torch.equal(got4, got)
+
+
+STEM_CONV_CASES = [(1, 16, True), (2, 6, True), (3, 224, False), (2, 10, False)]      # (N, H, emulation-sized); W = 224
+
+
+@pytest.mark.parametrize("N,H,small", STEM_CONV_CASES)
+def test_stem_convolution_on_the_matrix_cores_matches_conv2d(N, H, small):
+    """dp_stem_conv_fwd (round 5: 3 -> 64, 7x7 / stride 2 / pad 3 with the whole K in LDS, column-parity de-interleaved
+    rows) against F.conv2d at 1e-5 of the output scale; one-hot weights exact: output channel o copies input channel
+    o % 3 through tap (o % 7, (o // 7) % 7) — every tap, the padding at all four borders, the ragged last tile (H / 2 not a
+    multiple of 4 rows)."""
+    if DEV == "cpu" and not small:
+        pytest.skip("through the fibre emulation this case takes minutes: GPU only")
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(N, 3, H, 224, generator=g)
+    x[0] += torch.arange(float(H)).view(1, H, 1) * 0.1 + torch.arange(224.0).view(1, 1, 224) * 0.01
+    w = torch.randn(64, 3, 7, 7, generator=g) / 12.0
+    want = F.conv2d(x, w, stride=2, padding=3)
+    xd = x.to(DEV).contiguous()
+    got = ops.stem_conv_fwd(xd, ops.pack_stem_weights(w).to(DEV)).cpu()
+    assert tuple(got.shape) == (N, 64, H // 2, 112)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=1e-5 * float(want.abs().max()))
+    w1 = torch.zeros(64, 3, 7, 7)
+    for o in range(64):
+        w1[o, o % 3, o % 7, (o // 7) % 7] = 1.0
+    got1 = ops.stem_conv_fwd(xd, ops.pack_stem_weights(w1).to(DEV)).cpu()
+    assert torch.equal(got1, F.conv2d(x, w1, stride=2, padding=3))
 
 
 CONV3X3S2_CASES = [   # (N, C, O, INPUT side, emulation-sized)

@@ -391,33 +391,114 @@ int main(int argc, char **argv) {
   const double out_bytes = (double)N * img;
 
   if (g_filter && strstr(g_filter, "conv3x3")) {
-    // the stride-1 3x3 convolutions of ResNetV2-50 at the training micro-batch (B here = N of the
-    // convolution) on the matrix cores; all four have the same 118 GFLOP at N = 512.
+    // VERDICT r3 item 7 / r4 items 5 + 6: the stride-1 3x3 convolutions of ResNetV2-50 at the training micro-batch (B here = N
+    // of the convolution) on the matrix cores — all four 224-input shapes have the same 118 GFLOP at N = 512 — on both
+    // kernels (k_conv3x3_mfma: zero rows / columns laid out in LDS; k_conv3x3_flat: flat image + masked taps), plain and with
+    // the GroupNorm fold.  DP_C3_SIDES=384: the planes of a 384 x 384 input (flat kernel only).
     const int Nc = B;
-    const int shapes[4][2] = {{64, 56}, {128, 28}, {256, 14}, {512, 7}};
-    for (auto &sh : shapes) {
-      const int Cc = sh[0], Sc = sh[1];
+    const char *sides = getenv("DP_C3_SIDES");
+    const bool big = sides && strstr(sides, "384");
+    const int shapes224[4][2] = {{64, 56}, {128, 28}, {256, 14}, {512, 7}};
+    const int shapes384[4][2] = {{64, 96}, {128, 48}, {256, 24}, {512, 12}};
+    for (int si = 0; si < 4; ++si) {
+      const int Cc = big ? shapes384[si][0] : shapes224[si][0], Sc = big ? shapes384[si][1] : shapes224[si][1];
       const size_t e = (size_t)Nc * Cc * Sc * Sc;
       float *cx = (float *)dmalloc(e * 4), *cy = (float *)dmalloc(e * 4), *cw = (float *)dmalloc((size_t)Cc * Cc * 9 * 4);
+      float *cab = (float *)dmalloc((size_t)Nc * Cc * 2 * 4);
       hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, st, (f4 *)cx, e / 4, 0.37f);
       hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, st, (f4 *)cw, (size_t)Cc * Cc * 9 / 4, 0.01f);
+      hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, st, (f4 *)cab, (size_t)Nc * Cc * 2 / 4, 0.5f);
       const double flop = 2.0 * Nc * Sc * Sc * (double)Cc * Cc * 9;
+      for (int variant = big ? 2 : 1; variant <= 2; ++variant) {
+        DP(dp_debug_set(DP_DEBUG_CONV3X3_VARIANT, variant));
+        for (int fold = 0; fold < 2; ++fold) {
+          if (fold && Sc == 7) continue;
+          for (int rep = 0; rep < 2; ++rep) {
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0));
+            CK(hipEventCreate(&e1));
+            auto run = [&]() {
+              if (fold) DP(dp_conv3x3_gn_fwd(cx, cw, cab, Nc, Cc, Cc, Sc, Sc, cy, st));
+              else DP(dp_conv3x3_fwd(cx, cw, Nc, Cc, Cc, Sc, Sc, cy, st));
+              return 0;
+            };
+            if (run()) return 1;
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < iters; ++i) if (run()) return 1;
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            ms /= iters;
+            printf("dp_conv3x3_fwd %3d->%3d @%2dx%2d N=%d %s %s  %8.4f ms  %7.1f TFLOP/s  (%.1f%% of the 157.3 TFLOP/s f32 peak)\n",
+                   Cc, Cc, Sc, Sc, Nc, variant == 1 ? "k_conv3x3_mfma" : "k_conv3x3_flat", fold ? "fold " : "plain", ms,
+                   flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 1.573);
+          }
+        }
+      }
+      DP(dp_debug_set(DP_DEBUG_CONV3X3_VARIANT, 0));
+      CK(hipFree(cx)); CK(hipFree(cy)); CK(hipFree(cw)); CK(hipFree(cab));
+    }
+    return 0;
+  }
+  if (g_filter && strstr(g_filter, "stemconv")) {
+    // round 5: the stem convolution (3 -> 64, 7x7 / 2 @224) on the matrix cores; B = images
+    const int Nc = B;
+    const size_t ex = (size_t)Nc * 3 * 224 * 224, ey = (size_t)Nc * 64 * 112 * 112;
+    float *cx = (float *)dmalloc(ex * 4), *cy = (float *)dmalloc(ey * 4), *cw = (float *)dmalloc(77 * 128 * 4);
+    hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, st, (f4 *)cx, ex / 4, 0.37f);
+    hipLaunchKernelGGL(k_fill, dim3(8), dim3(256), 0, st, (f4 *)cw, (size_t)77 * 128 / 4, 0.01f);
+    const double flop = 2.0 * Nc * 112 * 112 * 147.0 * 64;
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEvent_t e0, e1;
+      CK(hipEventCreate(&e0));
+      CK(hipEventCreate(&e1));
+      DP(dp_stem_conv_fwd(cx, cw, Nc, 224, 224, cy, st));
+      CK(hipEventRecord(e0, st));
+      for (int i = 0; i < iters; ++i) DP(dp_stem_conv_fwd(cx, cw, Nc, 224, 224, cy, st));
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= iters;
+      printf("dp_stem_conv_fwd 3->64 7x7/2 @224x224 N=%d  %8.4f ms  %7.1f TFLOP/s useful (%.1f%% of the 157.3 TFLOP/s f32 peak)  %.2f TB/s (x read + y written)\n",
+             Nc, ms, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 1.573, (ex + ey) * 4.0 / (ms * 1e-3) / 1e12);
+    }
+    CK(hipFree(cx)); CK(hipFree(cy)); CK(hipFree(cw));
+    return 0;
+  }
+  if (g_filter && strstr(g_filter, "conv3s2bwd")) {
+    // round 5: the input gradients of the three stride-2 3x3 convolutions (four masked parity-class walks, one launch)
+    const int Nc = B;
+    const char *sides = getenv("DP_C3_SIDES");
+    const bool big = sides && strstr(sides, "384");
+    const int shapes224[3][2] = {{128, 28}, {256, 14}, {512, 7}};
+    const int shapes384[3][2] = {{128, 48}, {256, 24}, {512, 12}};
+    for (int si = 0; si < 3; ++si) {
+      const int Cc = big ? shapes384[si][0] : shapes224[si][0], So = big ? shapes384[si][1] : shapes224[si][1];
+      const size_t ey = (size_t)Nc * Cc * So * So, ex = 4 * ey;
+      float *cdy = (float *)dmalloc(ey * 4), *cdx = (float *)dmalloc(ex * 4), *cw = (float *)dmalloc((size_t)Cc * Cc * 9 * 4);
+      hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, st, (f4 *)cdy, ey / 4, 0.37f);
+      hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, st, (f4 *)cw, (size_t)Cc * Cc * 9 / 4, 0.01f);
+      const double flop = 2.0 * Nc * So * So * (double)Cc * Cc * 9;
+      for (int form = 0; form < 2; ++form)
       for (int rep = 0; rep < 2; ++rep) {
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0));
         CK(hipEventCreate(&e1));
-        DP(dp_conv3x3_fwd(cx, cw, Nc, Cc, Cc, Sc, Sc, cy, st));
+        DP(dp_conv3x3s2_bwd(cdy, cw, Nc, Cc, Cc, So, So, cdx, form, st));
         CK(hipEventRecord(e0, st));
-        for (int i = 0; i < iters; ++i) DP(dp_conv3x3_fwd(cx, cw, Nc, Cc, Cc, Sc, Sc, cy, st));
+        for (int i = 0; i < iters; ++i) DP(dp_conv3x3s2_bwd(cdy, cw, Nc, Cc, Cc, So, So, cdx, form, st));
         CK(hipEventRecord(e1, st));
         CK(hipEventSynchronize(e1));
         float ms;
         CK(hipEventElapsedTime(&ms, e0, e1));
         ms /= iters;
-        printf("dp_conv3x3_fwd %3d->%3d @%2dx%2d N=%d (v_mfma_f32_32x32x2_f32)  %8.4f ms  %7.1f TFLOP/s  (%.1f%% of the 157.3 TFLOP/s f32 peak)\n",
-               Cc, Cc, Sc, Sc, Nc, ms, flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 1.573);
+        printf("dp_conv3x3s2_bwd %3d->%3d @%2dx%2d -> %2dx%2d N=%d %s  %8.4f ms  %7.1f TFLOP/s  (%.1f%% of the 157.3 TFLOP/s f32 peak)  %.2f TB/s written\n",
+               Cc, Cc, So, So, 2 * So, 2 * So, Nc, form == DP_S2BWD_PAIRS ? "pairs  " : "classes", ms, flop / (ms * 1e-3) / 1e12,
+               flop / (ms * 1e-3) / 1e12 / 1.573, ex * 4.0 / (ms * 1e-3) / 1e12);
       }
-      CK(hipFree(cx)); CK(hipFree(cy)); CK(hipFree(cw));
+      CK(hipFree(cdy)); CK(hipFree(cdx)); CK(hipFree(cw));
     }
     return 0;
   }
