@@ -104,7 +104,11 @@ def conv_roofline(loop, i, ms_per_step, samples):
                                      "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1),
                                      "frac_of_peak": round(v[2] / (v[1] * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4)}
                                  for k, v in sorted(per_kernel.items())},
-            "own_conv_share_of_step": round(total_ms / ms_per_step, 4)}
+            "own_conv_share_of_step": round(total_ms / ms_per_step, 4),
+            "classes": [{"kernel": k[0], "N": k[1][0], "C": k[1][1], "O": k[1][2], "pixels": k[1][3], "fold": bool(k[1][4]),
+                         "add": bool(k[1][5]), "launches": v[0], "ms": round(v[1], 3), "avg_ms": round(v[1] / v[0], 4),
+                         "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
+                        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])]}
 
 
 def comm_only(loop, pg, world, rank, json_fd, reps=50):
