@@ -3397,7 +3397,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3s2_mfma(const float *__res
   auto stash_w = [&](int buf, int k) {
     *reinterpret_cast<f4 *>(lds + buf * G::BUF + G::IN + 4 * (tid + k * kBlock)) = pwt[k];
   };
-  auto fetch = [&](int chunk) {
+  auto fetch = [&](int chunk) {        // items, then weights: the order the loop requests them in (below)
 #pragma unroll
     for (int it = 0; it < G::IT; ++it) fetch_item(chunk, it);
 #pragma unroll
@@ -3464,15 +3464,23 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3s2_mfma(const float *__res
 #pragma unroll
       for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t & 1], b[t & 1][q], acc[q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < kCv2Steps) {         // after MFMA group t (0..7): items t, t + 8 of chunk c + 1 to LDS, of chunk c + 2 requested
+      if (t + 1 < kCv2Steps) {
+        // after MFMA group t (0..7): slot i of the chunk's IT + WIT staging items (the activation items, then the weights) goes
+        // after group i * 8 / (IT + WIT) — to LDS for chunk c + 1, requested again for chunk c + 2.  Items before weights, in
+        // the prologue and here alike: the wait-count pass merges both request queues at the loop head, and with another
+        // order in the loop (weights after the first items) every chunk's first store waited for nearly the whole queue
+        // (s_waitcnt vmcnt(1 - 2) instead of the 5 - 9 of a FIFO of in-flight items).
+        constexpr int NI = G::IT + kCv2WtIt;
 #pragma unroll
-        for (int it = t; it < G::IT; it += kCv2Steps - 1) {
-          stash_item(nb, it);
-          fetch_item(c2, it);
-        }
-        if (t < kCv2WtIt) {
-          stash_w(nb, t);
-          fetch_w(c2, t);
+        for (int i = 0; i < NI; ++i) {
+          if (i * (kCv2Steps - 1) / NI != t) continue;
+          if (i < G::IT) {
+            stash_item(nb, i);
+            fetch_item(c2, i);
+          } else {
+            stash_w(nb, i - G::IT);
+            fetch_w(c2, i - G::IT);
+          }
         }
       }
     }
@@ -3599,10 +3607,19 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
     if (FOLD) pab[it] = *reinterpret_cast<const f2 *>(A.ab + (size_t)chunk * kC1Ch * 2 + 2 * (size_t)aoff[it]);
   };
   auto fetch_w = [&](int chunk) { pwt = *reinterpret_cast<const f4 *>(wtg + (size_t)chunk * kC1Wt); };
+  // The prologue requests a chunk in the SAME order as the loop does (item 0, weights, items 1 .. 6): the wait-count pass
+  // merges the prologue's and the loop's queue of outstanding loads at the loop head, and with the weights last in one and
+  // third in the other it put s_waitcnt vmcnt(0) in front of the weights' LDS store in the FOLD instantiations — every chunk
+  // drained the loads issued one MFMA group earlier (the whole 12 - 25 % the fold cost on the deep shapes, r05b).
   auto fetch = [&](int chunk) {
-#pragma unroll
-    for (int it = 0; it < kC1It; ++it) fetch_item(chunk, it);
+    fetch_item(chunk, 0);
     fetch_w(chunk);
+    __builtin_amdgcn_sched_barrier(0);        // ... and the scheduler must not re-order the requests either
+#pragma unroll
+    for (int it = 1; it < kC1It; ++it) {
+      fetch_item(chunk, it);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
   auto stash_item = [&](int buf, int it) {   // registers -> LDS (flat copy), with the fused GroupNorm-apply + ReLU
     f4 v = pin[it];
