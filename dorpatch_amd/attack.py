@@ -389,12 +389,14 @@ def sweep_plan(B, rows):
     two) x rows // g masks.  The row count of a forward is then the same whatever B is — when images retire from a batch
     the sweep keeps presenting the library convolutions the shapes they have already seen (a new batch size costs MIOpen
     a kernel lookup per layer and, under deterministic="auto", three probe runs per convolution problem: measured 2.4x on
-    the sweeps of a 4-image attack whose batch shrank to 3, 2, 1 images, profiles/r04a_bench_whole_attack.json)."""
+    the sweeps of a 4-image attack whose batch shrank to 3, 2, 1 images, profiles/r04a_bench_whole_attack.json).
+    g is the largest power of two that fits the remaining images AND divides ``rows`` (rows = 100: groups of 4 x 25 masks,
+    not 64 x 1), so the product g * (rows // g) is ``rows`` for every group."""
     plan, b = [], 0
     rows = max(1, int(rows))
     while b < B:
         g = 1
-        while g * 2 <= min(B - b, rows):
+        while g * 2 <= min(B - b, rows) and rows % (g * 2) == 0:     # g divides rows: g * (rows // g) == rows exactly
             g *= 2
         plan.append((b, b + g, max(1, rows // g)))
         b += g

@@ -933,7 +933,54 @@ __global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
           acc[1][2] += wgt * g2;
         }
       };
-      if (g_dev_gather == 0) {   // the shipped gather: a branch per candidate
+      if (g_dev_gather == 2 && cqx1 - cqx0 < 8 && cqy1 - cqy0 < 8) {
+      // Round 5: HIT COMPACTION.  The branchy loop below visits every candidate slot in turn, and with 64
+      // lanes nearly every slot is some lane's hit: ~30 slots x (branch + LDS round trip for the hit's weights / gradients)
+      // per sample, the wave parked on each (SQ counters: VALU active 26 %, waves parked 44 %).  Here pass 1 only reads the
+      // window's tap records (rows of <= 8 requested back to back) and sets bit 8 r + i of a 64-bit mask for a record that is
+      // a tap of either of the thread's two pixels; pass 2 walks the lane's OWN set bits in ascending order — one LDS round
+      // trip (record, two weights, three gradients) per iteration, ~6 iterations instead of ~30 slots.  Same candidates, same
+      // order (rows ascending, records ascending), same expressions: bit-identical.
+      const int ncol = cqx1 - cqx0 + 1;
+      unsigned long long hits = 0ull;
+      for (int qy = cqy0; qy <= (cqx0 <= cqx1 ? cqy1 : cqy0 - 1); ++qy) {
+        const int er = __mul24(qy, QWp) + cqx0;
+        int rec[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rec[u] = stap[er + min(u, ncol - 1)];
+        unsigned rowbits = 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int d0 = want0 - rec[u];
+          const bool hit = (((unsigned)d0 & ~0x101u) == 0u || ((unsigned)(d0 + 1) & ~0x101u) == 0u) && u < ncol;
+          rowbits |= (hit ? 1u : 0u) << u;
+        }
+        hits |= (unsigned long long)rowbits << ((qy - cqy0) << 3);
+      }
+      while (hits) {
+        const int c = __ffsll((long long)hits) - 1;
+        hits &= hits - 1ull;
+        const int e = __mul24(cqy0 + (c >> 3), QWp) + cqx0 + (c & 7);
+        const int rec = stap[e];
+        const float fx = swx[e], fy = swy[e];
+        const float g0 = sg[e], g1 = sg[CAP + e], g2 = sg[2 * CAP + e];
+        const int d0 = want0 - rec, d1 = d0 + 1;
+        if (((unsigned)d0 & ~0x101u) == 0u) {
+          float wgt = (d0 & 1) ? fx : 1.f - fx;
+          wgt = ((d0 >> 8) ? fy : 1.f - fy) * wgt;
+          acc[0][0] += wgt * g0;
+          acc[0][1] += wgt * g1;
+          acc[0][2] += wgt * g2;
+        }
+        if (((unsigned)d1 & ~0x101u) == 0u) {
+          float wgt = (d1 & 1) ? fx : 1.f - fx;
+          wgt = ((d1 >> 8) ? fy : 1.f - fy) * wgt;
+          acc[1][0] += wgt * g0;
+          acc[1][1] += wgt * g1;
+          acc[1][2] += wgt * g2;
+        }
+      }
+      } else if (g_dev_gather != 1) {   // the round-3 gather: a branch per candidate
       // A row of the window is <= 2 kx + 2 records (6 for the default placement range): its first 6 records are read
       // back to back before any is tested (one LDS round trip per row instead of one per candidate — the gather spent
       // its time waiting on them); order of accumulation unchanged: rows ascending, records ascending.
@@ -4491,7 +4538,7 @@ int dp_debug_set(int knob, int value) {
       g_apply_order = value;
       return 0;
     case DP_DEBUG_AFFINE_GATHER:
-      DP_REQUIRE(value == 0 || value == 1);
+      DP_REQUIRE(value >= 0 && value <= 2);
       g_aff_gather = value;
       return 0;
     case DP_DEBUG_CONV1X1_VARIANT:

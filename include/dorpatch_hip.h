@@ -58,7 +58,9 @@ const char *dp_error_string(int err);
  *                                      less HBM traffic, measured 19 % slower); 0: tile-fastest 3-D grid (one ascending
  *                                      output stream)
  *   DP_DEBUG_AFFINE_GATHER             dp_apply_affine_bwd: 1 = branch-free gather loop (same candidates, same order, same
- *                                      bits; measured 34 % slower); 0: a branch per candidate
+ *                                      bits; measured 34 % slower); 2 = hit compaction (round 5: a 64-bit mask of the
+ *                                      window's taps, then only the lane's own hits; same bits; measured 22 % slower);
+ *                                      0: a branch per candidate
  *   DP_DEBUG_CONV1X1_VARIANT           dp_conv1x1_fwd: bits 0-1 workgroup id -> (pixel tile, channel group): 0 XCD-aware
  *                                      (a tile's channel groups adjacent on one XCD), 1 channel group fastest, 2 tile
  *                                      fastest; bit 2 non-temporal result stores; bit 3 the next chunk goes to LDS in one

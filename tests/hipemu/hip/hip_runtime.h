@@ -302,6 +302,7 @@ inline hipemu_f16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, hipemu_
 
 // v_mul_i32_i24: the product of the operands' low 24 bits (sign-extended); exact for the small values it is used on
 inline int __mul24(int a, int b) { return ((a << 8) >> 8) * ((b << 8) >> 8); }
+inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 
 // v_readlane_b32 with a wave-uniform lane index
 inline int __builtin_amdgcn_readlane(int v, int lane) { return hipemu::shuffle(v, lane); }

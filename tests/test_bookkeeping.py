@@ -124,3 +124,15 @@ def test_lr_floor_and_stop_rule():
             break
     assert stops.index(True) == 402           # 1 improving step + 2 x 201 patience windows
     assert st.lr_current < np.float32(1e-3)
+
+
+def test_sweep_plan_presents_one_row_count():
+    """attack.sweep_plan: every group of the failure sweep is g images x rows // g masks with g a power of two that DIVIDES
+    ``rows`` — the forward's row count is ``rows`` for every group, whatever the number of running images."""
+    from dorpatch_amd.attack import sweep_plan
+    for B, rows in ((64, 512), (3, 512), (5, 100), (7, 96), (1, 512), (4, 128), (9, 1)):
+        plan = sweep_plan(B, rows)
+        assert plan[0][0] == 0 and plan[-1][1] == B and all(a[1] == b[0] for a, b in zip(plan, plan[1:]))
+        for b0, b1, masks in plan:
+            g = b1 - b0
+            assert g & (g - 1) == 0 and g * masks == rows, (B, rows, plan)

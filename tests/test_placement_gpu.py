@@ -135,12 +135,13 @@ def test_backward_gather_variants_are_bit_identical(B, S, H, affine):
     norm = ops.make_norm(*NORM, 0.5)
     outs = []
     try:
-        for variant in (1, 0):
+        for variant in (1, 2, 0):      # 2: hit compaction (round 5: a 64-bit mask of the window's taps, then the lane's own hits)
             ops.debug_set(KNOB, variant)
             outs.append(ops.apply_affine_bwd(G, th, thi, table, idx, idx2, norm, B=B).cpu())
     finally:
         ops.debug_set(KNOB, 0)
-    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+    assert torch.equal(outs[0], outs[2]), float((outs[0] - outs[2]).abs().max())
+    assert torch.equal(outs[1], outs[2]), float((outs[1] - outs[2]).abs().max())
     assert outs[0].abs().max() > 0
 
 

@@ -777,6 +777,11 @@ int main(int argc, char **argv) {
       DP(dp_apply_affine_bwd(big2, d_th, d_thi, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, nslab == 1 ? g_adv : slabs, st));
       if (nslab > 1) DP(dp_sum_slabs(slabs, nslab, (int64_t)B * 3 * P, g_adv, 0, st));
     });
+    g_aff_gather = 2;
+    bench("dp_apply_affine_bwd, hit-compaction gather (round 5)", out_bytes + (double)B * img, iters, st, [&] {
+      DP(dp_apply_affine_bwd(big2, d_th, d_thi, d_table, 2, d_idx, nullptr, S, B, S, H, W, &norm, nslab == 1 ? g_adv : slabs, st));
+      if (nslab > 1) DP(dp_sum_slabs(slabs, nslab, (int64_t)B * 3 * P, g_adv, 0, st));
+    });
     g_aff_gather = 0;
     g_aff_bwd_cap = 2048;
     bench("dp_apply_affine_bwd, 48 KiB region (3 workgroups per CU)", out_bytes + (double)B * img, iters, st, [&] {
