@@ -74,12 +74,15 @@ def conv_roofline(loop, i, ms_per_step, samples):
     matrix peak (157.3 TFLOP/s); `achieved` = the class's algorithmic flop / its summed launch time."""
     from dorpatch_amd import ops
     ops.CONV_EVENTS = []
+    streams = loop.o.streams
+    loop.o.streams = 1          # one stream for this pass: an event pair then brackets its own launch only
     try:
         loop.step(i)
         torch.cuda.synchronize()
         ev = ops.CONV_EVENTS
     finally:
         ops.CONV_EVENTS = None
+        loop.o.streams = streams
     if not ev:
         return None
     agg, per_kernel = {}, {}
@@ -99,7 +102,8 @@ def conv_roofline(loop, i, ms_per_step, samples):
             "bound": "mfma_f32", "achieved": round(tf, 1), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / F32_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms / n, 4), "launches_per_step": n,
             "class_ms_per_step": round(ms, 2), "timing": "torch events around each launch on the launch stream, one extra "
-                                                         "untimed step (in the step's own order and cache state)",
+                                                         "untimed step on ONE stream (in the step's own order and cache state; "
+                                                         "the timed steps run on config.streams streams)",
             "own_conv_kernels": {k: {"launches_per_step": v[0], "ms_per_step": round(v[1], 2),
                                      "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1),
                                      "frac_of_peak": round(v[2] / (v[1] * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4)}
