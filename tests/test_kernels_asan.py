@@ -75,7 +75,12 @@ def test_kernel_suite_is_clean_under_address_sanitizer():
     if full:
         files += [os.path.join(HERE, "test_taped_emu.py"), os.path.join(HERE, "test_placement_emu.py")]
     else:
-        select = ["-k", "not resnetv2_fused and not (add_gn_relu_fusion and (shape0 or shape1))"]
+        # ... and, of the round-5 matrix-core kernels' emulation-sized cases, one or two per kernel (row mode + fold and
+        # flat mode of k_conv3x3_flat, one dp_conv3x3s2_bwd case in both forms, one stem case): each costs the fibre
+        # emulation under ASan minutes; the others run in the plain emulation suite
+        select = ["-k", "not resnetv2_fused and not (add_gn_relu_fusion and (shape0 or shape1))"
+                        " and not (flat_kernel and (1-16-64-28 or 3-8-64-12))"
+                        " and not (stride2_input_gradient and 10-32-64-7) and not (stem_convolution and 1-16-True)"]
     res = subprocess.run([sys.executable, "-m", "pytest"] + files + ["-q", "-x", "-p", "no:cacheprovider"] + select,
                          env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=2400)
     tail = (res.stdout + res.stderr)[-3000:]
