@@ -3142,6 +3142,32 @@ int launch_apply_fwd(int variant, const float *adv_x, const int32_t *table, int 
 // LDS <= 2 x 40.3 KB -> 2 workgroups per CU = 2 waves per SIMD.
 typedef float f16v __attribute__((ext_vector_type(16)));
 
+// relu(x * a + b) on four values, the multiply and the add as PACKED fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 with
+// op_sel broadcasting a / b out of the coefficient pair): the same two roundings per value as dp_gn_relu_fwd's scalar
+// expression, 8 instead of 12 VALU instructions in the wave's in-order stream between two MFMA groups (hipcc splits a
+// float2 multiply into scalar ones on gfx950, hence the asm; the 4 v_cndmask this kernel used to spend per item on
+// pixel-less lanes were worth 4 - 5 % of the plain kernel: profiles/r05r_*).
+__device__ __forceinline__ void gn_apply4(f4 &v, f2 ab) {
+#ifdef HIPEMU_HOST
+  v.x = fmaxf(v.x * ab.x + ab.y, 0.f);
+  v.y = fmaxf(v.y * ab.x + ab.y, 0.f);
+  v.z = fmaxf(v.z * ab.x + ab.y, 0.f);
+  v.w = fmaxf(v.w * ab.x + ab.y, 0.f);
+#else
+  f2 lo = f2{v.x, v.y}, hi = f2{v.z, v.w};
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(lo) : "v"(lo), "v"(ab));
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(hi) : "v"(hi), "v"(ab));
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(lo) : "v"(lo), "v"(ab));
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(hi) : "v"(hi), "v"(ab));
+  // (fmaxf on an asm result would first canonicalise it — a second v_max_f32 per value; v_max_f32 itself is fmaxf)
+  asm("v_max_f32 %0, 0, %1" : "=v"(v.x) : "v"(lo.x));
+  asm("v_max_f32 %0, 0, %1" : "=v"(v.y) : "v"(lo.y));
+  asm("v_max_f32 %0, 0, %1" : "=v"(v.z) : "v"(hi.x));
+  asm("v_max_f32 %0, 0, %1" : "=v"(v.w) : "v"(hi.y));
+#endif
+}
+
+
 constexpr int kCvO = 64;                               // output channels per workgroup
 constexpr int kCvPix = 448, kCvFrags = kCvPix / 32;    // pixels per workgroup (14 fragments)
 constexpr int kCvCh = 8;                               // input channels per K-chunk
@@ -3244,10 +3270,14 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3_mfma(const float *__restr
       const int row = rem / G::VPR, q = rem - row * G::VPR;
       vec_t v = pin[it];
       if (FOLD) {
-        const float a = pab[it].x, b = pab[it].y;
-        float *e = reinterpret_cast<float *>(&v);
+        if constexpr (G::VW == 4) {
+          gn_apply4(*reinterpret_cast<f4 *>(&v), pab[it]);
+        } else {
+          const float a = pab[it].x, b = pab[it].y;
+          float *e = reinterpret_cast<float *>(&v);
 #pragma unroll
-        for (int k = 0; k < G::VW; ++k) e[k] = fmaxf(e[k] * a + b, 0.f);
+          for (int k = 0; k < G::VW; ++k) e[k] = fmaxf(e[k] * a + b, 0.f);
+        }
       }
       if (i < G::NV) *reinterpret_cast<vec_t *>(dst + ch * G::CHS + row * G::PITCH + G::X0 + q * G::VW) = v;
     }
@@ -3424,9 +3454,13 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3s2_mfma(const float *__res
     vec_t v = pin[it];
     float *e = reinterpret_cast<float *>(&v);
     if (FOLD) {                                  // dp_gn_relu_fwd's own expression: x * a + b (not fused), max 0
-      const float a = pab[it].x, b = pab[it].y;
+      if constexpr (G::VW == 4) {
+        gn_apply4(*reinterpret_cast<f4 *>(&v), pab[it]);
+      } else {
+        const float a = pab[it].x, b = pab[it].y;
 #pragma unroll
-      for (int k = 0; k < G::VW; ++k) e[k] = fmaxf(e[k] * a + b, 0.f);
+        for (int k = 0; k < G::VW; ++k) e[k] = fmaxf(e[k] * a + b, 0.f);
+      }
     }
     if (gofs[it] < 0) {
 #pragma unroll
@@ -3670,14 +3704,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
   };
   auto stash_item = [&](int buf, int it) {   // registers -> LDS (flat copy), with the fused GroupNorm-apply + ReLU
     f4 v = pin[it];
-    if (FOLD) {                          // dp_gn_relu_fwd's own expression: x * a + b (not fused), max 0
-      const float a = pab[it].x, b = pab[it].y;
-      v.x = fmaxf(v.x * a + b, 0.f);
-      v.y = fmaxf(v.y * a + b, 0.f);
-      v.z = fmaxf(v.z * a + b, 0.f);
-      v.w = fmaxf(v.w * a + b, 0.f);
-    }
-    if (xoff[it] < 0) v = f4{0.f, 0.f, 0.f, 0.f};
+    if (FOLD) gn_apply4(v, pab[it]);     // dp_gn_relu_fwd's own expression: x * a + b (not fused), max 0
+    // (an item without a pixel — past the end of the batch / of the tile's images — holds whatever lies at offset 0: it feeds
+    // only the D columns of lanes that never store, a 1 x 1 convolution has no neighbours)
     *reinterpret_cast<f4 *>(lds + buf * kC1Buf + 4 * (tid + it * kBlock)) = v;
   };
   auto stash_w = [&](int buf) { *reinterpret_cast<f4 *>(lds + buf * kC1Buf + kC1In + 4 * tid) = pwt; };
@@ -3777,8 +3806,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
   }
 
   const int oc0 = og * kC1O + ocf * 32 + 4 * half;
-#pragma unroll
-  for (int q = 0; q < 7; ++q) {
+  // fragment q -> element offset of its first output row (row (v & 3) + 8 (v >> 2) is that many planes further), -1: no pixel
+  auto out_offset = [&](int q) -> long {
     const int gl = (pf0 + 2 * q) * 32 + l32;
     int n, p;
     bool ok;
@@ -3791,17 +3820,34 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
       p = gl - s * FD, n = n0 + s;
       ok = s < A.spt && n < A.N;
     }
-    if (!ok) continue;
-    const size_t o = ((size_t)n * A.O + oc0) * HW + p;
-    float *yq = A.y + o;
-    if (RES) {
-      const float *rq = A.res + o;
-      float r[16];
+    return ok ? (long)(((size_t)n * A.O + oc0) * HW + p) : -1L;
+  };
+  // RES: the residual of fragment q + 1 is requested BEFORE fragment q is stored (res may be y itself: a store to y could
+  // alias the next loads for all the compiler knows, so left alone every fragment waited for its own 16 loads — seven
+  // memory round trips in a row per workgroup; the fragments' elements are disjoint, so the order is free)
+  float r[2][16];
+  long o_next = out_offset(0);
+  if (RES) {
 #pragma unroll
-      for (int v = 0; v < 16; ++v) r[v] = rq[(size_t)((v & 3) + 8 * (v >> 2)) * HW];
+    for (int v = 0; v < 16; ++v) r[0][v] = A.res[(o_next < 0 ? 0 : o_next) + (size_t)((v & 3) + 8 * (v >> 2)) * HW];
+  }
 #pragma unroll
-      for (int v = 0; v < 16; ++v) acc[q][v] += r[v];
+  for (int q = 0; q < 7; ++q) {
+    const long o = o_next;
+    if (q + 1 < 7) {
+      o_next = out_offset(q + 1);
+      if (RES) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v)
+          r[(q + 1) & 1][v] = A.res[(o_next < 0 ? 0 : o_next) + (size_t)((v & 3) + 8 * (v >> 2)) * HW];
+      }
     }
+    if (RES) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[q][v] += r[q & 1][v];
+    }
+    if (o < 0) continue;
+    float *yq = A.y + o;
     if (A.nt) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) __builtin_nontemporal_store(acc[q][v], yq + (size_t)((v & 3) + 8 * (v >> 2)) * HW);
@@ -3947,7 +3993,7 @@ __device__ __forceinline__ void cf_body(float *lds, const CfArgs &A, const float
   auto stash_item = [&](float *buf, int it) {    // registers -> LDS (flat copy), with the fused GroupNorm-apply + ReLU
     f4 v = pin[it];
     if (FOLD) {                                  // dp_gn_relu_fwd's own expression: x * a + b (not fused), max 0
-      const float a = pab[it].x, b = pab[it].y;
+      const float a = pab[it].x, b = pab[it].y;    // (scalar here: with gn_apply4's register pairs <14, true> starts to spill)
       v.x = fmaxf(v.x * a + b, 0.f);
       v.y = fmaxf(v.y * a + b, 0.f);
       v.z = fmaxf(v.z * a + b, 0.f);

@@ -342,6 +342,8 @@ def test_micro_batching_does_not_change_the_step(mb):
 def test_side_streams_do_not_change_the_step_or_the_sweep(streams):
     """DorPatch(streams=N): image-disjoint micro-batches (and the failure sweep's forwards) enqueued round-robin on N HIP
     streams — every micro-batch writes its own rows, nothing accumulates across streams: bit-identical to one stream."""
+    if DEV == "cpu" and streams == 3:
+        pytest.skip("through the emulation the stream count only changes the enqueue order: one count (2) is enough there")
     H, S, B = 56, 8, 4
     model = _toy(2.0)
     g = torch.Generator().manual_seed(21)

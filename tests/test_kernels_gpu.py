@@ -430,7 +430,7 @@ def test_conv3x3_with_folded_groupnorm_is_bit_identical_to_the_two_kernels(N, C,
 CONV3X3_FLAT_CASES = [   # (N, C, O, S, fold groups or 0, emulation-sized)
     (3, 16, 64, 14, 16, True),      # 1.3 tiles of 2.3 planes each: halo items before the batch, seams inside the tile, ragged end
     (11, 8, 64, 7, 0, True),        # flat mode: 9 whole images + a ragged second tile, ONE chunk
-    (1, 16, 64, 28, 0, True),       # 1.75 tiles inside one plane: the halo is the same image's rows
+    (1, 16, 64, 28, 0, False),      # 1.75 tiles inside one plane: the halo is the same image's rows
     (3, 8, 64, 12, 0, True),        # a 384-input side: 432 pixels, one ragged tile
     (1, 8, 64, 24, 0, False), (1, 8, 64, 48, 0, False), (1, 32, 64, 96, 32, False), (2, 8, 64, 56, 0, False),
     (9, 256, 256, 14, 32, False), (37, 512, 512, 7, 0, False), (5, 128, 128, 28, 32, False), (2, 128, 128, 48, 32, False),
@@ -481,7 +481,7 @@ def test_conv3x3_flat_kernel_matches_conv2d_and_the_row_kernel(N, C, O, S, G, sm
 
 CONV3X3S2_BWD_CASES = [   # (N, O = channels of dy, C = channels of dx, side of dy, emulation-sized)
     (2, 16, 64, 14, True),      # 392 pixels: one ragged tile spanning both images; ONE chunk in class (0,0), 4 in class (1,1)
-    (10, 32, 64, 7, True),      # flat mode: 9 whole images + a ragged second tile; 2 - 8 chunks per class
+    (10, 16, 64, 7, True),      # flat mode: 9 whole images + a ragged second tile; 1 - 4 chunks per class
     (1, 16, 128, 28, False),    # 1.75 tiles inside one plane, two channel groups
     (3, 16, 64, 12, False),     # a 384-input side
     (3, 128, 128, 28, False), (5, 256, 256, 14, False), (20, 512, 512, 7, False), (2, 128, 128, 48, False),
