@@ -233,7 +233,7 @@ def test_end_metric_through_resnetv2_is_a_plausible_draw_from_the_reference_null
 def test_end_metric_at_224_through_resnetv2_is_a_plausible_draw_from_the_reference_null(tmp_path, monkeypatch):
     """The end metric AT THE SIZE IT IS QUOTED ON: 224 x 224 through ResNetV2-50x1-BiT with a 10-class
     head (so that PatchCleanser has something to certify), well-conditioned seeded weights, S = 32, 100 iterations per stage
-    — tests/golden/end_metric_bit_224.npz: 2 images x (1 + 3) full runs of the UNMODIFIED reference on the CPU
+    — tests/golden/end_metric_bit_224.npz: 2 (round 4) or 6 (round 5) images x (1 + 3) full runs of the UNMODIFIED reference on the CPU
     (gen_golden.make_end_metric_bit224_fixture; runs 1-3 with 2 ulp of gradient noise = the reference-vs-reference spread).
     Image 0 keeps the network's natural margin between the clean class and the target, image 1 has the target's head bias
     raised (``gains`` = the shift) so that the margin is 0.15: one problem on each side of the tipping point.
@@ -286,6 +286,14 @@ def test_end_metric_at_224_through_resnetv2_is_a_plausible_draw_from_the_referen
     # cells directly: at most ONE of the 8 (image, ratio) cells may differ for "certified attack success" and for
     # "certified clean label", the clean adversarial images must land where the reference's do, and each failure count
     # must lie within 10 % of the universe (250 masks) of the recorded range.
+    if n > 2:
+        # The extended fixture (round 5, VERDICT r4 item 7: 6 images whose margins straddle the tipping point, 1 + 3 reference
+        # runs each): with six images the interval tests of check_against_null have power — certified ASR / ACC per ratio
+        # within the null's t-interval + two images, the count of clean adversarial images that reach the target, the total
+        # and the per-image failure counts against the null's range, at most 5 disagreements on the cells the four reference
+        # runs are unanimous on.
+        check_against_null(g, pred, cert, n_fail, adv_pred, per_image=True)
+        return
     target, clean = g["target"], g["clean"]
     ref_asr = (g["pc_pred"] == target[None, :, None]) & g["pc_cert"].astype(bool)
     ref_acc = (g["pc_pred"] == clean[None, :, None]) & g["pc_cert"].astype(bool)
