@@ -119,3 +119,54 @@ def test_conv3x3_route_table_and_pack_cache(monkeypatch):
     b = libconv._packed3(w, False)
     assert b is not a and torch.equal(b, 2 * a)
     assert set(libconv.report_conv3x3()) == {"mode", "fwd", "bwd"}
+
+
+def test_round5_weight_packings_and_routes():
+    """The host-side packings of the round-5 kernels, element by element against the layouts include/dorpatch_hip.h states,
+    and, for the stride-2 input gradient, against the convolution itself: summing each parity class's taps over the packed
+    weights reproduces ATen's backward-data on a tiny problem (pure host arithmetic: no kernel involved)."""
+    from dorpatch_amd import libconv, ops
+    g = torch.Generator().manual_seed(5)
+    O, C = 32, 64
+    w = torch.randn(O, C, 3, 3, generator=g)
+    # paired form: [row class 1 | row class 0], each [og][chunk][cp][th][j][half][c'], kw = (1, 2, 0)[j]
+    p = ops.pack_conv3x3s2_dgrad_weights(w, pairs=True)
+    assert p.numel() == 9 * O * C
+    p1 = p[:6 * O * C].reshape(C // 64, O // 8, 4, 2, 3, 2, 64)
+    p0 = p[6 * O * C:].reshape(C // 64, O // 8, 4, 1, 3, 2, 64)
+    for (chunk, cp, th, j, half, c) in ((1, 2, 0, 0, 1, 5), (3, 0, 1, 2, 0, 63), (0, 3, 1, 1, 1, 17)):
+        o = 8 * chunk + 2 * cp + half
+        assert float(p1[0, chunk, cp, th, j, half, c]) == float(w[o, c, (2, 0)[th], (1, 2, 0)[j]])
+        if th == 0:
+            assert float(p0[0, chunk, cp, 0, j, half, c]) == float(w[o, c, 1, (1, 2, 0)[j]])
+    # four-class form: classes (1,1), (0,1), (1,0), (0,0) with 16 / T channels per chunk
+    q = ops.pack_conv3x3s2_dgrad_weights(w, pairs=False)
+    q11 = q[:4 * O * C].reshape(C // 64, O // 4, 2, 2, 2, 2, 64)
+    assert float(q11[0, 5, 1, 1, 0, 1, 9]) == float(w[4 * 5 + 2 + 1, 9, 0, 2])      # th = 1 -> kh 0, tw = 0 -> kw 2
+    q00 = q[8 * O * C:].reshape(C // 64, O // 16, 8, 1, 1, 2, 64)
+    assert float(q00[0, 1, 3, 0, 0, 0, 40]) == float(w[16 + 6, 40, 1, 1])
+    # the classes ARE the input gradient: dx[2a + pr][2b + pc] = sum_{th <= pr, tw <= pc} dy[a + th][b + tw] w[kh][kw]
+    N, S = 1, 3
+    dy = torch.randn(N, O, S, S, generator=g)
+    want = torch.ops.aten.convolution_backward(dy, torch.zeros(N, C, 2 * S, 2 * S), w, None, (2, 2), (1, 1), (1, 1), False,
+                                               (0, 0), 1, (True, False, False))[0]
+    dyp = F.pad(dy, (0, 1, 0, 1))
+    got = torch.zeros_like(want)
+    for pr in (0, 1):
+        for pc in (0, 1):
+            for th in range(pr + 1):
+                for tw in range(pc + 1):
+                    kh, kw = ((2, 0)[th] if pr else 1), ((2, 0)[tw] if pc else 1)
+                    got[:, :, pr::2, pc::2] += torch.einsum("nohw,oc->nchw", dyp[:, :, th:th + S, tw:tw + S], w[:, :, kh, kw])
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=1e-5 * float(want.abs().max()))
+    # stem: [7 j + kw][half][o] = w[o][r % 3][r // 3][kw], r = 2 j + half, the 22nd row zero
+    ws = torch.randn(64, 3, 7, 7, generator=g)
+    ps = ops.pack_stem_weights(ws).reshape(11, 7, 2, 64)
+    for (j, kw, half, o) in ((0, 0, 0, 0), (4, 6, 1, 63), (10, 3, 0, 7)):
+        r = 2 * j + half
+        assert float(ps[j, kw, half, o]) == float(ws[o, r % 3, r // 3, kw])
+    assert float(ps[10, :, 1].abs().max()) == 0.0
+    # the committed route table knows the 384-input planes (round 5) and keeps the 224 ones
+    assert libconv.CONV3X3_TABLE[64].get(("fwd", 64, 96)) == "mfma" and libconv.CONV3X3_TABLE[512].get(("bwd", 512, 7)) == "mfma"
+    assert libconv.CONV3X3_TABLE[64].get(("fwd", 512, 12)) is None
+    assert libconv.CONV3X3S2_BWD in ("on", "off") and libconv.STEM_CONV in ("on", "off")
