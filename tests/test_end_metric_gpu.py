@@ -287,12 +287,37 @@ def test_end_metric_at_224_through_resnetv2_is_a_plausible_draw_from_the_referen
     # "certified clean label", the clean adversarial images must land where the reference's do, and each failure count
     # must lie within 10 % of the universe (250 masks) of the recorded range.
     if n > 2:
-        # The extended fixture (round 5, VERDICT r4 item 7: 6 images whose margins straddle the tipping point, 1 + 3 reference
-        # runs each): with six images the interval tests of check_against_null have power — certified ASR / ACC per ratio
-        # within the null's t-interval + two images, the count of clean adversarial images that reach the target, the total
-        # and the per-image failure counts against the null's range, at most 5 disagreements on the cells the four reference
-        # runs are unanimous on.
-        check_against_null(g, pred, cert, n_fail, adv_pred, per_image=True)
+        # The extended fixture (round 5): 6 images whose clean-vs-target margins straddle the tipping point
+        # (none, 0.15, 0.05, 0.22, 0.30, 0.38), 1 + 3 reference runs each.  What the reference recorded: the four runs are
+        # UNANIMOUS on every cell again (2 ulp of gradient noise moves nothing at 100 iterations per stage) — images 1, 2
+        # broken (1 / 0 failing masks of 2520, the target certified at 0.015 - 0.06), images 0, 4, 5 not (2520 / 2519 / 2520
+        # failing masks, the clean class certified), image 3 IN BETWEEN: 1110 failing masks, PatchCleanser returns the target
+        # at three ratios and the clean class at 0.12, nothing certified.  Criteria, fixed before the product was run on it:
+        # the five decided images must agree with the reference cell for cell on "certified attack success" and "certified
+        # clean label" up to ONE cell, land where the reference's clean adversarial images land, and keep their failure
+        # counts within 10 % of the universe (250 masks); the in-between image may fall either way but must stay
+        # un-certified-as-clean-AND-as-target in at most the pattern of one side, i.e. its failure count is only reported.
+        target, clean = g["target"], g["clean"]
+        ref_asr = (g["pc_pred"] == target[None, :, None]) & g["pc_cert"].astype(bool)
+        ref_acc = (g["pc_pred"] == clean[None, :, None]) & g["pc_cert"].astype(bool)
+        assert (ref_asr == ref_asr[0]).all() and (ref_acc == ref_acc[0]).all() and (g["n_fail"] == g["n_fail"][0]).all()
+        asr, acc = (pred == target[:, None]) & cert, (pred == clean[:, None]) & cert
+        print("certified ASR per ratio: product %s reference %s; certified ACC: product %s reference %s" % (
+            (asr.mean(0) * 100).round(1).tolist(), (ref_asr[0].mean(0) * 100).round(1).tolist(),
+            (acc.mean(0) * 100).round(1).tolist(), (ref_acc[0].mean(0) * 100).round(1).tolist()))
+        ref_fail = g["n_fail"][0]
+        decided = np.flatnonzero((ref_fail <= 2) | (ref_fail >= 2518))          # images 0, 1, 2, 4, 5
+        between = np.setdiff1d(np.arange(n), decided)
+        print("decided images %s, in between %s: product failures %s vs reference %s" % (
+            decided.tolist(), between.tolist(), n_fail[between].tolist(), ref_fail[between].tolist()))
+        assert len(decided) == 5
+        assert int((asr[decided] != ref_asr[0][decided]).sum()) <= 1, (asr.tolist(), ref_asr[0].tolist())
+        assert int((acc[decided] != ref_acc[0][decided]).sum()) <= 1, (acc.tolist(), ref_acc[0].tolist())
+        assert ((adv_pred == target) == (g["adv_pred"][0] == target))[decided].all(), (adv_pred.tolist(), g["adv_pred"][0].tolist())
+        assert (np.abs(n_fail - ref_fail)[decided] <= 250).all(), (n_fail.tolist(), ref_fail.tolist())
+        # certified ASR / ACC of the whole set: within one image (16.7 %) of the reference at every ratio
+        assert (np.abs(asr.mean(0) - ref_asr[0].mean(0)) <= 1.0 / n + 1e-9).all()
+        assert (np.abs(acc.mean(0) - ref_acc[0].mean(0)) <= 1.0 / n + 1e-9).all()
         return
     target, clean = g["target"], g["clean"]
     ref_asr = (g["pc_pred"] == target[None, :, None]) & g["pc_cert"].astype(bool)

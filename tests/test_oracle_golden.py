@@ -96,7 +96,9 @@ def test_end_metric_224_fixture_is_self_consistent():
     from dorpatch_amd.utils import NormModel, get_normalize
     g = load_golden("end_metric_bit_224.npz")
     assert (int(g["H"]), int(g["S"]), int(g["max_iterations"]), int(g["n_classes"])) == (224, 32, 100, 10)
-    for k in range(2):
+    n = g["x"].shape[0]
+    assert n in (2, 6)
+    for k in range(n):
         net = seeded_init_(resnetv2_50x1_bit(10), seed=1234, gn_bias=WELL_CONDITIONED_GN_BIAS).fold_weight_standardization().freeze()
         with torch.no_grad():
             net.head.fc.bias[int(g["target"][k])] += float(g["gains"][k])
@@ -105,7 +107,15 @@ def test_end_metric_224_fixture_is_self_consistent():
         assert int(top[1][0]) == int(g["clean"][k]) and int(top[1][1]) == int(g["target"][k])
         if not np.isnan(g["margins"][k]):
             assert abs(float(top[0][0] - top[0][1]) - float(g["margins"][k])) < 1e-4
-    assert (g["n_fail"] == np.array([2520, 1])).all() and (g["adv_pred"] == np.array([5, 1])).all()
-    asr = ((g["pc_pred"] == g["target"][None, :, None]) & g["pc_cert"]).mean(1) * 100
-    acc = ((g["pc_pred"] == g["clean"][None, :, None]) & g["pc_cert"]).mean(1) * 100
-    assert (asr == np.array([50.0, 50.0, 50.0, 0.0])).all() and (acc == 50.0).all()     # every run, every ratio
+    assert (g["n_fail"][:, :2] == np.array([2520, 1])).all() and (g["adv_pred"][:, :2] == np.array([5, 1])).all()
+    asr = ((g["pc_pred"] == g["target"][None, :, None]) & g["pc_cert"]).sum(1)          # images per (run, ratio)
+    acc = ((g["pc_pred"] == g["clean"][None, :, None]) & g["pc_cert"]).sum(1)
+    if n == 2:
+        assert (asr == np.array([1, 1, 1, 0])).all() and (acc == 1).all()                # every run, every ratio
+    else:
+        # round 5: margins none / 0.15 / 0.05 / 0.22 / 0.30 / 0.38 — images 1, 2 broken, 0, 4, 5 not, image 3 in between
+        # (1110 failing masks, nothing certified); the four runs are unanimous on every cell
+        assert (g["n_fail"] == np.array([2520, 1, 0, 1110, 2519, 2520])).all()
+        assert (g["adv_pred"] == np.array([5, 1, 1, 1, 5, 5])).all()
+        assert (asr == np.array([2, 2, 2, 1])).all() and (acc == np.array([3, 2, 3, 3])).all()
+        assert not g["pc_cert"][:, 3].any()
