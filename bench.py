@@ -68,6 +68,13 @@ PRESETS = {0: (8, 4, 224, 0.0204),          # configs[0]: the reference's own CP
 CONFIG3_TOTAL_SAMPLES = 512              # configs[3]: "512 EOT samples sharded 64/GPU" on 8 GPUs
 
 
+def conv_roofline_wanted(rank, world, dev_type, disabled):
+    """The extra, untimed step of `conv_roofline` runs on ONE rank — so only in a single-rank job: a step contains the
+    all-reduce of the patch gradient, and rank 0 entering it alone would wait for its peers for ever (the per-GPU launches
+    are the same at every N: like the PMC traffic, the entry is measured at --gpus 1)."""
+    return rank == 0 and world == 1 and dev_type == "cuda" and not disabled
+
+
 def conv_roofline(loop, i, ms_per_step, samples):
     """One extra, UNTIMED step with an event pair around every matrix-core convolution launch (ops.CONV_EVENTS) ->
     the dominant launch class (kernel, shape, fold / add) as a roofline entry + a per-kernel summary.  Bound: the fp32
@@ -705,7 +712,7 @@ def main(argv=None):
     events = loop.kernel_events
     loop.kernel_events = None
     conv_roof = None
-    if rank == 0 and dev.type == "cuda" and not args.no_conv_roofline:
+    if conv_roofline_wanted(rank, world, dev.type, args.no_conv_roofline):
         conv_roof = conv_roofline(loop, i, dt / args.steps * 1e3, B * S_local)
         i += 1
         note("matrix-core convolution pass done: %s" % (conv_roof or {}).get("kernel"))

@@ -201,3 +201,19 @@ def test_project_update_roofline_entry(stage):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["traffic"] is None
     assert r["algorithmic_bytes_per_launch"] == 56 * 56 * (72 if stage == 0 else 68) and r["avg_launch_ms"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "k_project_update_v4" in r["kernel"]
+
+
+def test_rank_local_extra_steps_only_in_single_rank_jobs():
+    """bench.py's conv-roofline pass is ONE more HotLoop.step on rank 0 — a step holds the job's all-reduce, so it may only
+    run when there is no peer to wait for (found by reading, round 5: the GPU multi-rank runs of the test suite pass
+    --no-conv-roofline or run on CPU tensors, where the pass is off anyway; the driver's --gpus N command passes neither)."""
+    import bench
+    assert bench.conv_roofline_wanted(0, 1, "cuda", False) is True
+    assert bench.conv_roofline_wanted(0, 2, "cuda", False) is False and bench.conv_roofline_wanted(0, 8, "cuda", False) is False
+    assert bench.conv_roofline_wanted(1, 2, "cuda", False) is False
+    assert bench.conv_roofline_wanted(0, 1, "cpu", False) is False and bench.conv_roofline_wanted(0, 1, "cuda", True) is False
+    # nothing else between the timed region and the JSON line runs a step on a subset of the ranks
+    import inspect
+    src = inspect.getsource(bench)
+    tail = src[src.index("conv_roof = None"):]
+    assert tail.count("loop.step(") == 0 and src.count("= conv_roofline(loop") == 1
