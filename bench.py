@@ -189,7 +189,8 @@ def parse(argv=None):
     ap.add_argument("--no-fused-gn", action="store_true", help="eager GroupNorm+ReLU instead of dp_gn_relu_*")
     ap.add_argument("--streams", type=int, default=None,
                     help="DorPatch(streams=N): the step's independent micro-batches enqueued round-robin on N HIP streams "
-                         "(default: the product's, DORPATCH_STREAMS or 1)")
+                         "(default: the product's — DORPATCH_STREAMS, else 2; each extra stream keeps one more micro-batch of saved "
+                         "activations live in its own allocator pool: DORPATCH_STREAMS=1 where memory is tight)")
     ap.add_argument("--conv3x3-kernel", default="default", choices=["default", "rows", "flat"],
                     help="A/B: dp_debug_set(DP_DEBUG_CONV3X3_VARIANT): which of the two stride-1 3x3 MFMA kernels runs "
                          "(rows: k_conv3x3_mfma wherever it applies; flat: k_conv3x3_flat everywhere; default: per side)")
@@ -648,6 +649,9 @@ def main(argv=None):
     if args.conv3x3_kernel != "default":
         from dorpatch_amd import _lib as _dp_lib, ops as _dp_ops
         _dp_ops.debug_set(_dp_lib.DP_DEBUG_CONV3X3_VARIANT, {"rows": 1, "flat": 2}[args.conv3x3_kernel])
+    for kv in filter(None, os.environ.get("DORPATCH_BENCH_DEBUG_SET", "").split(",")):     # A/B only: "5=16,6=16" = dp_debug_set(5, 16) ...
+        from dorpatch_amd import ops as _dp_ops
+        _dp_ops.debug_set(int(kv.split("=")[0]), int(kv.split("=")[1]))
     model = build_model(dev)
     x = torch.rand(B, 3, H, H, generator=torch.Generator().manual_seed(1234)).to(dev)
     with torch.no_grad():

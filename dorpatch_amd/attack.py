@@ -438,13 +438,21 @@ def _collect_failure(net, norm, adv_x, y_img, table, targeted_flags, batch_size,
     # the forwards are independent (disjoint slices of `fail`): round-robin over `streams` HIP streams, like the step's
     # micro-batches (DorPatch(streams=...)), so one forward's HBM-bound kernels overlap another's matrix-core kernels
     n_str = int(streams) if dev.type == "cuda" and streams and streams > 1 else 1
+    # everything the side streams only READ is produced on the calling stream BEFORE they fork from it: the
+    # labels as int32 (one conversion, the groups take views — a per-group `.to()` after the fork was ordered behind nothing
+    # the side streams wait for, and its block could be re-used by the next group's while queued forwards still read it),
+    # and the packed weights of the frozen convolutions (libconv builds them lazily on whatever stream asks first).
+    y32 = y_img.view(B, 1).to(torch.int32)
+    if dev.type == "cuda":
+        from . import libconv
+        libconv.prepack(net)
     if n_str > 1:
         side, main = _side_streams([] if stream_pool is None else stream_pool, n_str, dev)
     k = 0
     for b0, b1, chunk in plan:
         chunk = max(1, min(chunk, hi - lo))          # a universe (slice) smaller than one forward: no padding beyond it
         g = b1 - b0
-        xg, yg, tg = adv_x[b0:b1], y_img[b0:b1].view(g, 1).to(torch.int32), tflag[b0:b1].view(g, 1)
+        xg, yg, tg = adv_x[b0:b1], y32[b0:b1], tflag[b0:b1].view(g, 1)
         for j0 in range(lo, hi, chunk):
             j1 = min(hi, j0 + chunk)
             with (torch.cuda.stream(side[k % n_str]) if n_str > 1 else contextlib.nullcontext()):
@@ -620,6 +628,9 @@ class HotLoop(object):
         self._n_g, self._n_slab = n_g, n_slab
         self._n_tail = self.world * (2 * n_slab + 1)
         self._streams = []                  # side streams of the micro-batch loop (DorPatch(streams=...) > 1)
+        if dev.type == "cuda":              # packed weights of the frozen convolutions: built here, on the step's own stream,
+            from . import libconv           # not lazily by whichever side stream's micro-batch asks first
+            libconv.prepack(self.net)
         self._comm = torch.zeros((n_g + self._n_tail + 3 * B,), dtype=torch.float32, device=dev)
         self.g_adv = self._comm[:n_g].view(B, 3, H, W)
         self._tail = self._comm[n_g:n_g + self._n_tail].view(self.world, 2 * n_slab + 1)

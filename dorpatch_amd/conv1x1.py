@@ -328,6 +328,10 @@ def _pick(direction, t, w4d, x):
             _from_table(direction, C, O, HW, t.is_cuda, t.shape[0])
     elif MODE == "table":
         algo = _from_table(direction, C, O, HW, t.is_cuda, t.shape[0])
+        if algo == "mfma":      # the table knows shapes, not sizes: a micro-batch beyond the kernel's 32-bit offsets takes
+            from . import ops   # the library route of the same table instead of failing in DP_REQUIRE
+            if not ops.conv1x1_supported(t, w4d if direction == "fwd" else w4d.transpose(0, 1)):
+                algo = _from_table(direction, C, O, HW, False, t.shape[0])
     else:
         key = (direction, t.shape[0], C, O, HW)
         algo = _choice.get(key)

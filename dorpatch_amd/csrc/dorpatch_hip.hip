@@ -36,8 +36,8 @@ int g_aff_samples_per_block = 0;   // DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK (tools/k
 int g_update_variant = 0;          // DP_DEBUG_UPDATE_VARIANT
 int g_apply_order = 0;             // DP_DEBUG_APPLY_ORDER
 int g_aff_gather = 0;              // DP_DEBUG_AFFINE_GATHER
-int g_conv1x1_variant = 0;         // DP_DEBUG_CONV1X1_VARIANT: bits 0-1 workgroup map, bit 2 non-temporal stores, bit 3 LDS staging in one lump
-int g_conv3x3_variant = 0;         // DP_DEBUG_CONV3X3_VARIANT: 0 per-side default, 1 k_conv3x3_mfma wherever it applies, 2 k_conv3x3_flat everywhere
+int g_conv1x1_variant = 0;         // DP_DEBUG_CONV1X1_VARIANT: bits 0-1 workgroup map, bit 2 non-temporal stores, bit 3 LDS staging in one lump, bits 4-6 forced pixel tile
+int g_conv3x3_variant = 0;         // DP_DEBUG_CONV3X3_VARIANT: bits 0-1: 0 per-side default, 1 k_conv3x3_mfma wherever it applies, 2 k_conv3x3_flat everywhere; bits 4-6 forced pixel tile
 
 // Register-allocation hint: the compiler must forget what it knows about a lane-private value (so that it re-derives
 // addresses / predicates from it instead of keeping dozens of them alive).  No semantics; empty in the host emulation.
@@ -3381,14 +3381,20 @@ constexpr int kCv2WtFloats = kCv2Steps * 2 * kCvO;      // 1152 floats of packed
 constexpr int kCv2WtF4 = kCv2WtFloats / 4;              // 288 float4
 constexpr int kCv2WtIt = (kCv2WtF4 + kBlock - 1) / kBlock;   // 2 per thread; the LDS region is padded to 2 x kBlock float4
 
-template <int SO>
+// NQ (round 6): pixel fragments per wave — the tile is 64 NQ OUTPUT pixels (7: the round-5 tile of 448, which starts at a row
+// start on all three sides; 2 / 1: 128 / 64 pixels for the batches at which 448-pixel tiles leave the chip idle — 512 -> 512
+// @14 -> 7 at 64 samples: 7 tiles x 8 channel groups = 56 workgroups, 0.58 ms for 14.8 GFLOP).  Same k-walk, same bits.
+template <int SO, int NQ = 7>
 struct Cv2Geom {
+  static constexpr int PIX = 64 * NQ;                                      // output pixels per workgroup
   static constexpr int SI = 2 * SO;                                        // input side
   static constexpr int VW = (SI % 4 == 0) ? 4 : 2;                         // floats per staging load
   static constexpr int X0 = 2;                                             // LDS column of output column 0 (even: aligned f2)
   static constexpr int PITCH = ((X0 + SO + 1) / 2) * 2;                    // 30 / 16 / 10
   // output rows of a tile (448 / SO) + one zero row per image boundary it can cross + the row above
-  static constexpr int ROWS = SO == 28 ? 18 : SO == 14 ? 36 : 75;
+  // (a tile that may start anywhere: the row above + the rows PIX pixels can touch + one zero row per image boundary crossed)
+  static constexpr int ROWS = NQ == 7 ? (SO == 28 ? 18 : SO == 14 ? 36 : 75)
+                                      : 1 + (SO + PIX - 2) / SO + 1 + (SO * SO + PIX - 2) / (SO * SO);
   static constexpr int CHS = ROWS * 4 * PITCH;                             // floats per channel
   static constexpr int IN = kCv2Ch * CHS;
   static constexpr int BUF = IN + kCv2WtIt * kBlock * 4;
@@ -3397,17 +3403,17 @@ struct Cv2Geom {
   static_assert(IT <= 16 && IN % 4 == 0, "item schedule / float4 alignment of the weights");
 };
 
-template <int SO, bool FOLD>
-__global__ __launch_bounds__(kBlock, 2) void k_conv3x3s2_mfma(const float *__restrict__ x, const float *__restrict__ wt,
+template <int SO, bool FOLD, int NQ = 7>
+__global__ __launch_bounds__(kBlock, (NQ >= 6 ? 2 : 4)) void k_conv3x3s2_mfma(const float *__restrict__ x, const float *__restrict__ wt,
                                                               float *__restrict__ y, int N, int C, int O,
                                                               const float *__restrict__ ab) {
-  typedef Cv2Geom<SO> G;
+  typedef Cv2Geom<SO, NQ> G;
   typedef typename CvVec<G::VW>::T vec_t;
   __shared__ __attribute__((aligned(16))) float lds[2 * G::BUF];
   constexpr int HW = SO * SO, SI = G::SI;
   const int NCH = C / kCv2Ch;
   const int total = N * HW;                                  // < 2^31 (checked by the launcher)
-  const int g0 = blockIdx.x * kCvPix;                        // first OUTPUT pixel of the tile (batch-linear)
+  const int g0 = blockIdx.x * G::PIX;                        // first OUTPUT pixel of the tile (batch-linear)
   const int n0 = g0 / HW, h0 = (g0 - n0 * HW) / SO;
   const int vr0 = n0 * (SO + 1) + h0 - 1;                    // virtual row of LDS row 0 (the row above the tile)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -3494,44 +3500,44 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3s2_mfma(const float *__res
   // lane bases: A = weights [tap][half][oc]; B = sub-row 0, column X0 + w of the lane's pixel, channel parity = half.
   // A pixel past the end of the batch (last tile only) reads the tile's first pixel and is never stored.
   const int abase = G::IN + half * kCvO + ocf * 32 + l32;
-  int boff[7];
+  int boff[NQ];
 #pragma unroll
-  for (int q = 0; q < 7; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     int g = g0 + (pf0 + 2 * q) * 32 + l32;
     if (g >= total) g = g0;
     const int n = g / HW, p = g - n * HW;
     const int h = p / SO, w = p - h * SO;
     boff[q] = half * G::CHS + (n * (SO + 1) + h - vr0) * 4 * G::PITCH + G::X0 + w;
   }
-  f16v acc[7];
+  f16v acc[NQ];
 #pragma unroll
-  for (int q = 0; q < 7; ++q)
+  for (int q = 0; q < NQ; ++q)
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
 
-  auto operands = [&](const float *cur, int t, float &a, float (&bv)[7]) {
+  auto operands = [&](const float *cur, int t, float &a, float (&bv)[NQ]) {
     const int kh = t / 3, kw = t - 3 * kh;
     const int koff = (2 * (kh - 1) + (kw != 1 ? 1 : 0)) * G::PITCH - (kw == 0 ? 1 : 0);
     a = cur[abase + t * 2 * kCvO];
 #pragma unroll
-    for (int q = 0; q < 7; ++q) bv[q] = cur[boff[q] + koff];
+    for (int q = 0; q < NQ; ++q) bv[q] = cur[boff[q] + koff];
   };
 
   fetch(0);
   stash(0);
   fetch(NCH > 1 ? 1 : 0);
   DP_BARRIER_LDS();
-  float an, bn[7];                     // step 0 of the next chunk, requested behind the chunk's barrier
+  float an, bn[NQ];                    // step 0 of the next chunk, requested behind the chunk's barrier
   operands(lds, 0, an, bn);
   const int last = NCH - 1;
   for (int chunk = 0; chunk < NCH; ++chunk) {
     const float *cur = lds + (chunk & 1) * G::BUF;
     const int nb = (chunk + 1) & 1;
     const int c2 = chunk + 2 < NCH ? chunk + 2 : last;    // past the end of K the staging repeats the last chunk (branch-free)
-    float a[2], b[2][7];
+    float a[2], b[2][NQ];
     a[0] = an;
 #pragma unroll
-    for (int q = 0; q < 7; ++q) b[0][q] = bn[q];
+    for (int q = 0; q < NQ; ++q) b[0][q] = bn[q];
 #pragma unroll
     for (int t = 0; t < kCv2Steps; ++t) {
       if (t + 1 < kCv2Steps) {
@@ -3543,7 +3549,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3s2_mfma(const float *__res
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t & 1], b[t & 1][q], acc[q], 0, 0, 0);
+      for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t & 1], b[t & 1][q], acc[q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (t + 1 < kCv2Steps) {
         // after MFMA group t (0..7): slot i of the chunk's IT + WIT staging items (the activation items, then the weights) goes
@@ -3569,7 +3575,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3s2_mfma(const float *__res
 
   const int oc0 = blockIdx.y * kCvO + ocf * 32 + 4 * half;
 #pragma unroll
-  for (int q = 0; q < 7; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     const int g = g0 + (pf0 + 2 * q) * 32 + l32;
     if (g >= total) continue;
     const int n = g / HW, p = g - n * HW;
@@ -3606,14 +3612,25 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3s2_mfma(const float *__res
 // Workgroup ids are decoded XCD-aware (block b runs on XCD b % 8): the O / 64 channel groups of one pixel tile are
 // consecutive workgroups of ONE XCD, so a tile of x is fetched from HBM once and re-read from that XCD's L2.
 constexpr int kC1O = 64;                               // output channels per workgroup
-constexpr int kC1Pix = 448;                            // pixels per workgroup (14 fragments)
+constexpr int kC1Pix = 448;                            // pixels per workgroup of the full-size tile (14 fragments)
 constexpr int kC1Ch = 16;                              // input channels per K-chunk
 constexpr int kC1Steps = kC1Ch / 2;                    // 8 MFMA k-steps per chunk
 constexpr int kC1Wt = kC1Ch * kC1O;                    // 1024 floats of packed weights per (oc group, chunk): one f4 per thread
-constexpr int kC1In = kC1Ch * kC1Pix;                  // 7168 floats of activations per chunk
-constexpr int kC1Buf = kC1In + kC1Wt;                  // 32 KB
-constexpr int kC1It = kC1In / 4 / kBlock;              // 7 staging float4 per thread and chunk
-static_assert(kC1Wt == 4 * kBlock && kC1It * 4 * kBlock == kC1In, "one weight float4 / seven activation float4 per thread");
+static_assert(kC1Wt == 4 * kBlock, "one weight float4 per thread");
+// Round 6: the pixel tile is a template parameter.  A wave holds NQ fragments of 32 pixels (NQ
+// accumulators), the workgroup 64 NQ pixels: 448 (NQ = 7, the round-5 kernel), 256, 128 or 64.  The k-walk of an output
+// element — channels ascending, one fmaf chain — does not depend on the tile, so every tile size gives THE SAME BITS;
+// the launcher picks the largest tile that still fills the chip (64 samples on a 14 x 14 plane are 28 tiles of 448 pixels:
+// 112 workgroups for 512 slots at O = 256).  A chunk's staging is NQ float4 items per thread (one per pixel fragment).
+template <int NQ>
+struct C1Geom {
+  static constexpr int PIX = 64 * NQ;                  // pixels per workgroup
+  static constexpr int IN = kC1Ch * PIX;               // floats of activations per chunk
+  static constexpr int BUF = IN + kC1Wt;               // one LDS buffer (NQ = 7: 32 KB)
+  static constexpr int IT = NQ;                        // staging float4 per thread and chunk
+  static constexpr int MW = NQ >= 6 ? 2 : NQ >= 3 ? 3 : 4;     // workgroups per CU the register budget is set for
+  static_assert(IT * 4 * kBlock == IN, "NQ activation float4 per thread");
+};
 
 struct C1Args {
   const float *x, *wt;
@@ -3628,8 +3645,10 @@ struct C1Args {
   int nt;               // non-temporal result stores (A/B knob)
 };
 
-template <int FHW, bool FOLD, bool RES, bool SPREAD>
-__global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
+template <int NQ, int FHW, bool FOLD, bool RES, bool SPREAD>
+__global__ __launch_bounds__(kBlock, C1Geom<NQ>::MW) void k_conv1x1_mfma(C1Args A) {
+  typedef C1Geom<NQ> G;
+  constexpr int kC1Pix = G::PIX, kC1In = G::IN, kC1Buf = G::BUF, kC1It = G::IT;      // (shadow the full-size tile's constant)
   __shared__ __attribute__((aligned(16))) float lds[2 * kC1Buf];
   constexpr bool FLAT = FHW != 0;
   constexpr int FD = FLAT ? FHW : 1;                         // divisor of the flat-mode decodes (dead code in row mode)
@@ -3719,9 +3738,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
   // lane bases: A = weights [channel][oc]; B = the lane's pixel of each of its 7 fragments, channel parity = half.
   // Lanes without a pixel (past the end of the batch / of the tile's images) read a valid LDS word and never store.
   const int abase = kC1In + half * kC1O + ocf * 32 + l32;
-  int boff[7];
+  int boff[NQ];
 #pragma unroll
-  for (int q = 0; q < 7; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     const int gl = (pf0 + 2 * q) * 32 + l32;
     if (!FLAT) {
       boff[q] = half * kC1Pix + gl;
@@ -3731,9 +3750,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
       boff[q] = s * (kC1Ch * FHW) + half * FHW + p;
     }
   }
-  f16v acc[7];
+  f16v acc[NQ];
 #pragma unroll
-  for (int q = 0; q < 7; ++q)
+  for (int q = 0; q < NQ; ++q)
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
 
@@ -3756,12 +3775,12 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
   stash(0);
   fetch(NCH > 1 ? 1 : 0);
   DP_BARRIER_LDS();
-  auto operands = [&](const float *cur, int t, float &a, float (&bv)[7]) {
+  auto operands = [&](const float *cur, int t, float &a, float (&bv)[NQ]) {
     a = cur[abase + t * 2 * kC1O];
 #pragma unroll
-    for (int q = 0; q < 7; ++q) bv[q] = cur[boff[q] + t * 2 * CHS];
+    for (int q = 0; q < NQ; ++q) bv[q] = cur[boff[q] + t * 2 * CHS];
   };
-  float a0, b0[7], a1, b1[7];
+  float a0, b0[NQ], a1, b1[NQ];
   operands(lds, 0, a0, b0);
   // The loop body is BRANCH-FREE: past the end of K the staging simply repeats the last chunk (loads of valid memory, stores
   // into the LDS buffer nobody reads any more).  With `if (chunk + 2 < NCH)` around the loads hipcc's wait-count pass merged
@@ -3773,6 +3792,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
     const int nb = (chunk + 1) & 1;
     const int c2 = chunk + 2 < NCH ? chunk + 2 : last;
     auto piece = [&](int g) {            // after MFMA group g (0..6): item g of chunk c + 1 to LDS, item g of chunk c + 2 requested
+      if (g >= NQ) return;
       stash_item(nb, g);
       if (g == 0) stash_w(nb);
       fetch_item(c2, g);
@@ -3783,7 +3803,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
       operands(cur, t + 1, a1, b1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[q], acc[q], 0, 0, 0);
+      for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[q], acc[q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (SPREAD) {
         piece(t);
@@ -3799,7 +3819,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[q], acc[q], 0, 0, 0);
+      for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[q], acc[q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (SPREAD && t + 2 < kC1Steps) piece(t + 1);
     }
@@ -3832,9 +3852,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
     for (int v = 0; v < 16; ++v) r[0][v] = A.res[(o_next < 0 ? 0 : o_next) + (size_t)((v & 3) + 8 * (v >> 2)) * HW];
   }
 #pragma unroll
-  for (int q = 0; q < 7; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     const long o = o_next;
-    if (q + 1 < 7) {
+    if (q + 1 < NQ) {
       o_next = out_offset(q + 1);
       if (RES) {
 #pragma unroll
@@ -3858,16 +3878,64 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv1x1_mfma(C1Args A) {
   }
 }
 
+// Which pixel tile runs a problem (round 6).  Every tile gives the same bits, so this is a pure scheduling decision.
+// Model, fitted to the measured sweeps (profiles/r06b_kbench_conv1x1_tiles_n{32..512}.txt, r06c_kbench_conv3x3_tiles_*):
+// a workgroup's time is proportional to its NQ MFMAs per k-step (whatever its idle lanes), the 256 CUs share the
+// workgroups evenly, so   cost(NQ) = ceil(workgroups(NQ) / 256) * NQ * penalty(NQ)   — e.g. 1024 -> 256 @14x14, N = 64:
+// 112 workgroups of 448 pixels cost 1 * 7, 392 of 128 pixels 2 * 2 (measured 55 vs 96 TFLOP/s); 2048 -> 512 @7x7,
+// N = 512: 456 x 7 -> 14 against 824 x 4 -> 16 (116 vs 103).  The penalties are what is left at large grids: the 448-pixel
+// tile is 4 - 8 % ahead for plain / residual launches (fewer barriers and weight re-reads per flop).  Launches with the
+// GroupNorm fold in the staging run FASTER stand-alone with 64-pixel tiles (8 workgroups per CU hide the apply's VALU + the
+// extra request: 1024 -> 512 120 vs 108, 512 -> 128 116 vs 105 TFLOP/s at N = 512; the one-stream step 375.9 -> 373.1 ms) —
+// but 8 workgroups of 4 waves are ALL 32 wave slots of a CU, so nothing of the step's other stream runs beside them: the
+// two-stream step (the product's) went 357.8 -> 363.5 ms (profiles/r06f_bench_*.json, 3 interleaved runs each).  At large
+// grids the fold therefore keeps the 448-pixel tile as well; ties go to the larger tile.
+static int pick_tile(const int *cand, const float *pen, int n, const long *wgs) {
+  int best = cand[0];
+  float best_cost = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const float cost = (float)((wgs[i] + 255) / 256) * (float)cand[i] * pen[i];
+    if (i == 0 || cost < best_cost * 0.999f) best = cand[i], best_cost = cost;
+  }
+  return best;
+}
+// DP_DEBUG_CONV1X1_VARIANT bits 4-6 force a tile for A/B runs (1: 448, 2: 256, 3: 128, 4: 64).
+static long conv1x1_tiles(long N, int HW, bool flat, int nq) {
+  const int pix = 64 * nq;
+  return flat ? (N + pix / HW - 1) / (pix / HW) : (N * HW + pix - 1) / pix;
+}
+static int conv1x1_tile_nq(long N, int C, int HW, int og, bool flat, bool fold, bool res) {
+  const int force = (g_conv1x1_variant >> 4) & 7;
+  if (force) return force == 1 ? 7 : force == 2 ? 4 : force == 3 ? 2 : 1;
+  static const int cand[4] = {7, 4, 2, 1};
+  static const float pen_plain[4] = {1.00f, 1.07f, 1.08f, 1.08f}, pen_fold[4] = {1.00f, 1.03f, 1.04f, 1.03f},
+                     pen_res[4] = {1.00f, 1.07f, 1.07f, 1.04f}, pen_flat[4] = {1.00f, 1.00f, 1.04f, 1.06f};
+  long wgs[4];
+  for (int i = 0; i < 4; ++i) wgs[i] = conv1x1_tiles(N, HW, flat, cand[i]) * og;
+  if (!flat && C <= 64 && og == 1 && wgs[0] < 1024) return 1;   // 64 -> 64 on a small grid: four chunks of K against a whole epilogue
+  return pick_tile(cand, flat ? pen_flat : fold ? pen_fold : res ? pen_res : pen_plain, 4, wgs);
+}
+
 int launch_conv1x1(C1Args A, bool flat, hipStream_t st) {
+  const int nq = conv1x1_tile_nq(A.N, A.C, A.HW, A.og, flat, A.ab != nullptr, A.res != nullptr);
+  A.spt = flat ? 64 * nq / A.HW : 0;
+  const long tiles = conv1x1_tiles(A.N, A.HW, flat, nq);
+  if ((tiles + 7) / 8 * 8 * A.og >= (1L << 31)) return hipErrorInvalidValue;
+  A.tiles = (int)tiles;
   const dim3 grid((unsigned)(cdiv(A.tiles, 8) * 8 * A.og)), block(kBlock);
   const bool fold = A.ab != nullptr, res = A.res != nullptr;
   A.map = g_conv1x1_variant & 3;
   A.nt = (g_conv1x1_variant >> 2) & 1;
   const bool spread = !(g_conv1x1_variant & 8);
+#define DP_LAUNCH_C1Q(NQ_, FHW_, FOLD_, RES_) hipLaunchKernelGGL((k_conv1x1_mfma<NQ_, FHW_, FOLD_, RES_, true>), grid, block, 0, st, A)
 #define DP_LAUNCH_C1(FHW_, FOLD_, RES_)                                                                      \
   do {                                                                                                       \
-    if (spread) hipLaunchKernelGGL((k_conv1x1_mfma<FHW_, FOLD_, RES_, true>), grid, block, 0, st, A);        \
-    else hipLaunchKernelGGL((k_conv1x1_mfma<FHW_, FOLD_, RES_, false>), grid, block, 0, st, A);              \
+    if (nq == 7) {                                                                                           \
+      if (spread) DP_LAUNCH_C1Q(7, FHW_, FOLD_, RES_);                                                       \
+      else hipLaunchKernelGGL((k_conv1x1_mfma<7, FHW_, FOLD_, RES_, false>), grid, block, 0, st, A);         \
+    } else if (nq == 4) DP_LAUNCH_C1Q(4, FHW_, FOLD_, RES_);                                                 \
+    else if (nq == 2) DP_LAUNCH_C1Q(2, FHW_, FOLD_, RES_);                                                   \
+    else DP_LAUNCH_C1Q(1, FHW_, FOLD_, RES_);                                                                \
   } while (0)
   if (flat) {
     if (res) DP_LAUNCH_C1(49, false, true);
@@ -3880,6 +3948,7 @@ int launch_conv1x1(C1Args A, bool flat, hipStream_t st) {
     else DP_LAUNCH_C1(0, false, false);
   }
 #undef DP_LAUNCH_C1
+#undef DP_LAUNCH_C1Q
   return launch_status();
 }
 
@@ -3916,15 +3985,18 @@ struct TapsS2 {                  // class (PR, PC) of the stride-2 input gradien
   static constexpr int dw(int t) { return t % (1 + PC); }
 };
 
-template <int S_, int T_, int CH_, int BACK_, int FWD_>
+// NQ_ (round 6, VERDICT r5 items 1 + 6): pixel fragments per wave — the workgroup's tile is 64 NQ pixels (7: the round-5
+// tile of 448; 4 / 2 / 1: 256 / 128 / 64 pixels, for batches whose planes give too few 448-pixel tiles to fill 512 slots).
+// The k-walk of an output element does not depend on it: every tile gives the same bits.
+template <int S_, int T_, int CH_, int BACK_, int FWD_, int NQ_ = 7>
 struct CfGeom {
-  static constexpr int S = S_, HW = S_ * S_, T = T_, CH = CH_;
+  static constexpr int S = S_, HW = S_ * S_, T = T_, CH = CH_, NQ = NQ_, PIX = 64 * NQ_;
   static constexpr bool FLAT = (HW % 4) != 0;                              // 7 x 7: whole-image tiles
   static constexpr int KS = CH / 2 * T;                                    // MFMA k-steps per chunk
   static constexpr int BACK = BACK_;                                       // words a tap reaches back / forward from its pixel
   static constexpr int HL = FLAT ? 0 : (BACK_ + 3) / 4 * 4, HR = FLAT ? 0 : (FWD_ + 3) / 4 * 4;
-  static constexpr int RL = HL + kCvPix + HR;                              // row mode: floats per channel
-  static constexpr int SPT = FLAT ? kCvPix / HW : 1;                       // flat mode: images per tile
+  static constexpr int RL = HL + PIX + HR;                                 // row mode: floats per channel
+  static constexpr int SPT = FLAT ? PIX / HW : 1;                          // flat mode: images per tile
   static constexpr int CHS = FLAT ? HW : RL;                               // LDS stride between channels
   static constexpr int NV = FLAT ? SPT * CH * HW / 4 : CH * RL / 4;        // float4 items per chunk
   static constexpr int IT = (NV + kBlock - 1) / kBlock;
@@ -3950,11 +4022,11 @@ struct CfArgs {
 // MODE 0: y (N, O, S, S) plain;  MODE 1: y (N, O, 2S, 2S), the tile's pixel (a, b) goes to (2a + PR, 2b + PC)
 template <class G, class TAPS, bool FOLD, int MODE, int PR, int PC>
 __device__ __forceinline__ void cf_body(float *lds, const CfArgs &A, const float *wtg, int tile, int og) {
-  constexpr int S = G::S, HW = G::HW, KS = G::KS, T = G::T;
+  constexpr int S = G::S, HW = G::HW, KS = G::KS, T = G::T, NQ = G::NQ;
   static_assert(!(FOLD && G::FLAT), "the GroupNorm fold needs H*W % 4 == 0");
   const int NCH = A.C / G::CH;
   const int total = A.N * HW;                                  // < 2^31 (checked by the launcher)
-  const int g0 = G::FLAT ? 0 : tile * kCvPix;                  // row mode: first pixel of the tile (batch-linear)
+  const int g0 = G::FLAT ? 0 : tile * G::PIX;                  // row mode: first pixel of the tile (batch-linear)
   const int n0 = G::FLAT ? tile * G::SPT : 0;                  // flat mode: first image of the tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l32 = lane & 31;
@@ -4027,10 +4099,10 @@ __device__ __forceinline__ void cf_body(float *lds, const CfArgs &A, const float
   // parity = half.  Lanes without a pixel (past the end of the batch / of the tile's images) read valid LDS and never store.
   // Masks: the lane's pixel is not in the first / last row / column of its plane.
   const int abase = G::WOFF + half * kCvO + ocf * 32 + l32;
-  int boff[7];
-  bool mT[7], mB[7], mL[7], mR[7];
+  int boff[NQ];
+  bool mT[NQ], mB[NQ], mL[NQ], mR[NQ];
 #pragma unroll
-  for (int q = 0; q < 7; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     const int gl = (pf0 + 2 * q) * 32 + l32;
     int p;
     if (!G::FLAT) {
@@ -4047,25 +4119,25 @@ __device__ __forceinline__ void cf_body(float *lds, const CfArgs &A, const float
     const int a = p / S, b = p - a * S;
     mT[q] = a > 0, mB[q] = a < S - 1, mL[q] = b > 0, mR[q] = b < S - 1;
   }
-  f16v acc[7];
+  f16v acc[NQ];
 #pragma unroll
-  for (int q = 0; q < 7; ++q)
+  for (int q = 0; q < NQ; ++q)
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
 
-  auto operands = [&](const float *cur, int t, float &a, float (&bv)[7]) {
+  auto operands = [&](const float *cur, int t, float &a, float (&bv)[NQ]) {
     const int cp = t / T, tap = t - cp * T;
     const int koff = cp * 2 * G::CHS + G::BACK + TAPS::dh(tap) * S + TAPS::dw(tap);
     a = cur[abase + t * 2 * kCvO];
 #pragma unroll
-    for (int q = 0; q < 7; ++q) bv[q] = cur[boff[q] + koff];
+    for (int q = 0; q < NQ; ++q) bv[q] = cur[boff[q] + koff];
   };
-  auto masked = [&](int t, float (&bv)[7]) {
+  auto masked = [&](int t, float (&bv)[NQ]) {
     const int tap = t % T;
     const int dh = TAPS::dh(tap), dw = TAPS::dw(tap);
     if (dh == 0 && dw == 0) return;
 #pragma unroll
-    for (int q = 0; q < 7; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       bool m = true;
       if (dh < 0) m = m && mT[q];
       if (dh > 0) m = m && mB[q];
@@ -4090,17 +4162,17 @@ __device__ __forceinline__ void cf_body(float *lds, const CfArgs &A, const float
 #pragma unroll
   for (int k = 0; k < G::WIT; ++k) fetch_w(c1, k);
   DP_BARRIER_LDS();
-  float an, bn[7];                     // step 0 of the next chunk, requested behind the chunk's barrier
+  float an, bn[NQ];                    // step 0 of the next chunk, requested behind the chunk's barrier
   operands(buf0, 0, an, bn);
   const int last = NCH - 1;
   for (int chunk = 0; chunk < NCH; ++chunk) {
     const float *cur = (chunk & 1) ? buf1 : buf0;
     float *nxt = (chunk & 1) ? buf0 : buf1;
     const int c2 = chunk + 2 < NCH ? chunk + 2 : last;    // past the end of K the staging repeats the last chunk (branch-free)
-    float a[2], b[2][7];
+    float a[2], b[2][NQ];
     a[0] = an;
 #pragma unroll
-    for (int q = 0; q < 7; ++q) b[0][q] = bn[q];
+    for (int q = 0; q < NQ; ++q) b[0][q] = bn[q];
 #pragma unroll
     for (int t = 0; t < KS; ++t) {
       masked(t, b[t & 1]);
@@ -4113,7 +4185,7 @@ __device__ __forceinline__ void cf_body(float *lds, const CfArgs &A, const float
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t & 1], b[t & 1][q], acc[q], 0, 0, 0);
+      for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t & 1], b[t & 1][q], acc[q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (t + 1 < KS) piece(nxt, c2, t);
     }
@@ -4121,7 +4193,7 @@ __device__ __forceinline__ void cf_body(float *lds, const CfArgs &A, const float
 
   const int oc0 = og * kCvO + ocf * 32 + 4 * half;
 #pragma unroll
-  for (int q = 0; q < 7; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     const int gl = (pf0 + 2 * q) * 32 + l32;
     int n, p;
     bool ok;
@@ -4156,9 +4228,12 @@ __device__ __forceinline__ void cf_decode(int slot, int xcd, int ogs, int &tile,
   tile = tl * 8 + xcd;
 }
 
-template <int S, bool FOLD>
-__global__ __launch_bounds__(kBlock, 2) void k_conv3x3_flat(CfArgs A) {
-  typedef CfGeom<S, 9, kCvCh, S + 1, S + 1> G;
+template <int S, bool FOLD, int NQ = 7>
+__global__ __launch_bounds__(kBlock, (NQ >= 6 ? 2 : NQ >= 3 ? 3 : NQ == 2 ? 4 : 6)) void k_conv3x3_flat(CfArgs A) {
+  // the small tiles walk K in chunks of 4 channels (half a packed 8-channel chunk: [chunk][channel pair][tap][half][oc] is
+  // contiguous per channel pair, same k order, same bits): 9 KB of weights per buffer instead of 18, so that 6 - 7
+  // workgroups fit a CU's LDS instead of 3
+  typedef CfGeom<S, 9, (NQ >= 4 ? kCvCh : kCvCh / 2), S + 1, S + 1, NQ> G;
   __shared__ __attribute__((aligned(16))) float lds[G::LDS];
   int tile, og;
   cf_decode(blockIdx.x >> 3, blockIdx.x & 7, A.og, tile, og);
@@ -4588,11 +4663,11 @@ int dp_debug_set(int knob, int value) {
       g_aff_gather = value;
       return 0;
     case DP_DEBUG_CONV1X1_VARIANT:
-      DP_REQUIRE(value >= 0 && value < 16 && (value & 3) != 3);
+      DP_REQUIRE(value >= 0 && value < 128 && (value & 3) != 3 && (value >> 4) <= 4);     // bits 4-6: forced pixel tile
       g_conv1x1_variant = value;
       return 0;
     case DP_DEBUG_CONV3X3_VARIANT:
-      DP_REQUIRE(value >= 0 && value <= 2);
+      DP_REQUIRE(value >= 0 && (value & 15) <= 2 && (value >> 4) <= 4 && (value >> 4) != 2);     // bits 4-6: forced pixel tile
       g_conv3x3_variant = value;
       return 0;
     default:
@@ -4859,6 +4934,28 @@ static bool conv3x3_side_rows(int H) { return H == 56 || H == 28 || H == 14 || H
 static bool conv3x3_side_flat(int H) { return H == 56 || H == 28 || H == 14 || H == 7 || H == 96 || H == 48 || H == 24 || H == 12; }
 static bool conv3x3_flat_default(int H) { return !conv3x3_side_rows(H) || H == 7; }   // 7 x 7: 1.054 vs 1.169 ms at N = 512 (r05j)
 
+// Pixel tile of k_conv3x3_flat (round 6): 448 (the round-5 tile; on the sides k_conv3x3_mfma takes, that kernel unless the
+// flat one measured faster), 128 or 64 pixels — the 7 x 7 planes: 9 / 2 / 1 whole images.  Same bits from every tile.
+// DP_DEBUG_CONV3X3_VARIANT bits 4-6 force one (1: 448, 3: 128, 4: 64); the rule is the measured one (profiles/r06c_*).
+static long conv3x3_tiles(long N, int H, int nq) {
+  const int pix = 64 * nq;
+  return H == 7 ? (N + pix / 49 - 1) / (pix / 49) : (N * H * H + pix - 1) / pix;
+}
+static int conv3x3_tile_nq(long N, int H, int og, bool fold) {
+  if (H == 56 || H == 96 || H == 48) return 7;       // big planes: plenty of 448-pixel tiles at any batch, halo >= a small tile
+  const int force = (g_conv3x3_variant >> 4) & 7;
+  if (force) return force == 1 ? 7 : force == 3 ? 2 : 1;
+  if (g_conv3x3_variant & 3) return 7;               // the kernel-choice knob reproduces the round-5 launches
+  (void)fold;
+  // pick_tile's model (k_conv1x1_mfma's launcher): cost = ceil(workgroups / 256) * NQ * penalty; the 64-pixel tile pays 8 %
+  // for its halo and weight re-reads (profiles/r06c_kbench_conv3x3_tiles_n512.txt), the 128-pixel one nothing measurable
+  static const int cand[3] = {7, 2, 1};
+  static const float pen[3] = {1.00f, 1.00f, 1.08f};
+  long wgs[3];
+  for (int i = 0; i < 3; ++i) wgs[i] = conv3x3_tiles(N, H, cand[i]) * og;
+  return pick_tile(cand, pen, 3, wgs);
+}
+
 static int conv3x3_launch(const float *x, const float *wt, const float *ab, int N, int C, int O, int H, int W, float *y,
                           dp_stream_t stream) {
   DP_REQUIRE(x && wt && y && aligned16(x) && aligned16(wt) && aligned16(y));
@@ -4867,33 +4964,45 @@ static int conv3x3_launch(const float *x, const float *wt, const float *ab, int 
   DP_REQUIRE(!ab || (H != 7 && (reinterpret_cast<uintptr_t>(ab) & 7u) == 0));   // no fold on the 7 x 7 planes (rows are not 16-byte multiples)
   DP_REQUIRE((long)N * H * W + kCvPix < (1L << 31));      // 32-bit pixel arithmetic in the kernel
   hipStream_t st = as_stream(stream);
-  const bool flat = g_conv3x3_variant == 2 ? conv3x3_side_flat(H)
-                    : g_conv3x3_variant == 1 ? !conv3x3_side_rows(H) : conv3x3_flat_default(H);
+  const int kvar = g_conv3x3_variant & 3;
+  const int nq = conv3x3_tile_nq(N, H, O / kCvO, ab != nullptr);
+  const bool flat = nq != 7 || (kvar == 2 ? conv3x3_side_flat(H) : kvar == 1 ? !conv3x3_side_rows(H) : conv3x3_flat_default(H));
   if (flat) {
     DP_REQUIRE((long)N * C * H * W < (1L << 31));         // 32-bit element offsets in the kernel
     CfArgs A;
     A.x = x; A.wt = wt; A.ab = ab; A.y = y;
     A.N = N; A.C = C; A.O = O; A.og = O / kCvO;
-    const long tiles = H == 7 ? ((long)N + 8) / 9 : ((long)N * H * W + kCvPix - 1) / kCvPix;
+    const long tiles = conv3x3_tiles(N, H, nq);
     DP_REQUIRE((tiles + 7) / 8 * 8 * A.og < (1L << 31));
     A.tiles = (int)tiles;
     const dim3 grid((unsigned)((tiles + 7) / 8 * 8 * A.og)), block(kBlock);
+#define DP_LAUNCH_CFQ(S_, NQ_)                                                                 \
+  do {                                                                                         \
+    if (ab) hipLaunchKernelGGL((k_conv3x3_flat<S_, true, NQ_>), grid, block, 0, st, A);        \
+    else hipLaunchKernelGGL((k_conv3x3_flat<S_, false, NQ_>), grid, block, 0, st, A);          \
+  } while (0)
 #define DP_LAUNCH_CF(S_)                                                                       \
   do {                                                                                         \
-    if (ab) hipLaunchKernelGGL((k_conv3x3_flat<S_, true>), grid, block, 0, st, A);             \
-    else hipLaunchKernelGGL((k_conv3x3_flat<S_, false>), grid, block, 0, st, A);               \
+    if (nq == 7) DP_LAUNCH_CFQ(S_, 7);                                                         \
+    else if (nq == 2) DP_LAUNCH_CFQ(S_, 2);                                                    \
+    else DP_LAUNCH_CFQ(S_, 1);                                                                 \
   } while (0)
     switch (H) {
-      case 7: hipLaunchKernelGGL((k_conv3x3_flat<7, false>), grid, block, 0, st, A); break;
+      case 7:
+        if (nq == 7) hipLaunchKernelGGL((k_conv3x3_flat<7, false, 7>), grid, block, 0, st, A);
+        else if (nq == 2) hipLaunchKernelGGL((k_conv3x3_flat<7, false, 2>), grid, block, 0, st, A);
+        else hipLaunchKernelGGL((k_conv3x3_flat<7, false, 1>), grid, block, 0, st, A);
+        break;
       case 14: DP_LAUNCH_CF(14); break;
       case 28: DP_LAUNCH_CF(28); break;
-      case 56: DP_LAUNCH_CF(56); break;
+      case 56: DP_LAUNCH_CFQ(56, 7); break;
       case 12: DP_LAUNCH_CF(12); break;
       case 24: DP_LAUNCH_CF(24); break;
-      case 48: DP_LAUNCH_CF(48); break;
-      default: DP_LAUNCH_CF(96); break;
+      case 48: DP_LAUNCH_CFQ(48, 7); break;
+      default: DP_LAUNCH_CFQ(96, 7); break;
     }
 #undef DP_LAUNCH_CF
+#undef DP_LAUNCH_CFQ
     return launch_status();
   }
   const long tiles = ((long)N * H * W + kCvPix - 1) / kCvPix;
@@ -4929,18 +5038,36 @@ int dp_conv3x3s2_fwd(const float *x, const float *wt, const float *ab, int N, in
   DP_REQUIRE(!ab || (reinterpret_cast<uintptr_t>(ab) & 7u) == 0);
   DP_REQUIRE((long)N * C * H * W < (1L << 31));                       // 32-bit element offsets in the kernel
   const int SO = H / 2;
-  const long tiles = ((long)N * SO * SO + kCvPix - 1) / kCvPix;
+  // pixel tile by pick_tile's model (k_conv1x1_mfma's launcher); DP_DEBUG_CONV3X3_VARIANT bits 4-6 force one
+  int nq;
+  {
+    static const int cand[3] = {7, 2, 1};
+    static const float pen[3] = {1.00f, 1.03f, 1.10f};
+    long wgs[3];
+    for (int i = 0; i < 3; ++i) wgs[i] = (((long)N * SO * SO + 64 * cand[i] - 1) / (64 * cand[i])) * (O / kCvO);
+    const int force = (g_conv3x3_variant >> 4) & 7;
+    nq = force ? (force == 1 ? 7 : force == 3 ? 2 : 1) : (g_conv3x3_variant & 3) ? 7 : pick_tile(cand, pen, 3, wgs);
+  }
+  const long tiles = ((long)N * SO * SO + 64 * nq - 1) / (64 * nq);
+  DP_REQUIRE(tiles < (1L << 31));
   const dim3 grid((unsigned)tiles, O / kCvO), block(kBlock);
   hipStream_t st = as_stream(stream);
-#define DP_LAUNCH_CV2(SO_)                                                                                        \
-  do {                                                                                                            \
-    if (ab) hipLaunchKernelGGL((k_conv3x3s2_mfma<SO_, true>), grid, block, 0, st, x, wt, y, N, C, O, ab);        \
-    else hipLaunchKernelGGL((k_conv3x3s2_mfma<SO_, false>), grid, block, 0, st, x, wt, y, N, C, O, ab);          \
+#define DP_LAUNCH_CV2Q(SO_, NQ_)                                                                                       \
+  do {                                                                                                                 \
+    if (ab) hipLaunchKernelGGL((k_conv3x3s2_mfma<SO_, true, NQ_>), grid, block, 0, st, x, wt, y, N, C, O, ab);        \
+    else hipLaunchKernelGGL((k_conv3x3s2_mfma<SO_, false, NQ_>), grid, block, 0, st, x, wt, y, N, C, O, ab);          \
+  } while (0)
+#define DP_LAUNCH_CV2(SO_)                                                                                             \
+  do {                                                                                                                 \
+    if (nq == 7) DP_LAUNCH_CV2Q(SO_, 7);                                                                               \
+    else if (nq == 2) DP_LAUNCH_CV2Q(SO_, 2);                                                                          \
+    else DP_LAUNCH_CV2Q(SO_, 1);                                                                                       \
   } while (0)
   if (SO == 28) DP_LAUNCH_CV2(28);
   else if (SO == 14) DP_LAUNCH_CV2(14);
   else DP_LAUNCH_CV2(7);
 #undef DP_LAUNCH_CV2
+#undef DP_LAUNCH_CV2Q
   return launch_status();
 }
 
@@ -5008,10 +5135,8 @@ int dp_conv1x1_fwd(const float *x, const float *wt, const float *ab, const float
   A.x = x; A.wt = wt; A.ab = ab; A.res = res; A.y = y;
   A.N = N; A.C = C; A.O = O; A.HW = HW;
   A.og = O / kC1O;
-  A.spt = flat ? kC1Pix / HW : 0;
-  const long tiles = flat ? ((long)N + A.spt - 1) / A.spt : ((long)N * HW + kC1Pix - 1) / kC1Pix;
-  DP_REQUIRE((tiles + 7) / 8 * 8 * A.og < (1L << 31));
-  A.tiles = (int)tiles;
+  DP_REQUIRE((((long)N * (flat ? 64 : HW) + 63) / 64 + 7) / 8 * 8 * A.og < (1L << 31));     // the grid of the smallest tile
+  A.spt = 0, A.tiles = 0;        // set by launch_conv1x1 for the tile it picks
   return launch_conv1x1(A, flat, as_stream(stream));
 }
 

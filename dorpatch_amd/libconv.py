@@ -57,7 +57,20 @@ for _extra in filter(None, os.environ.get("DORPATCH_CONV3X3_ALSO", "").split(","
 CONV3X3S2 = os.environ.get("DORPATCH_CONV3X3S2", "on")
 if CONV3X3S2 not in ("on", "off"):
     raise ValueError("DORPATCH_CONV3X3S2 must be on or off, got %r" % CONV3X3S2)
-CONV3X3S2_MIN_BATCH = int(os.environ.get("DORPATCH_CONV3X3S2_MIN_BATCH", "64"))
+# (round 6: with the 128- / 64-pixel tiles also at 32 rows — MIOpen / own 1.51, 1.30, 1.67 there, profiles/r06e_conv3x3s2_vs_miopen.jsonl)
+CONV3X3S2_MIN_BATCH = int(os.environ.get("DORPATCH_CONV3X3S2_MIN_BATCH", "32"))
+CONV3X3S2_BWD_MIN_BATCH = int(os.environ.get("DORPATCH_CONV3X3S2_BWD_MIN_BATCH", "64"))    # at 32 rows: 1.27, 1.20, 0.66
+# Round 6: below ~192 workgroups (512 -> 512 @14 -> 7 at 64 samples: 7 tiles x 8 channel groups = 56) the kernel's 448-pixel tiles
+# leave most of the chip idle (0.58 ms for 14.8 GFLOP, profiles/r06a_kernel_stats_timed_cfg3.txt) — but MIOpen has nothing
+# better there either (its stride-2 Winograd: 0.63 ms, profiles/r06d_kernel_stats_timed_cfg3_fold.txt), so the threshold
+# stays at 0 (DORPATCH_CONV3X3S2_MIN_WG is an A/B knob); the small-batch answer is a smaller tile, not the library.
+CONV3X3S2_MIN_WG = int(os.environ.get("DORPATCH_CONV3X3S2_MIN_WG", "0"))
+
+
+def conv3x3s2_fwd_pays(x, w):
+    """dp_conv3x3s2_fwd's grid for this problem fills the chip (see CONV3X3S2_MIN_WG)."""
+    so = int(x.shape[2]) // 2
+    return (-(-int(x.shape[0]) * so * so // 448)) * (int(w.shape[0]) // 64) >= CONV3X3S2_MIN_WG
 # ... and their input gradients on dp_conv3x3s2_bwd (masked parity-class walks over the dy plane, two column classes per
 # workgroup) instead of MIOpen's NHWC implicit GEMM between batched_transpose_* kernels: "on" | "off".  Measured
 # (profiles/r05k_*): MIOpen / own at N = 512: 1.32 (128 @28 -> 56), 1.08, 1.00; at N = 128: 1.21, 1.00, 0.96; at N = 64: 1.10,
@@ -140,6 +153,46 @@ def packed1(w, transpose):
     return _packed(w, ("1x1", bool(transpose)), lambda: ops.pack_conv1x1_weights(w, transpose=transpose))
 
 
+def prepack(net):
+    """Build every packed copy a frozen convolution of ``net`` can ask for, on the CURRENT stream, before the first
+    forward.  ``_packed`` builds lazily on whatever stream is current; with micro-batches / sweep forwards round-robin on
+    side streams (DorPatch(streams=2)) the first use would sit on side stream A and the second micro-batch, on stream B,
+    would read the cached tensor with nothing ordering it after A's permute + copy.  Called by HotLoop,
+    collect_failure and PatchCleanser before they fork side streams: those wait for the current stream, so every pack is
+    complete for them.  Cheap when the packs exist (a dictionary lookup per filter)."""
+    if not isinstance(net, torch.nn.Module):
+        return 0
+    n = 0
+    for m in net.modules():
+        w = getattr(m, "weight", None)
+        if not (isinstance(m, torch.nn.Conv2d) and isinstance(w, torch.Tensor) and w.is_cuda and w.dtype == torch.float32
+                and not w.requires_grad and getattr(m, "folded", False) and m.groups == 1):
+            continue
+        k, O, C = tuple(w.shape[2:]), int(w.shape[0]), int(w.shape[1])
+        stride = tuple(m.stride)
+        if k == (1, 1):
+            if C % 16 == 0 and O % 64 == 0:
+                packed1(w, False)
+                n += 1
+            if O % 16 == 0 and C % 64 == 0:
+                packed1(w, True)
+                n += 1
+        elif k == (3, 3):
+            if C % 8 == 0 and O % 64 == 0:
+                _packed3(w, False)
+                n += 1
+            if stride == (1, 1) and O % 8 == 0 and C % 64 == 0:
+                _packed3(w, True)
+                n += 1
+            if stride == (2, 2) and O % 16 == 0 and C % 64 == 0:
+                _packed3s2b(w)
+                n += 1
+        elif k == (7, 7) and (O, C) == (64, 3):
+            _packed_stem(w)
+            n += 1
+    return n
+
+
 def report_conv3x3():
     """{"mode", "fwd": {"mfma": n, "miopen": m}, "bwd": {...}}: distinct (batch, channels, plane) problems per route."""
     out = {"mode": CONV3X3}
@@ -187,7 +240,7 @@ def conv_fwd(x, w, stride=(1, 1), padding=(0, 0)):
         return ops.conv3x3_fwd(x, _packed3(w, False))
     if w.shape[2] == 3 and tuple(stride) == (2, 2) and CONV3X3S2 == "on" and x.shape[0] >= CONV3X3S2_MIN_BATCH:
         from . import ops
-        if ops.conv3x3s2_supported(x, w, stride, padding):
+        if ops.conv3x3s2_supported(x, w, stride, padding) and conv3x3s2_fwd_pays(x, w):
             _used3.setdefault(("fwd", "mfma"), set()).add((int(x.shape[0]), int(w.shape[1]), -int(x.shape[2])))
             return ops.conv3x3s2_fwd(x, _packed3(w, False))
     if w.shape[2] == 7 and STEM_CONV == "on" and x.shape[0] >= STEM_CONV_MIN_BATCH:
@@ -206,7 +259,7 @@ def conv_bwd_data(dy, x_ref, w, stride=(1, 1), padding=(0, 0)):
     if w.shape[2] == 3 and dy.shape[2:] == x_ref.shape[2:] and _conv3x3_route("bwd", dy, w, stride, padding):
         from . import ops
         return ops.conv3x3_fwd(dy, _packed3(w, True))
-    if (w.shape[2] == 3 and tuple(stride) == (2, 2) and CONV3X3S2_BWD == "on" and dy.shape[0] >= CONV3X3S2_MIN_BATCH
+    if (w.shape[2] == 3 and tuple(stride) == (2, 2) and CONV3X3S2_BWD == "on" and dy.shape[0] >= CONV3X3S2_BWD_MIN_BATCH
             and x_ref.shape[2] == 2 * dy.shape[2] and x_ref.shape[3] == 2 * dy.shape[3]):
         from . import ops
         if ops.conv3x3s2_bwd_supported(dy, w, stride, padding):

@@ -945,7 +945,8 @@ def gn_fold_supported(x, conv_weight, groups, stride=(1, 1), padding=None):
         padding = (1, 1) if padding is None else padding
         if tuple(stride) == (2, 2):
             from . import libconv
-            return libconv.CONV3X3S2 != "off" and conv3x3s2_supported(x, conv_weight, stride, padding)
+            return (libconv.CONV3X3S2 != "off" and conv3x3s2_supported(x, conv_weight, stride, padding)
+                    and libconv.conv3x3s2_fwd_pays(x, conv_weight))
         return conv3x3_supported(x, conv_weight, stride, padding) and x.shape[2] in CONV3X3_FOLD_SIDES
     return False
 

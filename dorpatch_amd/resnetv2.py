@@ -74,10 +74,13 @@ class GroupNormAct(nn.GroupNorm):
     # residual add into the producing convolution's epilogue, wherever the hand-written MFMA kernels take the shape.
     # ``GroupNormAct.fold = False`` (or DORPATCH_GNFOLD=0) restores the round-4 graph (A/B measurements).
     fold = os.environ.get("DORPATCH_GNFOLD", "1") != "0"
-    # ... for batches of at least this many samples: the MFMA kernels work in 448-pixel x 64-channel tiles, and below ~256
-    # samples the deep layers have too few of them for 512 workgroup slots — measured (profiles/r05e_*): the folded graph is
-    # 2.6 % FASTER than the round-4 graph at 512 samples, 2.5 % slower at 128, 17 % slower at 64, 40 % slower at 32
-    fold_min_batch = int(os.environ.get("DORPATCH_GNFOLD_MIN_BATCH", "256"))
+    # ... for batches of at least this many samples.  Round 5 gated it at 256: the MFMA kernels worked in 448-pixel x 64-channel
+    # tiles only, and below ~256 samples the deep layers had too few of them for 512 workgroup slots (the folded graph 2.5 %
+    # slower than the library routes at 128 samples, 17 % at 64, 40 % at 32: profiles/r05e_*).  Round 6: the launchers pick
+    # 256- / 128- / 64-pixel tiles where that fills the chip, and the folded graph is the faster one down to 32 samples
+    # (same box, ms/step folded vs library routes: 32 samples 9.8 vs 10.4 - 11.3, 64: 14.85 vs 15.14, 128: 27.1 vs 27.4;
+    # profiles/r06d_bench_*.json, r06e_bench_cfg3_*.json)
+    fold_min_batch = int(os.environ.get("DORPATCH_GNFOLD_MIN_BATCH", "32"))
 
     def __init__(self, num_channels, num_groups=32, eps=1e-5):
         super().__init__(num_groups, num_channels, eps=eps, affine=True)
@@ -162,11 +165,19 @@ class PreActBottleneck(nn.Module):
         if not (GroupNormAct.fused and GroupNormAct.fold and x.shape[0] >= GroupNormAct.fold_min_batch
                 and conv1x1.MODE in ("table", "mfma")
                 and all(c.folded and not c.weight.requires_grad for c in convs)
-                and all(n._use_hip(x) for n in (self.norm1,))):
+                and self.norm1._use_hip(x)
+                # norm2 / norm3 see other tensors: their frozen state and group shape are checked here, their planes below
+                and all(GroupNormAct.fused and not (n.weight.requires_grad or n.bias.requires_grad)
+                        and n.num_channels % n.num_groups == 0 for n in (self.norm2, self.norm3))):
             return False
         s = self.conv2.stride[0]
         small = x[:, :, ::s, ::s]
+        # the BACKWARD runs the same kernel on the transposed weights: conv1 / conv3 need C % 64 == 0 there —
+        # a bottleneck width that is not a multiple of 64 takes forward_pair instead of failing in the backward
         return (ops.conv1x1_supported(x, self.conv1.weight)
+                and self.conv1.weight.shape[1] % 64 == 0 and self.conv1.weight.shape[0] % 16 == 0
+                and self.conv3.weight.shape[1] % 64 == 0
+                and (self.downsample is None or self.downsample.conv.weight.shape[1] % 64 == 0)
                 and small.shape[0] * self.conv3.weight.shape[0] * small.shape[2] * small.shape[3] < 2 ** 31
                 and self.conv3.weight.shape[1] % 16 == 0 and self.conv3.weight.shape[0] % 64 == 0
                 and ((small.shape[2] * small.shape[3]) % 4 == 0 or small.shape[2] * small.shape[3] == 49)

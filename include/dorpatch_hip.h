@@ -64,11 +64,15 @@ const char *dp_error_string(int err);
  *   DP_DEBUG_CONV1X1_VARIANT           dp_conv1x1_fwd: bits 0-1 workgroup id -> (pixel tile, channel group): 0 XCD-aware
  *                                      (a tile's channel groups adjacent on one XCD), 1 channel group fastest, 2 tile
  *                                      fastest; bit 2 non-temporal result stores; bit 3 the next chunk goes to LDS in one
- *                                      lump half-way through the chunk (0: one item after each MFMA group).
+ *                                      lump half-way through the chunk (0: one item after each MFMA group); bits 4-6
+ *                                      (round 6) force the workgroup's pixel tile: 1 = 448, 2 = 256, 3 = 128, 4 = 64 pixels
+ *                                      (0: the launcher picks the largest tile whose grid fills the chip).
  *                                      Same bits out of every variant
  *   DP_DEBUG_CONV3X3_VARIANT           dp_conv3x3_fwd / dp_conv3x3_gn_fwd: 1 = k_conv3x3_mfma (zero rows / columns laid out
  *                                      in LDS) on every side it takes (56 / 28 / 14 / 7), 2 = k_conv3x3_flat (flat LDS
- *                                      image, masked taps) on every side, 0 = the measured winner per side.  Same bits */
+ *                                      image, masked taps) on every side, 0 = the measured winner per side; bits 4-6
+ *                                      (round 6) force k_conv3x3_flat's pixel tile on the sides 28 / 14 / 7 / 24 / 12:
+ *                                      1 = 448, 3 = 128, 4 = 64 pixels (0: the launcher's rule).  Same bits */
 #define DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK 1
 #define DP_DEBUG_UPDATE_VARIANT 2
 #define DP_DEBUG_APPLY_ORDER 3

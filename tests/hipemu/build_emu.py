@@ -42,20 +42,24 @@ def build(force=False):
         text = f.read()
     text = _DYN.sub(lambda m: "%s *%s = static_cast<%s *>(hipemu::dyn_lds_ptr());" % (m.group(1), m.group(2), m.group(1)),
                     text)
-    with open(GEN, "w") as f:
+    # per-process scratch names: the ranks of a multi-process test may find the library stale at the same moment
+    gen, tmp = "%s.%d.cpp" % (GEN[:-4], os.getpid()), "%s.tmp.%d" % (OUT, os.getpid())
+    with open(gen, "w") as f:
         f.write('#line 1 "%s"\n' % SRC)
         f.write(text)
     # same FP contract as the product build (dorpatch_amd/build.py): no fused multiply-add, no fast-math
     cmd = [cxx, "-x", "c++", "-std=c++17", "-O1", "-g0", "-ffp-contract=off", "-fPIC", "-shared", "-w",
-           "-I", HERE, "-I", os.path.join(ROOT, "include"), GEN, "-o", OUT + ".tmp"]
+           "-I", HERE, "-I", os.path.join(ROOT, "include"), gen, "-o", tmp]
     if SANITIZE:     # every LDS array, local array and (through the malloc interceptor) every tensor gets red zones
         cmd[cmd.index("-g0")] = "-g"
         cmd[5:5] = ["-fsanitize=address", "-shared-libasan", "-fno-omit-frame-pointer"]
     res = subprocess.run(cmd, capture_output=True, text=True)
+    os.remove(gen)
     if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hipemu build failed:\n" + res.stdout + res.stderr)
-    os.replace(OUT + ".tmp", OUT)
-    os.remove(GEN)
+    os.replace(tmp, OUT)
     return OUT
 
 

@@ -479,6 +479,51 @@ def test_conv3x3_flat_kernel_matches_conv2d_and_the_row_kernel(N, C, O, S, G, sm
         assert torch.equal(got, rows)
 
 
+CONV3X3_TILE_CASES = [   # (N, C, O, S, fold groups or 0, emulation-sized)
+    (3, 16, 64, 14, 16, True),      # 588 pixels: 1.3 / 4.6 / 9.2 tiles, seams of images inside every tile size, ragged ends
+    (5, 8, 64, 7, 0, True),         # flat mode: 9 / 2 / 1 whole images per tile
+    (2, 16, 128, 28, 16, False), (3, 8, 64, 12, 0, False), (1, 16, 64, 24, 16, False),
+    (9, 256, 256, 14, 32, False), (37, 512, 512, 7, 0, False), (5, 128, 128, 28, 32, False),
+]
+
+
+@pytest.mark.parametrize("N,C,O,S,G,small", CONV3X3_TILE_CASES)
+def test_conv3x3_flat_pixel_tiles_are_bit_identical(N, C, O, S, G, small):
+    """Round 6 (VERDICT r5 items 1 + 6): k_conv3x3_flat with 128- and 64-pixel tiles (K walked in 4-channel chunks) for
+    the batches whose planes give too few 448-pixel tiles — the same k-walk per output element, so plain and folded
+    launches must give the bits of the 448-pixel tile (which the test above pins to F.conv2d and to k_conv3x3_mfma), and
+    the launcher's own pick as well.  One-hot weights once more per tile: exact against F.conv2d."""
+    if DEV == "cpu" and not small:
+        pytest.skip("through the fibre emulation this case takes minutes: GPU only")
+    g = torch.Generator().manual_seed(C + S + N)
+    x = torch.randn(N, C, S, S, generator=g)
+    w = torch.randn(O, C, 3, 3, generator=g) / (3.0 * C ** 0.5)
+    xd, wt = x.to(DEV).contiguous(), ops.pack_conv3x3_weights(w).to(DEV)
+    w1 = torch.zeros(O, C, 3, 3)
+    for o in range(O):
+        w1[o, (5 * o + 3) % C, o % 3, (o // 3) % 3] = 1.0
+    wt1, want1 = ops.pack_conv3x3_weights(w1).to(DEV), F.conv2d(x, w1, padding=1)
+    if G:
+        gamma = (torch.rand(C, generator=g) + 0.5).to(DEV)
+        beta = (torch.randn(C, generator=g) * 0.2 + 1.0).to(DEV)
+        xr = (x * 1.5 + 0.3).to(DEV).contiguous()
+        _, _, ab, _ = ops.gn_stats(xr, gamma, beta, G, 1e-5)
+    outs = {}
+    try:
+        for variant in (2, 1 << 4, 3 << 4, 4 << 4, 0):       # flat 448 (reference), forced 448 / 128 / 64, the launcher's rule
+            ops.debug_set(_lib.DP_DEBUG_CONV3X3_VARIANT, variant)
+            got = [ops.conv3x3_fwd(xd, wt).cpu()]
+            if G:
+                got.append(ops.conv3x3_fwd(xr, wt, ab=ab).cpu())
+            outs[variant] = got
+            assert torch.equal(ops.conv3x3_fwd(xd, wt1).cpu(), want1), variant
+    finally:
+        ops.debug_set(_lib.DP_DEBUG_CONV3X3_VARIANT, 0)
+    for variant, got in outs.items():
+        for a, b in zip(got, outs[2]):
+            assert torch.equal(a, b), "variant %d differs from the 448-pixel flat tile" % variant
+
+
 CONV3X3S2_BWD_CASES = [   # (N, O = channels of dy, C = channels of dx, side of dy, emulation-sized)
     (2, 16, 64, 14, True),      # 392 pixels: one ragged tile spanning both images; ONE chunk in class (0,0), 4 in class (1,1)
     (10, 16, 64, 7, True),      # flat mode: 9 whole images + a ragged second tile; 1 - 4 chunks per class
@@ -557,15 +602,27 @@ CONV3X3S2_CASES = [   # (N, C, O, INPUT side, emulation-sized)
 ]
 
 
+@pytest.mark.parametrize("tile", [0, 1, 3, 4], ids=["auto", "448px", "128px", "64px"])
 @pytest.mark.parametrize("N,C,O,S,small", CONV3X3S2_CASES)
-def test_conv3x3_stride2_on_the_matrix_cores_matches_conv2d(N, C, O, S, small):
+def test_conv3x3_stride2_on_the_matrix_cores_matches_conv2d(N, C, O, S, small, tile):
     """dp_conv3x3s2_fwd (round 5: conv2 of the first bottleneck of stages 2-4, 3x3 / stride 2 / pad 1, de-interleaved LDS
     image) against F.conv2d at 1e-5 of the output scale; one-hot weights exact (padding above / left of every image, the
     seams between the images a tile spans, no padding below / right); bit-identical to the even pixels of the stride-1
-    kernel's result (same summation order); with the GroupNorm fold bit-identical to normalising first."""
+    kernel's result (same summation order); with the GroupNorm fold bit-identical to normalising first.  Round 6: with
+    448-, 128- and 64-pixel tiles (the small ones start mid-row and cross image boundaries anywhere) and the launcher's pick."""
     import os
     if DEV == "cpu" and not small and not (os.environ.get("DORPATCH_EMU_FULL", "0") == "1" and C <= 16):
         pytest.skip("through the fibre emulation this case takes minutes: GPU (or DORPATCH_EMU_FULL=1 for the narrow ones)")
+    if DEV == "cpu" and tile in (1, 3) and not os.environ.get("DORPATCH_EMU_FULL", "0") == "1":
+        pytest.skip("emulation: the launcher's pick and the 64-pixel tile cover the new geometry; all tiles run on the GPU")
+    ops.debug_set(_lib.DP_DEBUG_CONV3X3_VARIANT, tile << 4)      # bits 4-6: forced pixel tile (0: the launcher's rule)
+    try:
+        _conv3x3s2_case(N, C, O, S, small)
+    finally:
+        ops.debug_set(_lib.DP_DEBUG_CONV3X3_VARIANT, 0)
+
+
+def _conv3x3s2_case(N, C, O, S, small):
     g = torch.Generator().manual_seed(C + S)
     x = torch.randn(N, C, S, S, generator=g)
     x[0] += torch.arange(float(S)).view(1, S, 1) * 0.1 + torch.arange(float(S)).view(1, 1, S) * 0.01
@@ -604,16 +661,30 @@ CONV1X1_CASES = [   # (N, C, O, H, emulation-sized)
 ]
 
 
+CONV1X1_TILES = {0: "auto", 1: "448px", 2: "256px", 3: "128px", 4: "64px"}     # bits 4-6 of DP_DEBUG_CONV1X1_VARIANT
+
+
+@pytest.mark.parametrize("tile", sorted(CONV1X1_TILES), ids=lambda t: CONV1X1_TILES[t])
 @pytest.mark.parametrize("N,C,O,H,small", CONV1X1_CASES)
-def test_conv1x1_on_the_matrix_cores_matches_conv2d(N, C, O, H, small):
+def test_conv1x1_on_the_matrix_cores_matches_conv2d(N, C, O, H, small, tile):
     """dp_conv1x1_fwd (round 5: the backbone's 1x1 / 1 convolutions as an NCHW-in-place GEMM on v_mfma_f32_32x32x2_f32)
     against F.conv2d, forward and — the same entry point on the transposed weights — input gradient: exact-f32
     arithmetic, another summation order -> 1e-5 of the output scale; one-hot weights (output channel o copies input channel
     (5 o + 3) % C) must be EXACT for every pixel of every image, incl. the seams between the images a tile spans and the
-    ragged last tile; `res` (the epilogue add) exact against the sum; in place (out = res) as well."""
-    import os
+    ragged last tile; `res` (the epilogue add) exact against the sum; in place (out = res) as well.  Round 6: with every
+    pixel tile the launcher can pick and with its own choice."""
     if DEV == "cpu" and not small:
         pytest.skip("through the fibre emulation this case takes minutes: GPU only")
+    if DEV == "cpu" and tile in (2, 3):
+        pytest.skip("emulation: 448 / 64 pixels + the launcher's pick here, every tile in test_conv1x1_pixel_tiles_are_bit_identical")
+    ops.debug_set(_lib.DP_DEBUG_CONV1X1_VARIANT, tile << 4)       # bits 4-6: forced pixel tile (0: the launcher's rule)
+    try:
+        _conv1x1_case(N, C, O, H)
+    finally:
+        ops.debug_set(_lib.DP_DEBUG_CONV1X1_VARIANT, 0)
+
+
+def _conv1x1_case(N, C, O, H):
     g = torch.Generator().manual_seed(C + H)
     x = torch.randn(N, C, H, H, generator=g)
     x[0] += torch.arange(float(H)).view(1, H, 1) * 0.1 + torch.arange(float(H)).view(1, 1, H) * 0.01
@@ -661,6 +732,46 @@ def test_conv1x1_launch_variants_are_bit_identical():
         ops.debug_set(_lib.DP_DEBUG_CONV1X1_VARIANT, 0)
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+
+
+CONV1X1_TILE_CASES = [   # (N, C, O, H, emulation-sized)
+    (3, 32, 64, 14, True),      # row mode: tiles of 448 / 256 / 128 / 64 pixels cut 588 pixels at different seams
+    (11, 16, 128, 7, True),     # flat mode: 9 / 5 / 2 / 1 whole images per tile
+    (9, 64, 256, 56, False), (7, 1024, 256, 14, False), (23, 2048, 512, 7, False), (5, 128, 512, 28, False),
+]
+
+
+@pytest.mark.parametrize("N,C,O,H,small", CONV1X1_TILE_CASES)
+def test_conv1x1_pixel_tiles_are_bit_identical(N, C, O, H, small):
+    """Round 6: the pixel tile of dp_conv1x1_fwd is a scheduling choice of the launcher — an output
+    element's k-walk (channels ascending, one fmaf chain) is the same in every tile, so plain, folded (GroupNorm-apply in
+    the staging) and residual-add launches must give THE SAME BITS with 448-, 256-, 128- and 64-pixel tiles and with the
+    launcher's own pick; the output starts as NaN: every element is written by every tile."""
+    if DEV == "cpu" and not small:
+        pytest.skip("through the fibre emulation this case takes minutes: GPU only")
+    g = torch.Generator().manual_seed(N + C + H)
+    x = torch.randn(N, C, H, H, generator=g).to(DEV)
+    wt = ops.pack_conv1x1_weights(torch.randn(O, C, 1, 1, generator=g) / C ** 0.5).to(DEV)
+    res = torch.randn(N, O, H, H, generator=g).to(DEV)
+    fold = (H * H) % 4 == 0
+    if fold:
+        ab = torch.randn(N, C, 2, generator=g).to(DEV)
+    outs = {}
+    try:
+        for tile in sorted(CONV1X1_TILES):
+            ops.debug_set(_lib.DP_DEBUG_CONV1X1_VARIANT, tile << 4)
+            out = torch.full((N, O, H, H), float("nan"), device=DEV)
+            got = [ops.conv1x1_fwd(x, wt, out=out).cpu(), ops.conv1x1_fwd(x, wt, res=res).cpu()]
+            if fold:
+                got.append(ops.conv1x1_fwd(x, wt, ab=ab).cpu())
+                got.append(ops.conv1x1_fwd(x, wt, ab=ab, res=res).cpu())
+            outs[tile] = got
+    finally:
+        ops.debug_set(_lib.DP_DEBUG_CONV1X1_VARIANT, 0)
+    assert not torch.isnan(outs[1][0]).any()
+    for tile, got in outs.items():
+        for a, b in zip(got, outs[1]):
+            assert torch.equal(a, b), "tile %s differs from the 448-pixel tile" % CONV1X1_TILES[tile]
 
 
 CONV1X1_FOLD_CASES = [   # (N, C, O, H, emulation-sized)

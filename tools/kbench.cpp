@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void k_copy(const f4 *__restrict__ in, f4 *__r
 // after each MFMA group.
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_mfma_probe(float *__restrict__ out, int chunks, const float *__restrict__ src = nullptr) {
+  constexpr int kC1Buf = C1Geom<7>::BUF, kC1In = C1Geom<7>::IN;      // the full-size (448-pixel) tile
   __shared__ __attribute__((aligned(16))) float lds[2 * kC1Buf];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l32 = lane & 31;
   for (int i = tid; i < 2 * kC1Buf; i += 256) lds[i] = 1e-3f * (float)((i * 7 + 3) & 63);
@@ -409,7 +410,17 @@ int main(int argc, char **argv) {
       hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, st, (f4 *)cw, (size_t)Cc * Cc * 9 / 4, 0.01f);
       hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, st, (f4 *)cab, (size_t)Nc * Cc * 2 / 4, 0.5f);
       const double flop = 2.0 * Nc * Sc * Sc * (double)Cc * Cc * 9;
-      for (int variant = big ? 2 : 1; variant <= 2; ++variant) {
+      // $DP_C3_VARIANTS = values of DP_DEBUG_CONV3X3_VARIANT to run (default: 1 = k_conv3x3_mfma, 2 = k_conv3x3_flat; round 6:
+      // 16 / 48 / 64 = k_conv3x3_flat with 448- / 128- / 64-pixel tiles, 0 = the launcher's own choice)
+      std::vector<int> c3v;
+      if (const char *ev = getenv("DP_C3_VARIANTS")) {
+        int v, n = 0;
+        for (const char *p = ev; sscanf(p, "%d%n", &v, &n) == 1; p += n + (p[n] == ',')) c3v.push_back(v);
+      } else {
+        for (int v = big ? 2 : 1; v <= 2; ++v) c3v.push_back(v);
+      }
+      for (int variant : c3v) {
+        if ((variant & 3) == 1 && big) continue;
         DP(dp_debug_set(DP_DEBUG_CONV3X3_VARIANT, variant));
         for (int fold = 0; fold < 2; ++fold) {
           if (fold && Sc == 7) continue;
@@ -431,7 +442,9 @@ int main(int argc, char **argv) {
             CK(hipEventElapsedTime(&ms, e0, e1));
             ms /= iters;
             printf("dp_conv3x3_fwd %3d->%3d @%2dx%2d N=%d %s %s  %8.4f ms  %7.1f TFLOP/s  (%.1f%% of the 157.3 TFLOP/s f32 peak)\n",
-                   Cc, Cc, Sc, Sc, Nc, variant == 1 ? "k_conv3x3_mfma" : "k_conv3x3_flat", fold ? "fold " : "plain", ms,
+                   Cc, Cc, Sc, Sc, Nc, variant == 1 ? "k_conv3x3_mfma" : variant == 2 ? "k_conv3x3_flat" : variant == 0 ? "auto          " :
+                   variant == 16 ? "flat 448px    " : variant == 48 ? "flat 128px    " : variant == 64 ? "flat  64px    " : "other         ",
+                   fold ? "fold " : "plain", ms,
                    flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 1.573);
           }
         }
