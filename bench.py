@@ -54,6 +54,8 @@ import numpy as np
 import torch
 
 DEVICE_OVERRIDE = None     # test hook (tests/test_bench_emu.py runs main() on CPU tensors through the HIP emulation)
+SIZE_OVERRIDE = None       # test hook (tests/bench_emu_hook_tiny.py): image side in place of the preset's — the exact driver
+                           # command line of an 8-GPU configuration at a size 8 emulated ranks finish in a minute
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 matrix (v_mfma_f32_32x32x2_f32) = fp32 vector peak; 155 measured
 
@@ -120,6 +122,28 @@ def conv_roofline(loop, i, ms_per_step, samples):
                          "add": bool(k[1][5]), "launches": v[0], "ms": round(v[1], 3), "avg_ms": round(v[1] / v[0], 4),
                          "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
                         for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])]}
+
+
+def conv_class_traffic(cls):
+    """HBM bytes of ONE launch of a 1x1 launch class of `roofline_conv.classes` (round 6): the same
+    launch replayed by tools/kbench (same kernel, shape, fold / residual flags, the launcher's own tile) under rocprofv3 --pmc,
+    WRITE_SIZE + 2 x FETCH_SIZE in separate passes exactly as `roofline.traffic`.  Algorithmic bytes next to it:
+    4 (C + O [+ O with the residual]) N HW.  -> dict for the JSON line."""
+    N, C, O, HW = cls["N"], cls["C"], cls["O"], cls["pixels"]
+    side = int(round(HW ** 0.5))
+    mode = (1 if cls["fold"] else 0) + (2 if cls["add"] else 0)
+    env = {"DP_C1_SHAPES": "%d:%d:%d" % (C, O, side), "DP_C1_MODES": str(mode), "DP_C1_VARIANTS": "0"}
+    traffic, note = pmc_traffic_live(N, 1, 224, bench_filter="conv1x1", kernel="k_conv1x1_mfma", extra_env=env)
+    alg = 4 * N * HW * (C + O + (O if cls["add"] else 0))
+    out = {"launch_class": "N=%d %d->%d @%d pixels%s%s" % (N, C, O, HW, ", GroupNorm folded" if cls["fold"] else "",
+                                                          ", epilogue add" if cls["add"] else ""),
+           "tflops_in_step": cls["tflops"], "avg_ms_in_step": cls["avg_ms"], "algorithmic_bytes_per_launch": alg,
+           "traffic": traffic, "traffic_source": note}
+    if traffic:
+        out["traffic_over_algorithmic"] = round(traffic / alg, 3)
+        out["hbm_GBs_in_step"] = round(traffic / (cls["avg_ms"] * 1e-3) / 1e9, 1)
+        out["hbm_frac_of_8TBs"] = round(traffic / (cls["avg_ms"] * 1e-3) / 8e12, 4)
+    return out
 
 
 def comm_only(loop, pg, world, rank, json_fd, reps=50):
@@ -346,7 +370,7 @@ def cpu_baseline(size, n_masks=32, warm=3, timed=5, budget_s=40.0, threads=None,
             "detail": out}
 
 
-def pmc_traffic_live(B, S, H, timeout_s=150, bench_filter="dp_apply_fwd (default", kernel="k_apply_fwd"):
+def pmc_traffic_live(B, S, H, timeout_s=150, bench_filter="dp_apply_fwd (default", kernel="k_apply_fwd", extra_env=None):
     """HBM bytes of ONE launch of `kernel` (default: dp_apply_fwd at this run's geometry), measured now: a child process replays
     the launch (tools/kbench, same kernel, same grid) under `rocprofv3 --pmc WRITE_SIZE` and, in a second
     pass, `--pmc FETCH_SIZE` (MI355X_MICROARCH.md: the two do not fit one pass).  Corrections per that guide's
@@ -368,7 +392,7 @@ def pmc_traffic_live(B, S, H, timeout_s=150, bench_filter="dp_apply_fwd (default
         cmd = [rocprof, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "kb", "--",
                exe, str(B), str(S), str(H), "2", bench_filter]
         try:
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s,
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", **(extra_env or {})), timeout=timeout_s,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             vals = []
             for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -581,6 +605,8 @@ def main(argv=None):
     if hook:                                                    # test infrastructure only, see RANK_HOOK_ENV
         with open(hook) as f:
             exec(compile(f.read(), hook, "exec"), {"__name__": "bench_rank_hook", "__file__": hook, "bench": sys.modules[__name__]})
+    if SIZE_OVERRIDE is not None:                               # test infrastructure only, see SIZE_OVERRIDE
+        args.size = int(SIZE_OVERRIDE)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -715,6 +741,14 @@ def main(argv=None):
          % (dt, args.steps, step_ms, active_each))
     events = loop.kernel_events
     loop.kernel_events = None
+    digest_dir = os.environ.get("DORPATCH_BENCH_DIGEST_DIR")     # TEST HOOK: every rank records a digest of the optimised state
+    if digest_dir:                                              # after the timed steps (replicas must be bit-identical)
+        import hashlib
+        h = hashlib.sha256()
+        for t in (loop.adv_mask, loop.adv_pattern, loop.g_adv):
+            h.update(t.detach().cpu().contiguous().numpy().tobytes())
+        with open(os.path.join(digest_dir, "rank%d.txt" % rank), "w") as f:
+            f.write(h.hexdigest())
     conv_roof = None
     if conv_roofline_wanted(rank, world, dev.type, args.no_conv_roofline):
         conv_roof = conv_roofline(loop, i, dt / args.steps * 1e3, B * S_local)
@@ -803,6 +837,22 @@ def main(argv=None):
         out["step_tflops"] = round(step_tflops, 1)
         out["step_frac_of_peak"] = round(step_tflops / F32_PEAK_TFLOPS, 4)
         if conv_roof is not None:
+            if traffic is not None:      # the PMC passes are on in this run: HBM bytes of the 1x1 classes that matter most
+                c1 = [c for c in conv_roof["classes"] if c["kernel"] == "k_conv1x1_mfma" and c["launches"] >= 4]
+                picks = {}
+                if c1:
+                    picks["largest_share"] = max(c1, key=lambda c: c["ms"])
+                    picks["slowest"] = min(c1, key=lambda c: c["tflops"])
+                    picks["fastest"] = max(c1, key=lambda c: c["tflops"])
+                seen, conv_roof["traffic_classes"] = {}, {}
+                for name, cls in picks.items():
+                    key = (cls["C"], cls["O"], cls["pixels"], cls["fold"], cls["add"])
+                    if key not in seen:
+                        seen[key] = conv_class_traffic(cls)
+                    conv_roof["traffic_classes"][name] = seen[key]
+                dom = conv_roof["traffic_classes"].get("largest_share")
+                conv_roof["traffic"] = dom["traffic"] if dom and conv_roof["kernel"].startswith("k_conv1x1") else None
+                note("conv PMC passes done")
             out["roofline_conv"] = conv_roof
         if dt_sweep is not None:
             out["collect_failure_sweep_ms"] = round(dt_sweep * 1e3, 1)

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
-DP_ABI_VERSION = 11
+DP_ABI_VERSION = 12
 DP_MAX_RECTS = 4
 DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK, DP_DEBUG_UPDATE_VARIANT, DP_DEBUG_APPLY_ORDER, DP_DEBUG_AFFINE_GATHER = 1, 2, 3, 4   # dp_debug_set knobs
 DP_DEBUG_CONV1X1_VARIANT = 5
@@ -68,6 +68,7 @@ PROTOTYPES = {
     "dp_conv3x3_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "dp_conv3x3_gn_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "dp_conv3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "dp_conv3x3_wino_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "dp_stem_conv_fwd": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "dp_conv3x3s2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
     "dp_conv1x1_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),

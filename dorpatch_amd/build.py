@@ -36,7 +36,7 @@ def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [SRC, os.path.join(INCLUDE, "dorpatch_hip.h")]
+    deps = [SRC, os.path.join(os.path.dirname(SRC), "conv3x3_wino.inc"), os.path.join(INCLUDE, "dorpatch_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

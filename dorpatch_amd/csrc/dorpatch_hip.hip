@@ -3913,6 +3913,11 @@ static int conv1x1_tile_nq(long N, int C, int HW, int og, bool flat, bool fold, 
   long wgs[4];
   for (int i = 0; i < 4; ++i) wgs[i] = conv1x1_tiles(N, HW, flat, cand[i]) * og;
   if (!flat && C <= 64 && og == 1 && wgs[0] < 1024) return 1;   // 64 -> 64 on a small grid: four chunks of K against a whole epilogue
+  if (!flat && fold && (g_conv1x1_variant & 0x180)) {             // A/B knob (bits 7-8): the fold prefers the 256- / 128- / 64-pixel tile
+    static const float pen_a[4] = {1.00f, 0.94f, 1.04f, 1.03f}, pen_b[4] = {1.00f, 1.03f, 0.94f, 1.03f}, pen_c[4] = {1.05f, 1.02f, 1.03f, 1.00f};
+    const int k = (g_conv1x1_variant >> 7) & 3;
+    return pick_tile(cand, k == 1 ? pen_a : k == 2 ? pen_b : pen_c, 4, wgs);
+  }
   return pick_tile(cand, flat ? pen_flat : fold ? pen_fold : res ? pen_res : pen_plain, 4, wgs);
 }
 
@@ -4634,6 +4639,8 @@ int launch_stem_dgrad(int variant, const float *dy, const float *w, int N, int K
 
 }  // namespace
 
+#include "conv3x3_wino.inc"
+
 // ============================================================================
 // C ABI
 // ============================================================================
@@ -4663,7 +4670,7 @@ int dp_debug_set(int knob, int value) {
       g_aff_gather = value;
       return 0;
     case DP_DEBUG_CONV1X1_VARIANT:
-      DP_REQUIRE(value >= 0 && value < 128 && (value & 3) != 3 && (value >> 4) <= 4);     // bits 4-6: forced pixel tile
+      DP_REQUIRE(value >= 0 && value < 512 && (value & 3) != 3 && ((value >> 4) & 7) <= 4);     // bits 4-6: forced pixel tile, 7-8: fold preference (A/B)
       g_conv1x1_variant = value;
       return 0;
     case DP_DEBUG_CONV3X3_VARIANT:
@@ -5028,6 +5035,16 @@ int dp_conv3x3_gn_fwd(const float *x, const float *wt, const float *ab, int N, i
                       dp_stream_t stream) {
   DP_REQUIRE(ab);
   return conv3x3_launch(x, wt, ab, N, C, O, H, W, y, stream);
+}
+
+int dp_conv3x3_wino_fwd(const float *x, const float *wt, const float *ab, int N, int C, int O, int H, int W, float *y,
+                        dp_stream_t stream) {
+  DP_REQUIRE(x && wt && y && aligned16(x) && aligned16(wt) && aligned16(y));
+  DP_REQUIRE(N > 0 && C > 0 && C % kWnCh == 0 && O > 0 && O % kWnO == 0 && H == W);
+  DP_REQUIRE(H == 56 || H == 28 || H == 14 || H == 7);
+  DP_REQUIRE(!ab || (reinterpret_cast<uintptr_t>(ab) & 7u) == 0);
+  DP_REQUIRE((long)N * C * H * W < (1L << 31) && (long)N * O * H * W < (1L << 31));      // 32-bit element offsets in the kernel
+  return launch_conv3x3_wino(x, wt, ab, N, C, O, H, y, as_stream(stream));
 }
 
 int dp_conv3x3s2_fwd(const float *x, const float *wt, const float *ab, int N, int C, int O, int H, int W, float *y,

@@ -135,6 +135,33 @@ def _packed3(w, transpose):
     return _packed(w, ("3x3", bool(transpose)), lambda: ops.pack_conv3x3_weights(w, transpose=transpose))
 
 
+def _packed3w(w, transpose):
+    """pack_conv3x3_wino_weights(w[, transposed + flipped]), cached."""
+    from . import ops
+    return _packed(w, ("3x3-wino", bool(transpose)), lambda: ops.pack_conv3x3_wino_weights(w, transpose=transpose))
+
+
+# Round 6: the stride-1 3x3 problems that run on own kernels take Winograd F(2x2, 3x3) on the matrix cores (dp_conv3x3_wino_fwd:
+# 16 multiplications per 2 x 2 outputs instead of 36) where it is the faster one, else the direct kernels (dp_conv3x3_fwd):
+# "on" | "off" (DORPATCH_CONV3X3_WINO).  Both are exact-f32, fixed-order, deterministic; they differ by fp32 round-off.
+CONV3X3_WINO = os.environ.get("DORPATCH_CONV3X3_WINO", "on")
+if CONV3X3_WINO not in ("on", "off"):
+    raise ValueError("DORPATCH_CONV3X3_WINO must be on or off, got %r" % CONV3X3_WINO)
+CONV3X3_WINO_MIN_BATCH = int(os.environ.get("DORPATCH_CONV3X3_WINO_MIN_BATCH", "32"))
+_used_wino = set()
+
+
+def conv3x3_s1(x, w, transpose, ab=None):
+    """The stride-1 3x3 convolution of ``x`` with the frozen filter ``w`` (``transpose``: its input gradient on dy) on own
+    kernels: Winograd where enabled and supported, else the direct implicit GEMM."""
+    from . import ops
+    if CONV3X3_WINO == "on" and x.shape[0] >= CONV3X3_WINO_MIN_BATCH and x.shape[2] in ops.CONV3X3_WINO_SIDES \
+            and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0:
+        _used_wino.add((int(x.shape[0]), int(w.shape[1]), int(x.shape[2]), bool(transpose)))
+        return ops.conv3x3_wino_fwd(x, _packed3w(w, transpose), ab=ab)
+    return ops.conv3x3_fwd(x, _packed3(w, transpose), ab=ab)
+
+
 def _packed_stem(w):
     """pack_stem_weights(w), cached."""
     from . import ops
@@ -184,6 +211,10 @@ def prepack(net):
             if stride == (1, 1) and O % 8 == 0 and C % 64 == 0:
                 _packed3(w, True)
                 n += 1
+            if stride == (1, 1) and CONV3X3_WINO == "on" and O % 64 == 0 and C % 64 == 0:
+                _packed3w(w, False)
+                _packed3w(w, True)
+                n += 2
             if stride == (2, 2) and O % 16 == 0 and C % 64 == 0:
                 _packed3s2b(w)
                 n += 1
@@ -237,7 +268,7 @@ def conv_fwd(x, w, stride=(1, 1), padding=(0, 0)):
     """``F.conv2d(x, w, None, stride, padding)`` for a frozen filter."""
     if w.shape[2] == 3 and _conv3x3_route("fwd", x, w, stride, padding):
         from . import ops
-        return ops.conv3x3_fwd(x, _packed3(w, False))
+        return conv3x3_s1(x, w, False)
     if w.shape[2] == 3 and tuple(stride) == (2, 2) and CONV3X3S2 == "on" and x.shape[0] >= CONV3X3S2_MIN_BATCH:
         from . import ops
         if ops.conv3x3s2_supported(x, w, stride, padding) and conv3x3s2_fwd_pays(x, w):
@@ -258,7 +289,7 @@ def conv_bwd_data(dy, x_ref, w, stride=(1, 1), padding=(0, 0)):
     MIOpen's backward-data never reads it, but ATen wants a dense tensor there)."""
     if w.shape[2] == 3 and dy.shape[2:] == x_ref.shape[2:] and _conv3x3_route("bwd", dy, w, stride, padding):
         from . import ops
-        return ops.conv3x3_fwd(dy, _packed3(w, True))
+        return conv3x3_s1(dy, w, True)
     if (w.shape[2] == 3 and tuple(stride) == (2, 2) and CONV3X3S2_BWD == "on" and dy.shape[0] >= CONV3X3S2_BWD_MIN_BATCH
             and x_ref.shape[2] == 2 * dy.shape[2] and x_ref.shape[3] == 2 * dy.shape[3]):
         from . import ops

@@ -406,6 +406,56 @@ def conv3x3_fwd(x, wt, ab=None):
     return _timed_conv("k_conv3x3_mfma", (N, C, O, H * W, ab is not None, False), 18.0 * N * H * W * C * O, launch)
 
 
+# ---------------------------------------------------------------- a-8 (round 6): Winograd F(2x2, 3x3) on the matrix cores
+CONV3X3_WINO_SIDES = (56, 28, 14, 7)
+
+
+def conv3x3_wino_supported(x, weight, stride=(1, 1), padding=(1, 1)):
+    """Shapes dp_conv3x3_wino_fwd takes: fp32 GPU NCHW, 3x3 / stride 1 / pad 1, square planes of side 56 / 28 / 14 / 7,
+    C % 4 == 0, O % 64 == 0."""
+    return (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+            and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
+            and x.shape[2] == x.shape[3] and x.shape[2] in CONV3X3_WINO_SIDES and weight.shape[1] == x.shape[1]
+            and weight.shape[1] % 4 == 0 and weight.shape[0] % 64 == 0
+            and x.shape[0] * max(weight.shape[0], weight.shape[1]) * x.shape[2] * x.shape[3] < 2 ** 31)
+
+
+def pack_conv3x3_wino_weights(w, transpose=False):
+    """(O, C, 3, 3) frozen weights -> U = G g G^T, the 4 x 4 Winograd-domain filter of F(2 x 2, 3 x 3), in
+    dp_conv3x3_wino_fwd's k-walk order [og][chunk][position 4 xi + nu][c][o] (output channel 64 og + o, input channel
+    4 chunk + c; include/dorpatch_hip.h).  Computed in fp64 and rounded once.  ``transpose``: the filter of the INPUT
+    GRADIENT (w'[c][o][kh][kw] = w[o][c][2 - kh][2 - kw]).  Once per frozen convolution."""
+    w = w.detach().double()
+    if transpose:
+        w = w.transpose(0, 1).flip(2, 3)
+    O, C = w.shape[0], w.shape[1]
+    assert w.shape[2:] == (3, 3) and C % 4 == 0 and O % 64 == 0
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
+    U = torch.einsum("ai,ocij,bj->ocab", G, w, G).reshape(O // 64, 64, C // 4, 4, 16)
+    return U.permute(0, 2, 4, 3, 1).contiguous().float()
+
+
+def conv3x3_wino_fwd(x, wt, ab=None):
+    """y = conv2d(x', w, stride 1, padding 1) for x (N,C,S,S), wt = pack_conv3x3_wino_weights(w): Winograd F(2x2, 3x3) with
+    the 16 position GEMMs on v_mfma_f32_32x32x2_f32 (2.25x fewer multiplications than the direct form; fp32, fixed order,
+    ~1e-6 of the output scale away from the direct kernels).  ``ab`` (N,C,2) from ``gn_stats``: x' = relu(group_norm(x))
+    applied while staging (x is the RAW tensor; the zero padding pads the normalised activation)."""
+    lib = _lib.load()
+    _chk(x, torch.float32, "x"), _chk(wt, torch.float32, "wt")
+    N, C, H, W = x.shape
+    O = wt.shape[0] * wt.shape[-1]
+    assert wt.numel() == C * 16 * O, (wt.shape, C, O)
+    y = torch.empty((N, O, H, W), dtype=torch.float32, device=x.device)
+    if ab is not None:
+        _chk(ab, torch.float32, "ab")
+        assert ab.numel() == N * C * 2
+
+    def launch():
+        _lib.check(lib.dp_conv3x3_wino_fwd(_p(x), _p(wt), _p(ab), N, C, O, H, W, _p(y), _stream()), "dp_conv3x3_wino_fwd")
+        return y
+    return _timed_conv("k_conv3x3_wino", (N, C, O, H * W, ab is not None, False), 18.0 * N * H * W * C * O, launch)
+
+
 CONV3X3S2_SIDES = (56, 28, 14)        # INPUT sides of the stride-2 kernel (ResNetV2-50 at 224 x 224)
 
 
@@ -919,7 +969,7 @@ def _fconv_fwd(kind, x, w, ab, res):
     assert res is None
     if kind == 32:          # 3x3 / stride 2
         return conv3x3s2_fwd(x, libconv._packed3(w, False), ab=ab)
-    return conv3x3_fwd(x, libconv._packed3(w, False), ab=ab)
+    return libconv.conv3x3_s1(x, w, False, ab=ab)
 
 
 def _fconv_bwd(kind, dy, w, res=None, x_ref=None):
@@ -929,7 +979,7 @@ def _fconv_bwd(kind, dy, w, res=None, x_ref=None):
     assert res is None
     if kind == 32:          # dp_conv3x3s2_bwd where libconv routes it there, else the library (x_ref: its shape only)
         return libconv.conv_bwd_data(dy, x_ref, w, (2, 2), (1, 1))
-    return conv3x3_fwd(dy, libconv._packed3(w, True))
+    return libconv.conv3x3_s1(dy, w, True)
 
 
 def gn_fold_supported(x, conv_weight, groups, stride=(1, 1), padding=None):

@@ -99,6 +99,39 @@ def one_s2(N, C, S):
                 max_rel_diff_fwd=err, max_rel_diff_gn_fwd=err_gn, max_rel_diff_bwd_data=err_b)
 
 
+def one_wino(N, C, S):
+    """Round 6: dp_conv3x3_wino_fwd (Winograd F(2x2, 3x3), position GEMMs on the matrix cores) against the direct kernel
+    (dp_conv3x3_fwd) and MIOpen: forward, input gradient, and forward with the GroupNorm fold (fed the same coefficients)."""
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(N, C, S, S, generator=g).cuda()
+    w = (torch.randn(C, C, 3, 3, generator=g) / (3.0 * C ** 0.5)).cuda()
+    wt, wt_bwd = ops.pack_conv3x3_weights(w), ops.pack_conv3x3_weights(w, transpose=True)
+    ww, ww_bwd = ops.pack_conv3x3_wino_weights(w), ops.pack_conv3x3_wino_weights(w, transpose=True)
+    gamma, beta = torch.rand(C, generator=g).cuda() + 0.5, torch.randn(C, generator=g).cuda() * 0.2
+    flop = 2.0 * N * S * S * C * C * 9
+    want = F.conv2d(x.double(), w.double(), padding=1)
+    scale = float(want.abs().max())
+    err_w = float((ops.conv3x3_wino_fwd(x, ww).double() - want).abs().max()) / scale
+    err_d = float((ops.conv3x3_fwd(x, wt).double() - want).abs().max()) / scale
+    dy = torch.randn(N, C, S, S, generator=g).cuda()
+    bwd_lib = lambda: torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                          (True, False, False))[0]
+    ms = dict(miopen_fwd=timed(lambda: F.conv2d(x, w, padding=1)), direct_fwd=timed(lambda: ops.conv3x3_fwd(x, wt)),
+              wino_fwd=timed(lambda: ops.conv3x3_wino_fwd(x, ww)),
+              miopen_bwd_data=timed(bwd_lib), direct_bwd_data=timed(lambda: ops.conv3x3_fwd(dy, wt_bwd)),
+              wino_bwd_data=timed(lambda: ops.conv3x3_wino_fwd(dy, ww_bwd)))
+    if S != 7:
+        ab = ops.gn_stats(x, gamma, beta, 32, 1e-5)[2]
+        ms["direct_fold_fwd"] = timed(lambda: ops.conv3x3_fwd(x, wt, ab=ab))
+        ms["wino_fold_fwd"] = timed(lambda: ops.conv3x3_wino_fwd(x, ww, ab=ab))
+    return dict(shape="N=%d %d->%d 3x3/1 @%dx%d fp32" % (N, C, C, S, S), gflop=round(flop / 1e9, 2),
+                ms={k: round(v, 4) for k, v in ms.items()},
+                tflops_effective={k: round(flop / (v * 1e-3) / 1e12, 1) for k, v in ms.items()},
+                speedup_over_direct=dict(fwd=round(ms["direct_fwd"] / ms["wino_fwd"], 3),
+                                         bwd_data=round(ms["direct_bwd_data"] / ms["wino_bwd_data"], 3)),
+                max_err_vs_fp64_of_scale=dict(wino=err_w, direct=err_d))
+
+
 SHAPES_384 = ((64, 96), (128, 48), (256, 24), (512, 12))
 
 
@@ -147,6 +180,10 @@ def main():
         if "--flat" in sys.argv:
             for C, S in (SHAPES_384 if "--384" in sys.argv else SHAPES):
                 print(json.dumps(one_flat(N, C, S)), flush=True)
+            continue
+        if "--wino" in sys.argv:
+            for C, S in SHAPES:
+                print(json.dumps(one_wino(N, C, S)), flush=True)
             continue
         if "--stride2" in sys.argv:
             for C, S in SHAPES_S2:

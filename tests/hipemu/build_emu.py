@@ -18,7 +18,7 @@ SRC = os.path.join(ROOT, "dorpatch_amd", "csrc", "dorpatch_hip.hip")
 SANITIZE = os.environ.get("DORPATCH_EMU_SANITIZE", "0") == "1"      # AddressSanitizer build (tests/test_kernels_asan.py)
 OUT = os.path.join(HERE, "libdorpatch_emu_asan.so" if SANITIZE else "libdorpatch_emu.so")
 GEN = os.path.join(HERE, "_dorpatch_emu_asan_gen.cpp" if SANITIZE else "_dorpatch_emu_gen.cpp")
-DEPS = [SRC, os.path.join(ROOT, "include", "dorpatch_hip.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
+DEPS = [SRC, os.path.join(os.path.dirname(SRC), "conv3x3_wino.inc"), os.path.join(ROOT, "include", "dorpatch_hip.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
         os.path.abspath(__file__)]
 
 _DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(\w+)\s+(\w+)\[\];")
@@ -49,7 +49,7 @@ def build(force=False):
         f.write(text)
     # same FP contract as the product build (dorpatch_amd/build.py): no fused multiply-add, no fast-math
     cmd = [cxx, "-x", "c++", "-std=c++17", "-O1", "-g0", "-ffp-contract=off", "-fPIC", "-shared", "-w",
-           "-I", HERE, "-I", os.path.join(ROOT, "include"), gen, "-o", tmp]
+           "-I", HERE, "-I", os.path.join(ROOT, "include"), "-I", os.path.dirname(SRC), gen, "-o", tmp]
     if SANITIZE:     # every LDS array, local array and (through the malloc interceptor) every tensor gets red zones
         cmd[cmd.index("-g0")] = "-g"
         cmd[5:5] = ["-fsanitize=address", "-shared-libasan", "-fno-omit-frame-pointer"]

@@ -369,6 +369,32 @@ def test_side_streams_do_not_change_the_step_or_the_sweep(streams):
     assert fails[0] == fails[1] and any(len(f) for f in fails[0])
 
 
+def test_side_streams_sweep_with_several_image_groups_reads_each_groups_own_labels():
+    """with 7 images the sweep plan has three groups (4 + 2 + 1 images); their forwards run round-robin on the side
+    streams while the host already prepares the next group.  Every group must compare its predictions with ITS images'
+    labels (one int32 conversion of all labels before the streams fork; a per-group conversion after the fork was ordered
+    behind nothing the side streams wait for).  Labels differ per image and the classifier separates them, so reading
+    another group's labels changes the failure lists: one stream and two streams must agree list for list."""
+    from dorpatch_amd.attack import _collect_failure, sweep_plan
+    from dorpatch_amd.attack import _unwrap_model
+    H, B = 56, 7
+    model = _toy(2.0).to(DEV)
+    net, norm = _unwrap_model(model)
+    g = torch.Generator().manual_seed(5)
+    adv = torch.rand(B, 3, H, H, generator=g).to(DEV)
+    with torch.no_grad():
+        clean = model(adv).argmax(-1)
+    y = clean.clone()
+    y[4:6] = (y[4:6] + 3) % 10        # untargeted sweep: images 0-3 and 6 "are still their class" under (nearly) every mask,
+    table = ops.upload_table(masks.universe_rects(H, 1), DEV)       # images 4, 5 (the middle group) under (nearly) none
+    plan = sweep_plan(B, 16)                                        # (the 144 single-window masks: 9 forwards per group)
+    assert [b1 - b0 for b0, b1, _ in plan] == [4, 2, 1]
+    lists = [_collect_failure(net, norm, adv, y, table, False, None, plan=plan, streams=n, stream_pool=[]) for n in (1, 2, 2)]
+    assert lists[0] == lists[1] == lists[2]
+    n_fail = [len(l) for l in lists[0]]
+    assert min(n_fail[:4] + n_fail[6:]) > 100 and max(n_fail[4:6]) < 44, n_fail      # the last group did not read the middle one's labels
+
+
 def _retire_run(retire, *, mb, dropout=1, S=6, B=4, H=56, steps=6, stop_at=(2, 3), dual=False, stage=0):
     """`steps` steps of a B-image loop; image 1 is marked finished after step stop_at[0]-1, image 3 after stop_at[1]-1
     (what `_ImageState.step` does at attack.py:311-316).  The failure sweep runs at steps 0, 2, 4."""

@@ -133,6 +133,34 @@ def test_plain_command_strong_scaling_mode():
         bench.parse(["--samples", "10", "--scaling", "strong", "--gpus", "4"])
 
 
+def test_the_8_gpu_strong_scaling_command_runs_on_8_ranks_with_identical_replicas(tmp_path):
+    """the exact command a driver would run for BASELINE configs[3] on an 8-GPU node —
+    `python bench.py --gpus 8 --config 3 --scaling strong --steps K --warmup W` — through bench.py's own launcher on 8 gloo
+    ranks (kernels through the emulation; tests/bench_emu_hook_tiny.py swaps in 32 x 32 images and a toy classifier, nothing
+    else): 512 EOT samples of one image, 64 per rank; ONE JSON line with n_gpus 8; and every rank ends with the bit-identical
+    mask / pattern / all-reduced gradient (the replicas stay in lock-step through the signed update)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hook = os.path.join(root, "tests", "bench_emu_hook_tiny.py")
+    env_dir = str(tmp_path)
+    os.environ["DORPATCH_BENCH_DIGEST_DIR"] = env_dir
+    try:
+        res = _plain(["--gpus", "8", "--config", "3", "--scaling", "strong", "--steps", "2", "--warmup", "1", "--no-sweep",
+                      "--no-cpu-baseline", "--deterministic", "off", "--backend", "gloo"], hook=hook, timeout=900)
+    finally:
+        del os.environ["DORPATCH_BENCH_DIGEST_DIR"]
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["steps"] == 2 and out["warmup"] == 1
+    assert out["config"]["masks_per_image_per_gpu"] == 64 and out["config"]["masks_per_image_total"] == 512
+    assert out["config"]["workload"].startswith("BASELINE configs[3] (strong scaling: 512 EOT samples of one image in total, 64 per GPU)")
+    assert abs(out["value"] - 512 / (out["ms_per_step"] / 1e3)) <= 0.006 + 1e-3 * out["value"]
+    digests = [open(os.path.join(env_dir, "rank%d.txt" % r)).read() for r in range(8)]
+    assert len(set(digests)) == 1, digests
+
+
 def test_comm_only_mode_times_the_steps_real_message():
     """`bench.py --gpus N --comm-only` = 50 all-reduces of HotLoop's own message (patch gradient + one
     loss / prediction slab + checksum per rank), one JSON line with us per call and the byte count — here 2 gloo ranks."""

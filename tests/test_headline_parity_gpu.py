@@ -92,7 +92,10 @@ def test_micro_batch_with_shipped_routes_matches_fp64_oracle_and_miopen(n, oracl
     if GroupNormAct.fold and n >= GroupNormAct.fold_min_batch:
         # round 5: at this batch the graph is the FOLDED one — nearly every 1x1 convolution runs inside ops.GnConvFunction on
         # dp_conv1x1_fwd; what is left for the route table (the 7 x 7 planes, stage 3's first block) is on the MFMA kernel too
-        assert routes["fwd"]["mfma"] + routes["bwd"]["mfma"] >= 4 and routes["fwd"]["gemm"] + routes["bwd"]["gemm"] <= 4
+        # (round 6: the fold applies from 32 rows up; at 64 / 32 rows the table sends some of those leftovers to the libraries)
+        if n >= 256:
+            assert routes["fwd"]["mfma"] + routes["bwd"]["mfma"] >= 4 and routes["fwd"]["gemm"] + routes["bwd"]["gemm"] <= 4
+        assert sum(routes[d][r] for d in ("fwd", "bwd") for r in ("mfma", "gemm", "miopen")) <= 14      # only the leftovers
     else:
         assert routes["fwd"]["gemm"] + routes["bwd"]["gemm"] >= 8     # the GEMM route really ran at this batch size
     want_lg, want_gx = oracle_rows

@@ -524,6 +524,55 @@ def test_conv3x3_flat_pixel_tiles_are_bit_identical(N, C, O, S, G, small):
             assert torch.equal(a, b), "variant %d differs from the 448-pixel flat tile" % variant
 
 
+CONV3X3_WINO_CASES = [   # (N, C, O, S, emulation-sized)
+    (2, 8, 64, 14, True),       # 98 tiles: 3 full blocks of 32 + a ragged one, blocks that cross the image boundary, 2 K-chunks
+    (3, 4, 64, 7, True),        # odd side: 4 x 4 tiles cover 8 x 8, the overhang is not stored; ONE chunk
+    (1, 8, 128, 28, False),     # two output-channel groups
+    (3, 64, 64, 56, False), (5, 128, 128, 28, False), (9, 256, 256, 14, False), (20, 512, 512, 7, False),   # ResNetV2-50's four
+]
+
+
+@pytest.mark.parametrize("N,C,O,S,small", CONV3X3_WINO_CASES)
+def test_conv3x3_winograd_on_the_matrix_cores_matches_conv2d(N, C, O, S, small):
+    """dp_conv3x3_wino_fwd (round 6: Winograd F(2x2, 3x3), the 16 position GEMMs on v_mfma_f32_32x32x2_f32) against
+    F.conv2d and — on transposed + flipped weights — ATen's input gradient.  Winograd sums 16 transformed products where
+    the direct form sums 9 plain ones: fp32 round-off of another shape, so the bound is 2e-5 of the output scale (measured
+    ~1e-6; the direct kernels are held to 1e-5) and the one-hot check (every output channel copies ONE shifted input
+    channel: padding at all four borders of every image, the seams between the images a tile block spans, the odd side's
+    overhang) is to 2e-6 of the input scale instead of exact.  With the GroupNorm fold: bit-identical to normalising first
+    (same kernel, same patch values; the padding pads the NORMALISED activation).  Deterministic: two launches, same bits."""
+    if DEV == "cpu" and not small:
+        pytest.skip("through the fibre emulation this case takes minutes: GPU only")
+    g = torch.Generator().manual_seed(C + S)
+    x = torch.randn(N, C, S, S, generator=g)
+    x[0] += torch.arange(float(S)).view(1, S, 1) * 0.1 + torch.arange(float(S)).view(1, 1, S) * 0.01
+    w = torch.randn(O, C, 3, 3, generator=g) / (3.0 * C ** 0.5)
+    want = F.conv2d(x, w, padding=1)
+    xd, wt = x.to(DEV).contiguous(), ops.pack_conv3x3_wino_weights(w).to(DEV)
+    got = ops.conv3x3_wino_fwd(xd, wt)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=2e-5 * float(want.abs().max()))
+    assert torch.equal(got, ops.conv3x3_wino_fwd(xd, wt))
+    w1 = torch.zeros(O, C, 3, 3)
+    for o in range(O):
+        w1[o, (5 * o + 3) % C, o % 3, (o // 3) % 3] = 1.0
+    got1 = ops.conv3x3_wino_fwd(xd, ops.pack_conv3x3_wino_weights(w1).to(DEV)).cpu()
+    np.testing.assert_allclose(got1.numpy(), F.conv2d(x, w1, padding=1).numpy(), rtol=0, atol=2e-6 * float(x.abs().max()))
+    if C % 64 == 0:        # input gradient = the same kernel on dy with transposed, flipped weights
+        dy = torch.randn(N, O, S, S, generator=g)
+        want_dx = torch.ops.aten.convolution_backward(dy, x, w, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1,
+                                                      (True, False, False))[0]
+        got_dx = ops.conv3x3_wino_fwd(dy.to(DEV).contiguous(), ops.pack_conv3x3_wino_weights(w, transpose=True).to(DEV)).cpu()
+        np.testing.assert_allclose(got_dx.numpy(), want_dx.numpy(), rtol=0, atol=2e-5 * float(want_dx.abs().max()))
+    G = 32 if C % 32 == 0 else C // 2        # GroupNorm fold (any side: the staging loads are scalar)
+    if (C // G) * S * S % 4 == 0:
+        xr = (x * 1.5 + 0.3).to(DEV).contiguous()
+        gamma = (torch.rand(C, generator=g) + 0.5).to(DEV)
+        beta = (torch.randn(C, generator=g) * 0.2 + 1.0).to(DEV)        # mostly positive: relu(beta) != 0 in a polluted halo
+        y, mean, rstd, _ = ops.gn_relu_fwd(xr, gamma, beta, G, 1e-5)
+        _, _, ab, _ = ops.gn_stats(xr, gamma, beta, G, 1e-5)
+        assert torch.equal(ops.conv3x3_wino_fwd(xr, wt, ab=ab), ops.conv3x3_wino_fwd(y, wt))
+
+
 CONV3X3S2_BWD_CASES = [   # (N, O = channels of dy, C = channels of dx, side of dy, emulation-sized)
     (2, 16, 64, 14, True),      # 392 pixels: one ragged tile spanning both images; ONE chunk in class (0,0), 4 in class (1,1)
     (10, 16, 64, 7, True),      # flat mode: 9 whole images + a ragged second tile; 1 - 4 chunks per class

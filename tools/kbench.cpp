@@ -617,14 +617,17 @@ int main(int argc, char **argv) {
       hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, st, (f4 *)cab, (size_t)Nc * Cc * 2 / 4, 0.5f);
       const double flop = 2.0 * Nc * HWc * (double)Cc * Oc, bytes = 4.0 * (ex + ey);
       for (int v : variants) {
-        for (int mode = 0; mode < 3; ++mode) {     // 0 plain, 1 fold, 2 res
-          if (mode == 1 && (HWc & 3)) continue;
+        for (int mode = 0; mode < 4; ++mode) {     // 0 plain, 1 fold, 2 res, 3 fold + res ($DP_C1_MODES = "3" / "0,3": only those)
+          if ((mode & 1) && (HWc & 3)) continue;
           if (mode && getenv("DP_C1_PLAIN_ONLY")) continue;
+          if (const char *em = getenv("DP_C1_MODES")) {
+            if (!strchr(em, '0' + mode)) continue;
+          } else if (mode == 3) continue;
           DP(dp_debug_set(DP_DEBUG_CONV1X1_VARIANT, v));
           hipEvent_t e0, e1;
           CK(hipEventCreate(&e0));
           CK(hipEventCreate(&e1));
-          const float *ab = mode == 1 ? cab : nullptr, *res = mode == 2 ? cr : nullptr;
+          const float *ab = (mode & 1) ? cab : nullptr, *res = (mode & 2) ? cr : nullptr;
           DP(dp_conv1x1_fwd(cx, cw, ab, res, Nc, Cc, Oc, HWc, cy, st));
           CK(hipEventRecord(e0, st));
           for (int i = 0; i < iters; ++i) DP(dp_conv1x1_fwd(cx, cw, ab, res, Nc, Cc, Oc, HWc, cy, st));
@@ -634,8 +637,8 @@ int main(int argc, char **argv) {
           CK(hipEventElapsedTime(&ms, e0, e1));
           ms /= iters;
           printf("dp_conv1x1_fwd %4d->%4d @%2dx%2d N=%d variant %2d %-5s %8.4f ms  %6.1f TFLOP/s (%4.1f%% of 157.3)  %5.2f TB/s algorithmic\n",
-                 Cc, Oc, Sc, Sc, Nc, v, mode == 0 ? "plain" : mode == 1 ? "fold" : "res", ms, flop / (ms * 1e-3) / 1e12,
-                 flop / (ms * 1e-3) / 1e12 / 1.573, (bytes + (mode == 2 ? 4.0 * ey : 0.0)) / (ms * 1e-3) / 1e12);
+                 Cc, Oc, Sc, Sc, Nc, v, mode == 0 ? "plain" : mode == 1 ? "fold" : mode == 2 ? "res" : "f+res", ms, flop / (ms * 1e-3) / 1e12,
+                 flop / (ms * 1e-3) / 1e12 / 1.573, (bytes + ((mode & 2) ? 4.0 * ey : 0.0)) / (ms * 1e-3) / 1e12);
           fflush(stdout);
         }
       }
