@@ -5040,7 +5040,7 @@ int dp_conv3x3_gn_fwd(const float *x, const float *wt, const float *ab, int N, i
 int dp_conv3x3_wino_fwd(const float *x, const float *wt, const float *ab, int N, int C, int O, int H, int W, float *y,
                         dp_stream_t stream) {
   DP_REQUIRE(x && wt && y && aligned16(x) && aligned16(wt) && aligned16(y));
-  DP_REQUIRE(N > 0 && C > 0 && C % kWnCh == 0 && O > 0 && O % kWnO == 0 && H == W);
+  DP_REQUIRE(N > 0 && C > 0 && C % (2 * kWnCh) == 0 && O > 0 && O % kWnO == 0 && H == W);     // an even number of K-chunks
   DP_REQUIRE(H == 56 || H == 28 || H == 14 || H == 7);
   DP_REQUIRE(!ab || (reinterpret_cast<uintptr_t>(ab) & 7u) == 0);
   DP_REQUIRE((long)N * C * H * W < (1L << 31) && (long)N * O * H * W < (1L << 31));      // 32-bit element offsets in the kernel

@@ -412,27 +412,29 @@ CONV3X3_WINO_SIDES = (56, 28, 14, 7)
 
 def conv3x3_wino_supported(x, weight, stride=(1, 1), padding=(1, 1)):
     """Shapes dp_conv3x3_wino_fwd takes: fp32 GPU NCHW, 3x3 / stride 1 / pad 1, square planes of side 56 / 28 / 14 / 7,
-    C % 4 == 0, O % 64 == 0."""
+    C % 8 == 0, O % 64 == 0."""
     return (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
             and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
             and x.shape[2] == x.shape[3] and x.shape[2] in CONV3X3_WINO_SIDES and weight.shape[1] == x.shape[1]
-            and weight.shape[1] % 4 == 0 and weight.shape[0] % 64 == 0
+            and weight.shape[1] % 8 == 0 and weight.shape[0] % 64 == 0
             and x.shape[0] * max(weight.shape[0], weight.shape[1]) * x.shape[2] * x.shape[3] < 2 ** 31)
 
 
 def pack_conv3x3_wino_weights(w, transpose=False):
     """(O, C, 3, 3) frozen weights -> U = G g G^T, the 4 x 4 Winograd-domain filter of F(2 x 2, 3 x 3), in
-    dp_conv3x3_wino_fwd's k-walk order [og][chunk][position 4 xi + nu][c][o] (output channel 64 og + o, input channel
-    4 chunk + c; include/dorpatch_hip.h).  Computed in fp64 and rounded once.  ``transpose``: the filter of the INPUT
+    dp_conv3x3_wino_fwd's OPERAND order [og][chunk][position 4 xi + nu][half][lane][k-step t][fragment f] (output channel
+    64 og + 32 f + lane, input channel 4 chunk + 2 t + half: the float4 a lane loads is its four A operands of a
+    (chunk, position); include/dorpatch_hip.h).  Computed in fp64 and rounded once.  ``transpose``: the filter of the INPUT
     GRADIENT (w'[c][o][kh][kw] = w[o][c][2 - kh][2 - kw]).  Once per frozen convolution."""
     w = w.detach().double()
     if transpose:
         w = w.transpose(0, 1).flip(2, 3)
     O, C = w.shape[0], w.shape[1]
-    assert w.shape[2:] == (3, 3) and C % 4 == 0 and O % 64 == 0
+    assert w.shape[2:] == (3, 3) and C % 8 == 0 and O % 64 == 0
     G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
-    U = torch.einsum("ai,ocij,bj->ocab", G, w, G).reshape(O // 64, 64, C // 4, 4, 16)
-    return U.permute(0, 2, 4, 3, 1).contiguous().float()
+    # (og, f, l, chunk, t, half, p): output channel 64 og + 32 f + l, input channel 4 chunk + 2 t + half
+    U = torch.einsum("ai,ocij,bj->ocab", G, w, G).reshape(O // 64, 2, 32, C // 4, 2, 2, 16)
+    return U.permute(0, 3, 6, 5, 2, 4, 1).contiguous().float()      # [og][chunk][p][half][l][t][f]
 
 
 def conv3x3_wino_fwd(x, wt, ab=None):
@@ -443,7 +445,7 @@ def conv3x3_wino_fwd(x, wt, ab=None):
     lib = _lib.load()
     _chk(x, torch.float32, "x"), _chk(wt, torch.float32, "wt")
     N, C, H, W = x.shape
-    O = wt.shape[0] * wt.shape[-1]
+    O = wt.shape[0] * 64
     assert wt.numel() == C * 16 * O, (wt.shape, C, O)
     y = torch.empty((N, O, H, W), dtype=torch.float32, device=x.device)
     if ab is not None:

@@ -526,7 +526,7 @@ def test_conv3x3_flat_pixel_tiles_are_bit_identical(N, C, O, S, G, small):
 
 CONV3X3_WINO_CASES = [   # (N, C, O, S, emulation-sized)
     (2, 8, 64, 14, True),       # 98 tiles: 3 full blocks of 32 + a ragged one, blocks that cross the image boundary, 2 K-chunks
-    (3, 4, 64, 7, True),        # odd side: 4 x 4 tiles cover 8 x 8, the overhang is not stored; ONE chunk
+    (3, 8, 64, 7, True),        # odd side: 4 x 4 tiles cover 8 x 8, the overhang is not stored; TWO chunks (the minimum)
     (1, 8, 128, 28, False),     # two output-channel groups
     (3, 64, 64, 56, False), (5, 128, 128, 28, False), (9, 256, 256, 14, False), (20, 512, 512, 7, False),   # ResNetV2-50's four
 ]
