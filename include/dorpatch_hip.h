@@ -246,7 +246,7 @@ int dp_project_update(const dp_update_cfg_t *cfg, const float *x,
 int dp_conv3x3_fwd(const float *x, const float *wt, int N, int C, int O, int H, int W, float *y, dp_stream_t stream);
 /* Round 6: the same convolution as Winograd F(2 x 2, 3 x 3) with its 16 position GEMMs on v_mfma_f32_32x32x2_f32 — 16
  * multiplications per 2 x 2 output tile instead of 36 (the route the reference's own library takes for a 3x3 convolution,
- * attack.py:222, 247 through the classifier).  H = W in {56, 28, 14, 7}, C % 8 == 0, O % 64 == 0; ab: NULL, or the (N,C,2)
+ * attack.py:222, 247 through the classifier).  H = W in {56, 28, 14, 7, 96, 48, 24, 12}, C % 8 == 0, O % 64 == 0; ab: NULL, or the (N,C,2)
  * coefficients of dp_gn_stats (the GroupNorm-apply + ReLU folded into the patch loads; the zero padding pads the normalised
  * activation).  wt = the WINOGRAD-DOMAIN filter U = G g G^T (4 x 4 per (o, c), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]),
  * pre-packed in the lanes' OPERAND order (dorpatch_amd/ops.py pack_conv3x3_wino_weights, computed in fp64, rounded once):

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 O=gpurun_out/r06j; mkdir -p $O
 timeout 900 python -m pytest tests/test_kernels_gpu.py -q -m gpu -k "winograd" -x 2>&1 | tail -5 | tee $O/pytest_wino.log
-timeout 900 python scripts/conv3x3_vs_miopen.py --wino 512 64 > $O/conv3x3_wino_vs_direct.jsonl 2> $O/conv3x3_wino.err; echo "wino rc=$?" | tee -a $O/rc.txt
+timeout 900 python scripts/conv3x3_vs_miopen.py --wino 512 > $O/conv3x3_wino_vs_direct.jsonl 2> $O/conv3x3_wino.err; echo "wino rc=$?" | tee -a $O/rc.txt
 python - $O/conv3x3_wino_vs_direct.jsonl <<'PY'
 import json,sys
 for l in open(sys.argv[1]):

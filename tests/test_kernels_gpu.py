@@ -529,6 +529,7 @@ CONV3X3_WINO_CASES = [   # (N, C, O, S, emulation-sized)
     (3, 8, 64, 7, True),        # odd side: 4 x 4 tiles cover 8 x 8, the overhang is not stored; TWO chunks (the minimum)
     (1, 8, 128, 28, False),     # two output-channel groups
     (3, 64, 64, 56, False), (5, 128, 128, 28, False), (9, 256, 256, 14, False), (20, 512, 512, 7, False),   # ResNetV2-50's four
+    (1, 64, 64, 96, False), (2, 128, 128, 48, False), (3, 8, 64, 24, False), (5, 8, 64, 12, True),          # 384 x 384 inputs
 ]
 
 
