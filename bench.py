@@ -816,6 +816,10 @@ def main(argv=None):
                                     "samples_back_propagated": loop.n_backward, "tape_micro_batches": loop._tape_tabs,
                                     "step_ms": step_ms, "samples_with_gradient_each_step": active_each},
                        "conv3x3": libconv.report_conv3x3(),
+                       "conv3x3_winograd": {"mode": libconv.CONV3X3_WINO, "problems": len(libconv._used_wino),
+                                            "note": "stride-1 3x3 problems on own kernels run as Winograd F(2x2,3x3) on the "
+                                                    "matrix cores (dp_conv3x3_wino_fwd): fp32, fixed order; effective TFLOP/s of "
+                                                    "k_conv3x3_wino in roofline_conv count the direct form's 18 N HW C O flop"},
                        "conv1x1": dict(mode=args.conv1x1, gemm_solutions=conv1x1.report_tuned(),
                                        tuned_selftest=conv1x1.selftest_report(), **conv1x1.report()),
                        "parallelism": "eot-sample sharding x%d, 1 all-reduce per step (patch gradient + loss slabs)%s"

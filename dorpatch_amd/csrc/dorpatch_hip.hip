@@ -3890,11 +3890,17 @@ __global__ __launch_bounds__(kBlock, C1Geom<NQ>::MW) void k_conv1x1_mfma(C1Args 
 // but 8 workgroups of 4 waves are ALL 32 wave slots of a CU, so nothing of the step's other stream runs beside them: the
 // two-stream step (the product's) went 357.8 -> 363.5 ms (profiles/r06f_bench_*.json, 3 interleaved runs each).  At large
 // grids the fold therefore keeps the 448-pixel tile as well; ties go to the larger tile.
+// Once the largest tile already fills the chip (>= 512 workgroups) the small tiles pay for their occupancy as well: 8 (64-pixel)
+// or 5 - 6 (128-pixel) workgroups per CU take most of the CU's 32 wave slots, and the step's other stream stops running beside
+// them — 1024 -> 256 @14x14 at N = 512 wins 8 % on 64-pixel tiles alone (3.5 rounds of 448-pixel tiles become 24.5 of 64) and
+// the two-stream step loses 0.7 % (325.3 / 327.7 vs 329.2 / 328.1 ms, profiles/r06m_bench_s2*.json).
 static int pick_tile(const int *cand, const float *pen, int n, const long *wgs) {
   int best = cand[0];
   float best_cost = 0.f;
+  const bool filled = wgs[0] >= 512;
   for (int i = 0; i < n; ++i) {
-    const float cost = (float)((wgs[i] + 255) / 256) * (float)cand[i] * pen[i];
+    float cost = (float)((wgs[i] + 255) / 256) * (float)cand[i] * pen[i];
+    if (filled && cand[i] <= 2) cost *= cand[i] == 1 ? 1.12f : 1.05f;
     if (i == 0 || cost < best_cost * 0.999f) best = cand[i], best_cost = cost;
   }
   return best;

@@ -182,7 +182,7 @@ def main():
                 print(json.dumps(one_flat(N, C, S)), flush=True)
             continue
         if "--wino" in sys.argv:
-            for C, S in SHAPES:
+            for C, S in (SHAPES_384 if "--384" in sys.argv else SHAPES):
                 print(json.dumps(one_wino(N, C, S)), flush=True)
             continue
         if "--stride2" in sys.argv:

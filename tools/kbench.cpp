@@ -404,14 +404,14 @@ int main(int argc, char **argv) {
     for (int si = 0; si < 4; ++si) {
       const int Cc = big ? shapes384[si][0] : shapes224[si][0], Sc = big ? shapes384[si][1] : shapes224[si][1];
       const size_t e = (size_t)Nc * Cc * Sc * Sc;
-      float *cx = (float *)dmalloc(e * 4), *cy = (float *)dmalloc(e * 4), *cw = (float *)dmalloc((size_t)Cc * Cc * 9 * 4);
+      float *cx = (float *)dmalloc(e * 4), *cy = (float *)dmalloc(e * 4), *cw = (float *)dmalloc((size_t)Cc * Cc * 16 * 4);   // 16: room for the Winograd-domain filter
       float *cab = (float *)dmalloc((size_t)Nc * Cc * 2 * 4);
       hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, st, (f4 *)cx, e / 4, 0.37f);
-      hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, st, (f4 *)cw, (size_t)Cc * Cc * 9 / 4, 0.01f);
+      hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, st, (f4 *)cw, (size_t)Cc * Cc * 16 / 4, 0.01f);
       hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, st, (f4 *)cab, (size_t)Nc * Cc * 2 / 4, 0.5f);
       const double flop = 2.0 * Nc * Sc * Sc * (double)Cc * Cc * 9;
       // $DP_C3_VARIANTS = values of DP_DEBUG_CONV3X3_VARIANT to run (default: 1 = k_conv3x3_mfma, 2 = k_conv3x3_flat; round 6:
-      // 16 / 48 / 64 = k_conv3x3_flat with 448- / 128- / 64-pixel tiles, 0 = the launcher's own choice)
+      // 16 / 48 / 64 = k_conv3x3_flat with 448- / 128- / 64-pixel tiles, 0 = the launcher's own choice, 1000 = dp_conv3x3_wino_fwd)
       std::vector<int> c3v;
       if (const char *ev = getenv("DP_C3_VARIANTS")) {
         int v, n = 0;
@@ -420,16 +420,18 @@ int main(int argc, char **argv) {
         for (int v = big ? 2 : 1; v <= 2; ++v) c3v.push_back(v);
       }
       for (int variant : c3v) {
-        if ((variant & 3) == 1 && big) continue;
-        DP(dp_debug_set(DP_DEBUG_CONV3X3_VARIANT, variant));
+        if ((variant & 3) == 1 && big && variant != 1000) continue;
+        const bool wino = variant == 1000;          // round 6: dp_conv3x3_wino_fwd (Winograd F(2x2, 3x3) on the matrix cores)
+        if (!wino) DP(dp_debug_set(DP_DEBUG_CONV3X3_VARIANT, variant));
         for (int fold = 0; fold < 2; ++fold) {
-          if (fold && Sc == 7) continue;
+          if (fold && Sc == 7 && !wino) continue;
           for (int rep = 0; rep < 2; ++rep) {
             hipEvent_t e0, e1;
             CK(hipEventCreate(&e0));
             CK(hipEventCreate(&e1));
             auto run = [&]() {
-              if (fold) DP(dp_conv3x3_gn_fwd(cx, cw, cab, Nc, Cc, Cc, Sc, Sc, cy, st));
+              if (wino) DP(dp_conv3x3_wino_fwd(cx, cw, fold ? cab : nullptr, Nc, Cc, Cc, Sc, Sc, cy, st));
+              else if (fold) DP(dp_conv3x3_gn_fwd(cx, cw, cab, Nc, Cc, Cc, Sc, Sc, cy, st));
               else DP(dp_conv3x3_fwd(cx, cw, Nc, Cc, Cc, Sc, Sc, cy, st));
               return 0;
             };
@@ -443,6 +445,7 @@ int main(int argc, char **argv) {
             ms /= iters;
             printf("dp_conv3x3_fwd %3d->%3d @%2dx%2d N=%d %s %s  %8.4f ms  %7.1f TFLOP/s  (%.1f%% of the 157.3 TFLOP/s f32 peak)\n",
                    Cc, Cc, Sc, Sc, Nc, variant == 1 ? "k_conv3x3_mfma" : variant == 2 ? "k_conv3x3_flat" : variant == 0 ? "auto          " :
+                   variant == 1000 ? "k_conv3x3_wino" :
                    variant == 16 ? "flat 448px    " : variant == 48 ? "flat 128px    " : variant == 64 ? "flat  64px    " : "other         ",
                    fold ? "fold " : "plain", ms,
                    flop / (ms * 1e-3) / 1e12, flop / (ms * 1e-3) / 1e12 / 1.573);
