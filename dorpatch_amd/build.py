@@ -40,21 +40,47 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_extension(force=False, verbose=False):
-    """Compile the HIP kernels + C ABI. Returns the path of the shared library."""
+PARTS = (1, 2, 3, 4)     # -DDP_PART values: the one source is four translation units (csrc/dorpatch_hip.hip, top), compiled in parallel
+
+
+def build_extension(force=False, verbose=False, jobs=None):
+    """Compile the HIP kernels + C ABI. Returns the path of the shared library.
+
+    Round 6: the source is compiled as four translation units (kernel families, ``-DDP_PART=1..4``) by
+    concurrent hipcc processes and the objects are linked into the one library — 30 s of wall time instead of 75 on the
+    8-core build container."""
     if not force and not needs_build():
         return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIB_DIR, exist_ok=True)
-    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INCLUDE, SRC, "-o", tmp]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        if os.path.exists(tmp):
-            os.remove(tmp)
-        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    os.replace(tmp, LIB_PATH)
+    tag = "%d" % os.getpid()
+    tmp = LIB_PATH + ".tmp." + tag
+    compile_flags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-Wno-unused-function", "-Wno-unused-const-variable"]
+    objs = [os.path.join(LIB_DIR, "part%d.%s.o" % (k, tag)) for k in PARTS]
+
+    def compile_part(k, obj):
+        cmd = [_hipcc()] + compile_flags + ["-I", INCLUDE, "-DDP_PART=%d" % k, "-c", SRC, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        return subprocess.run(cmd, capture_output=True, text=True)
+
+    try:
+        with ThreadPoolExecutor(max_workers=jobs or min(len(PARTS), os.cpu_count() or 1)) as pool:
+            results = list(pool.map(compile_part, PARTS, objs))
+        bad = [r for r in results if r.returncode != 0]
+        if bad:
+            raise RuntimeError("hipcc failed:\n" + "\n".join(r.stdout + r.stderr for r in bad))
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc (link) failed:\n" + res.stdout + res.stderr)
+        os.replace(tmp, LIB_PATH)
+    finally:
+        for f in objs + [tmp]:
+            if os.path.exists(f):
+                os.remove(f)
     return LIB_PATH
 
 

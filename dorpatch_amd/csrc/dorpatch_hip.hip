@@ -23,6 +23,32 @@
 
 #include "dorpatch_hip.h"
 
+// One source, four translation units (round 6).  The product build (dorpatch_amd/build.py) compiles this file
+// four times IN PARALLEL with -DDP_PART=1..4 — 1: the DorPatch arithmetic, GroupNorm, pooling, the stem; 2: the direct 3x3
+// family (k_conv3x3_mfma / _flat, both stride-2 kernels); 3: k_conv1x1_mfma; 4: the Winograd 3x3 kernel (conv3x3_wino.inc) —
+// and links the objects into the one libdorpatch_hip.so; every kernel and its extern "C" entry point live in the same part.
+// DP_PART = 0 (the default: tools/kbench's white-box include, the host emulation) is the whole library in one unit.
+#ifndef DP_PART
+#define DP_PART 0
+#endif
+#define DP_HAS(part) (DP_PART == 0 || DP_PART == (part))
+
+// dp_debug_set knobs (include/dorpatch_hip.h): launch-geometry overrides for tests / A-B runs, 0 = the product's choice.
+// Defined in part 1 (where dp_debug_set lives), read by the launchers of every part.
+namespace dp_state {
+#if DP_HAS(1)
+__attribute__((visibility("hidden"))) int g_aff_samples_per_block = 0;   // DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK (tools/kbench sweeps it too)
+__attribute__((visibility("hidden"))) int g_update_variant = 0;          // DP_DEBUG_UPDATE_VARIANT
+__attribute__((visibility("hidden"))) int g_apply_order = 0;             // DP_DEBUG_APPLY_ORDER
+__attribute__((visibility("hidden"))) int g_aff_gather = 0;              // DP_DEBUG_AFFINE_GATHER
+__attribute__((visibility("hidden"))) int g_conv1x1_variant = 0;         // DP_DEBUG_CONV1X1_VARIANT: bits 0-1 workgroup map, bit 2 non-temporal stores, bit 3 LDS staging in one lump, bits 4-6 forced pixel tile
+__attribute__((visibility("hidden"))) int g_conv3x3_variant = 0;         // DP_DEBUG_CONV3X3_VARIANT: bits 0-1: 0 per-side default, 1 k_conv3x3_mfma wherever it applies, 2 k_conv3x3_flat everywhere; bits 4-6 forced pixel tile
+#else
+extern int g_aff_samples_per_block, g_update_variant, g_apply_order, g_aff_gather, g_conv1x1_variant, g_conv3x3_variant;
+#endif
+}  // namespace dp_state
+using namespace dp_state;
+
 namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -30,14 +56,6 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef int i4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBlock = 256;  // threads per workgroup: 4 waves of 64
-
-// dp_debug_set knobs (include/dorpatch_hip.h): launch-geometry overrides for tests / A-B runs, 0 = the product's choice
-int g_aff_samples_per_block = 0;   // DP_DEBUG_AFFINE_SAMPLES_PER_BLOCK (tools/kbench sweeps it too)
-int g_update_variant = 0;          // DP_DEBUG_UPDATE_VARIANT
-int g_apply_order = 0;             // DP_DEBUG_APPLY_ORDER
-int g_aff_gather = 0;              // DP_DEBUG_AFFINE_GATHER
-int g_conv1x1_variant = 0;         // DP_DEBUG_CONV1X1_VARIANT: bits 0-1 workgroup map, bit 2 non-temporal stores, bit 3 LDS staging in one lump, bits 4-6 forced pixel tile
-int g_conv3x3_variant = 0;         // DP_DEBUG_CONV3X3_VARIANT: bits 0-1: 0 per-side default, 1 k_conv3x3_mfma wherever it applies, 2 k_conv3x3_flat everywhere; bits 4-6 forced pixel tile
 
 // Register-allocation hint: the compiler must forget what it knows about a lane-private value (so that it re-derives
 // addresses / predicates from it instead of keeping dozens of them alive).  No semantics; empty in the host emulation.
@@ -93,6 +111,7 @@ __device__ __forceinline__ float sgn(float v) {
   return (float)((v > 0.f) - (v < 0.f));
 }
 
+#if DP_HAS(1)      // ---------------------------------------------------------------- part 1 begins
 // ----------------------------------------------------------------------------
 // a-2: sumsq partials + blend
 // ----------------------------------------------------------------------------
@@ -3120,6 +3139,7 @@ int launch_apply_fwd(int variant, const float *adv_x, const int32_t *table, int 
 }
 
 
+#endif             // ---------------------------------------------------------------- part 1 pauses (shared conv helpers follow)
 // ----------------------------------------------------------------------------
 // a-8 (round 4): the backbone's 3 x 3 / stride 1 / pad 1 convolutions on the matrix cores.
 // MIOpen runs them as fp32 Winograd on the VALUs (64 -> 64 @56^2, N = 512: 1.09 ms = 108 TFLOP/s effective); this is
@@ -3195,6 +3215,7 @@ template <> struct CvVec<4> { typedef f4 T; };
 template <> struct CvVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
 template <> struct CvVec<1> { typedef float T; };
 
+#if DP_HAS(2)      // ---------------------------------------------------------------- part 2 begins
 // FOLD (round 5): x is the RAW input of a GroupNorm + ReLU; max(x * a + b, 0) with the (N, C, 2) coefficients `ab` that
 // dp_gn_stats wrote is applied between the global load and the LDS store (dp_gn_relu_fwd's own expression: bit-identical
 // to normalising first).  Halo rows / the rows between images stay exactly zero (their coefficients are (0, 0)): the
@@ -3585,6 +3606,7 @@ __global__ __launch_bounds__(kBlock, (NQ >= 6 ? 2 : 4)) void k_conv3x3s2_mfma(co
   }
 }
 
+#endif             // ---------------------------------------------------------------- part 2 pauses
 // ----------------------------------------------------------------------------
 // a-8 (round 5, VERDICT r4 items 1 + 2): the backbone's 1 x 1 / stride 1 convolutions on the matrix cores — 33 of
 // ResNetV2-50's 53 convolutions, 17.4 of the 33.5 TFLOP of a configs[1] step, until now Tensile / MIOpen NHWC kernels.
@@ -3632,6 +3654,34 @@ struct C1Geom {
   static_assert(IT * 4 * kBlock == IN, "NQ activation float4 per thread");
 };
 
+// Which pixel tile runs a problem (round 6).  Every tile gives the same bits, so this is a pure scheduling decision.
+// Model, fitted to the measured sweeps (profiles/r06b_kbench_conv1x1_tiles_n{32..512}.txt, r06c_kbench_conv3x3_tiles_*):
+// a workgroup's time is proportional to its NQ MFMAs per k-step (whatever its idle lanes), the 256 CUs share the
+// workgroups evenly, so   cost(NQ) = ceil(workgroups(NQ) / 256) * NQ * penalty(NQ)   — e.g. 1024 -> 256 @14x14, N = 64:
+// 112 workgroups of 448 pixels cost 1 * 7, 392 of 128 pixels 2 * 2 (measured 55 vs 96 TFLOP/s); 2048 -> 512 @7x7,
+// N = 512: 456 x 7 -> 14 against 824 x 4 -> 16 (116 vs 103).  The penalties are what is left at large grids: the 448-pixel
+// tile is 4 - 8 % ahead for plain / residual launches (fewer barriers and weight re-reads per flop).  Launches with the
+// GroupNorm fold in the staging run FASTER stand-alone with 64-pixel tiles (8 workgroups per CU hide the apply's VALU + the
+// extra request: 1024 -> 512 120 vs 108, 512 -> 128 116 vs 105 TFLOP/s at N = 512; the one-stream step 375.9 -> 373.1 ms) —
+// but 8 workgroups of 4 waves are ALL 32 wave slots of a CU, so nothing of the step's other stream runs beside them: the
+// two-stream step (the product's) went 357.8 -> 363.5 ms (profiles/r06f_bench_*.json, 3 interleaved runs each).  At large
+// grids the fold therefore keeps the 448-pixel tile as well; ties go to the larger tile.
+// Once the largest tile already fills the chip (>= 512 workgroups) the small tiles pay for their occupancy as well: 8 (64-pixel)
+// or 5 - 6 (128-pixel) workgroups per CU take most of the CU's 32 wave slots, and the step's other stream stops running beside
+// them — 1024 -> 256 @14x14 at N = 512 wins 8 % on 64-pixel tiles alone (3.5 rounds of 448-pixel tiles become 24.5 of 64) and
+// the two-stream step loses 0.7 % (325.3 / 327.7 vs 329.2 / 328.1 ms, profiles/r06m_bench_s2*.json).
+static int pick_tile(const int *cand, const float *pen, int n, const long *wgs) {
+  int best = cand[0];
+  float best_cost = 0.f;
+  const bool filled = wgs[0] >= 512;
+  for (int i = 0; i < n; ++i) {
+    float cost = (float)((wgs[i] + 255) / 256) * (float)cand[i] * pen[i];
+    if (filled && cand[i] <= 2) cost *= cand[i] == 1 ? 1.12f : 1.05f;
+    if (i == 0 || cost < best_cost * 0.999f) best = cand[i], best_cost = cost;
+  }
+  return best;
+}
+#if DP_HAS(3)      // ---------------------------------------------------------------- part 3 begins
 struct C1Args {
   const float *x, *wt;
   const float *ab;      // FOLD: (N, C, 2) coefficients of the fused GroupNorm + ReLU on the input
@@ -3878,33 +3928,6 @@ __global__ __launch_bounds__(kBlock, C1Geom<NQ>::MW) void k_conv1x1_mfma(C1Args 
   }
 }
 
-// Which pixel tile runs a problem (round 6).  Every tile gives the same bits, so this is a pure scheduling decision.
-// Model, fitted to the measured sweeps (profiles/r06b_kbench_conv1x1_tiles_n{32..512}.txt, r06c_kbench_conv3x3_tiles_*):
-// a workgroup's time is proportional to its NQ MFMAs per k-step (whatever its idle lanes), the 256 CUs share the
-// workgroups evenly, so   cost(NQ) = ceil(workgroups(NQ) / 256) * NQ * penalty(NQ)   — e.g. 1024 -> 256 @14x14, N = 64:
-// 112 workgroups of 448 pixels cost 1 * 7, 392 of 128 pixels 2 * 2 (measured 55 vs 96 TFLOP/s); 2048 -> 512 @7x7,
-// N = 512: 456 x 7 -> 14 against 824 x 4 -> 16 (116 vs 103).  The penalties are what is left at large grids: the 448-pixel
-// tile is 4 - 8 % ahead for plain / residual launches (fewer barriers and weight re-reads per flop).  Launches with the
-// GroupNorm fold in the staging run FASTER stand-alone with 64-pixel tiles (8 workgroups per CU hide the apply's VALU + the
-// extra request: 1024 -> 512 120 vs 108, 512 -> 128 116 vs 105 TFLOP/s at N = 512; the one-stream step 375.9 -> 373.1 ms) —
-// but 8 workgroups of 4 waves are ALL 32 wave slots of a CU, so nothing of the step's other stream runs beside them: the
-// two-stream step (the product's) went 357.8 -> 363.5 ms (profiles/r06f_bench_*.json, 3 interleaved runs each).  At large
-// grids the fold therefore keeps the 448-pixel tile as well; ties go to the larger tile.
-// Once the largest tile already fills the chip (>= 512 workgroups) the small tiles pay for their occupancy as well: 8 (64-pixel)
-// or 5 - 6 (128-pixel) workgroups per CU take most of the CU's 32 wave slots, and the step's other stream stops running beside
-// them — 1024 -> 256 @14x14 at N = 512 wins 8 % on 64-pixel tiles alone (3.5 rounds of 448-pixel tiles become 24.5 of 64) and
-// the two-stream step loses 0.7 % (325.3 / 327.7 vs 329.2 / 328.1 ms, profiles/r06m_bench_s2*.json).
-static int pick_tile(const int *cand, const float *pen, int n, const long *wgs) {
-  int best = cand[0];
-  float best_cost = 0.f;
-  const bool filled = wgs[0] >= 512;
-  for (int i = 0; i < n; ++i) {
-    float cost = (float)((wgs[i] + 255) / 256) * (float)cand[i] * pen[i];
-    if (filled && cand[i] <= 2) cost *= cand[i] == 1 ? 1.12f : 1.05f;
-    if (i == 0 || cost < best_cost * 0.999f) best = cand[i], best_cost = cost;
-  }
-  return best;
-}
 // DP_DEBUG_CONV1X1_VARIANT bits 4-6 force a tile for A/B runs (1: 448, 2: 256, 3: 128, 4: 64).
 static long conv1x1_tiles(long N, int HW, bool flat, int nq) {
   const int pix = 64 * nq;
@@ -3963,6 +3986,8 @@ int launch_conv1x1(C1Args A, bool flat, hipStream_t st) {
   return launch_status();
 }
 
+#endif             // ---------------------------------------------------------------- part 3 pauses
+#if DP_HAS(2)      // ---------------------------------------------------------------- part 2 resumes
 // ----------------------------------------------------------------------------
 // a-8 (round 5): the 3 x 3 MFMA walk over a FLAT LDS image with MASKED taps.
 // k_conv3x3_mfma lays the input rows out in LDS with explicit zero rows / columns, which ties it to planes that tile 448
@@ -4507,6 +4532,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv3x3s2_dgrad2(CfArgs A) {
   else cf2_body<G0>(lds, A, A.wt + 6 * (size_t)A.C * A.O, tile, og);
 }
 
+#endif             // ---------------------------------------------------------------- part 2 pauses
+#if DP_HAS(1)      // ---------------------------------------------------------------- part 1 resumes
 // ----------------------------------------------------------------------------
 // a-8 (round 5): the STEM convolution (3 -> 64 channels, 7 x 7 / stride 2 / pad 3, 224 -> 112) on the matrix cores.
 // MIOpen runs it as a stride-2 Winograd (miopenSp3AsmConv_v30_3_1_gfx9_fp32_f3x2_stride2: 2.31 ms per 512 images = 52
@@ -4643,7 +4670,10 @@ int launch_stem_dgrad(int variant, const float *dy, const float *w, int N, int K
   return launch_status();
 }
 
+#endif             // ---------------------------------------------------------------- part 1 pauses
+#if DP_HAS(4)
 #include "conv3x3_wino.inc"      // round 6: Winograd F(2x2, 3x3) on the matrix cores (its own file: VERDICT r5 item 8)
+#endif
 
 }  // namespace
 
@@ -4653,6 +4683,7 @@ int launch_stem_dgrad(int variant, const float *dy, const float *w, int N, int K
 
 extern "C" {
 
+#if DP_HAS(1)
 int dp_abi_version(void) { return DP_ABI_VERSION; }
 
 const char *dp_error_string(int err) { return hipGetErrorString((hipError_t)err); }
@@ -4940,6 +4971,8 @@ int dp_project_update(const dp_update_cfg_t *cfg, const float *x, const float *a
   return launch_status();
 }
 
+#endif   // part 1
+#if DP_HAS(2)
 // Which kernel runs a stride-1 3x3 problem of side H: k_conv3x3_mfma (explicit zero rows / columns in LDS; sides 56 / 28 / 14 /
 // 7) or k_conv3x3_flat (flat image, masked taps; any of the sides below).  Same packed weights, same summation order, same
 // bits.  Default: the measured winner per side (profiles/r05j_*); DP_DEBUG_CONV3X3_VARIANT forces one for A/B runs.
@@ -5043,6 +5076,8 @@ int dp_conv3x3_gn_fwd(const float *x, const float *wt, const float *ab, int N, i
   return conv3x3_launch(x, wt, ab, N, C, O, H, W, y, stream);
 }
 
+#endif   // part 2
+#if DP_HAS(4)
 int dp_conv3x3_wino_fwd(const float *x, const float *wt, const float *ab, int N, int C, int O, int H, int W, float *y,
                         dp_stream_t stream) {
   DP_REQUIRE(x && wt && y && aligned16(x) && aligned16(wt) && aligned16(y));
@@ -5053,6 +5088,8 @@ int dp_conv3x3_wino_fwd(const float *x, const float *wt, const float *ab, int N,
   return launch_conv3x3_wino(x, wt, ab, N, C, O, H, y, as_stream(stream));
 }
 
+#endif   // part 4
+#if DP_HAS(2)
 int dp_conv3x3s2_fwd(const float *x, const float *wt, const float *ab, int N, int C, int O, int H, int W, float *y,
                      dp_stream_t stream) {
   DP_REQUIRE(x && wt && y && aligned16(x) && aligned16(wt) && aligned16(y));
@@ -5137,6 +5174,8 @@ int dp_conv3x3s2_bwd(const float *dy, const float *wt, int N, int O, int C, int 
   return launch_status();
 }
 
+#endif   // part 2
+#if DP_HAS(1)
 int dp_stem_conv_fwd(const float *x, const float *wt, int N, int H, int W, float *y, dp_stream_t stream) {
   DP_REQUIRE(x && wt && y && aligned16(x) && aligned16(wt) && aligned16(y));
   DP_REQUIRE(N > 0 && W == kStW && H > 0 && H % 2 == 0);
@@ -5146,6 +5185,8 @@ int dp_stem_conv_fwd(const float *x, const float *wt, int N, int H, int W, float
   return launch_status();
 }
 
+#endif   // part 1
+#if DP_HAS(3)
 int dp_conv1x1_fwd(const float *x, const float *wt, const float *ab, const float *res, int N, int C, int O, int HW,
                    float *y, dp_stream_t stream) {
   DP_REQUIRE(x && wt && y && aligned16(x) && aligned16(wt) && aligned16(y));
@@ -5163,6 +5204,8 @@ int dp_conv1x1_fwd(const float *x, const float *wt, const float *ab, const float
   return launch_conv1x1(A, flat, as_stream(stream));
 }
 
+#endif   // part 3
+#if DP_HAS(1)
 int dp_argmax(const float *logits, int N, int C, int32_t *pred, dp_stream_t stream) {
   DP_REQUIRE(logits && pred && N > 0 && C > 0);
   hipLaunchKernelGGL(k_argmax, dim3(cdiv(N, kBlock / 64)), dim3(kBlock), 0, as_stream(stream),
@@ -5347,5 +5390,7 @@ int dp_apply_fwd_timed(const float *adv_x, const int32_t *table, int R, const in
   return launch_apply_fwd(kApplyFwdDefaultVariant, adv_x, table, R, idx, idx2, idx_bstride, B, S, H, W,
                           norm, out, stream, (hipEvent_t)start, (hipEvent_t)stop);
 }
+
+#endif   // part 1
 
 }  // extern "C"
