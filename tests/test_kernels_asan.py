@@ -77,12 +77,14 @@ def test_kernel_suite_is_clean_under_address_sanitizer():
     else:
         # ... and, of the matrix-core convolution kernels (a 448-pixel x 64-channel MFMA tile costs the fibre emulation under
         # ASan a minute), ONE emulation-sized case per kernel: the others run in the plain emulation suite and on the GPU
+        # (round 6: the pixel-tile bit-identity sweeps launch every tile of every mode — the tiles themselves are covered here by
+        # the kept cases below, whose `auto` / `64px` parameters run the small-tile instantiations; one Winograd case, the odd side)
         mfma = ("on_the_matrix_cores or conv3x3_flat_kernel or conv3x3_with_folded or conv1x1_with_folded or "
-                "conv1x1_launch_variants")
+                "conv1x1_launch_variants or pixel_tiles")
         keep = ("(conv3x3_on_the_matrix_cores and 10-8-128-7) or (conv3x3_flat_kernel and 11-8-64-7) or "
                 "(stride2_input_gradient and 2-16-64-14) or (stem_convolution and 2-6-True) or "
                 "(conv3x3_stride2_on and 10-8-128-14) or (conv1x1_on_the_matrix_cores and 1-16-64-28) or "
-                "(conv1x1_with_folded and 1-64-64-28)")
+                "(conv1x1_with_folded and 1-64-64-28) or (winograd and 3-8-64-7)")
         select = ["-k", "not resnetv2_fused and not (add_gn_relu_fusion and (shape0 or shape1)) and (not (%s) or %s)"
                         % (mfma, keep)]
     res = subprocess.run([sys.executable, "-m", "pytest"] + files + ["-q", "-x", "-p", "no:cacheprovider"] + select,
