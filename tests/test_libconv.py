@@ -168,5 +168,6 @@ def test_round5_weight_packings_and_routes():
     assert float(ps[10, :, 1].abs().max()) == 0.0
     # the committed route table knows the 384-input planes (round 5) and keeps the 224 ones
     assert libconv.CONV3X3_TABLE[64].get(("fwd", 64, 96)) == "mfma" and libconv.CONV3X3_TABLE[512].get(("bwd", 512, 7)) == "mfma"
-    assert libconv.CONV3X3_TABLE[64].get(("fwd", 512, 12)) is None
+    # round 6: with the Winograd kernel every 384-input shape is routed from 64 rows up (32 rows: 224-input shapes only)
+    assert libconv.CONV3X3_TABLE[64].get(("fwd", 512, 12)) == "mfma" and libconv.CONV3X3_TABLE[32].get(("fwd", 512, 12)) is None
     assert libconv.CONV3X3S2_BWD in ("on", "off") and libconv.STEM_CONV in ("on", "off")
