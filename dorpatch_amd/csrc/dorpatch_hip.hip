@@ -23,11 +23,13 @@
 
 #include "dorpatch_hip.h"
 
-// One source, four translation units (round 6).  The product build (dorpatch_amd/build.py) compiles this file
-// four times IN PARALLEL with -DDP_PART=1..4 — 1: the DorPatch arithmetic, GroupNorm, pooling, the stem; 2: the direct 3x3
-// family (k_conv3x3_mfma / _flat, both stride-2 kernels); 3: k_conv1x1_mfma; 4: the Winograd 3x3 kernel (conv3x3_wino.inc) —
-// and links the objects into the one libdorpatch_hip.so; every kernel and its extern "C" entry point live in the same part.
-// DP_PART = 0 (the default: tools/kbench's white-box include, the host emulation) is the whole library in one unit.
+// One library, one file per kernel family, five translation units (round 6).  This file holds what the
+// families share (macros, reductions, the debug knobs) and the list of family files below; the product build
+// (dorpatch_amd/build.py) compiles it five times IN PARALLEL with -DDP_PART=1..5 — 1: apply.inc + update.inc (the DorPatch
+// arithmetic), gn.inc, stem.inc; 2: conv3x3.inc (direct 3x3, stride 1); 3: conv1x1.inc; 4: conv3x3_wino.inc; 5: conv3x3s2.inc
+// (stride-2 3x3 and its input gradient) — and links the objects into the one libdorpatch_hip.so; a kernel, its launcher and
+// its extern "C" entry point live in the same file.  DP_PART = 0 (the default: tools/kbench's white-box include, the host
+// emulation of tests/hipemu) is the whole library in one unit.
 #ifndef DP_PART
 #define DP_PART 0
 #endif
@@ -111,4579 +113,36 @@ __device__ __forceinline__ float sgn(float v) {
   return (float)((v > 0.f) - (v < 0.f));
 }
 
-#if DP_HAS(1)      // ---------------------------------------------------------------- part 1 begins
-// ----------------------------------------------------------------------------
-// a-2: sumsq partials + blend
-// ----------------------------------------------------------------------------
-
-constexpr int kSumsqGroupsPerThread = 4;                                // float4 groups
-constexpr int kSumsqPixPerBlock = kBlock * kSumsqGroupsPerThread * 4;   // 4096 pixels
-
-__global__ __launch_bounds__(kBlock) void k_sumsq_partials(
-    const float *__restrict__ mask, const float *__restrict__ pattern,
-    const float *__restrict__ x, int P, int nchunk, float *__restrict__ partials) {
-  __shared__ float sm4[4];
-  const int b = blockIdx.y, chunk = blockIdx.x;
-  const int P4 = P >> 2;
-  const f4 *m4 = reinterpret_cast<const f4 *>(mask + (size_t)b * P);
-  const f4 *p4 = reinterpret_cast<const f4 *>(pattern + (size_t)b * 3 * P);
-  const f4 *x4 = reinterpret_cast<const f4 *>(x + (size_t)b * 3 * P);
-  float acc = 0.f;
-#pragma unroll
-  for (int k = 0; k < kSumsqGroupsPerThread; ++k) {
-    const int g = (chunk * kSumsqGroupsPerThread + k) * kBlock + threadIdx.x;
-    if (g < P4) {
-      const f4 m = m4[g];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const f4 d = m * (p4[c * P4 + g] - x4[c * P4 + g]);
-        acc += d.x * d.x;
-        acc += d.y * d.y;
-        acc += d.z * d.z;
-        acc += d.w * d.w;
-      }
-    }
-  }
-  const float tot = block_sum(acc, sm4);
-  if (threadIdx.x == 0) partials[(size_t)b * nchunk + chunk] = tot;
-}
-
-__global__ __launch_bounds__(kBlock) void k_blend(
-    const float *__restrict__ mask, const float *__restrict__ pattern,
-    const float *__restrict__ x, const float *__restrict__ partials, int nchunk,
-    float eps, int P, int add_x, float *__restrict__ adv_x, float *__restrict__ scale_out,
-    float *__restrict__ l2_out) {
-  const int b = blockIdx.y;
-  // every block re-derives the per-image scale from the partials in a fixed order
-  float tot = 0.f;
-  for (int k = 0; k < nchunk; ++k) tot += partials[(size_t)b * nchunk + k];
-  const float l2 = sqrtf(tot);
-  const float s = fminf(eps / l2, 1.f);  // eps/0 = inf -> 1 (torch.clip(max=1))
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    scale_out[b] = s;
-    l2_out[b] = l2;
-  }
-  const int P4 = P >> 2;
-  const int g = blockIdx.x * kBlock + threadIdx.x;
-  if (g >= P4) return;
-  const f4 m = reinterpret_cast<const f4 *>(mask + (size_t)b * P)[g];
-  const f4 *p4 = reinterpret_cast<const f4 *>(pattern + (size_t)b * 3 * P);
-  const f4 *x4 = reinterpret_cast<const f4 *>(x + (size_t)b * 3 * P);
-  f4 *o4 = reinterpret_cast<f4 *>(adv_x + (size_t)b * 3 * P);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const f4 xv = x4[c * P4 + g];
-    const f4 d = m * (p4[c * P4 + g] - xv);
-    o4[c * P4 + g] = add_x ? d * s + xv : d * s;
-  }
-}
-
-// ----------------------------------------------------------------------------
-// a-4 / a-10: occlusion apply, forward and backward
-// ----------------------------------------------------------------------------
-
-// Bit j of the result is set iff pixel (h, w+j) lies inside any of the R windows
-// of table entry m.  The window coordinates are wave-uniform (scalar loads).
-__device__ __forceinline__ unsigned occluded4(const int32_t *__restrict__ table, int R,
-                                              int m, int h, int w) {
-  unsigned occ = 0u;
-  const int32_t *t = table + (size_t)m * R * 4;
-  for (int r = 0; r < R; ++r) {
-    const int r0 = t[4 * r + 0], r1 = t[4 * r + 1], c0 = t[4 * r + 2], c1 = t[4 * r + 3];
-    if (h >= r0 && h < r1) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) occ |= (unsigned)((w + j >= c0) & (w + j < c1)) << j;
-    }
-  }
-  return occ;
-}
-
-__device__ __forceinline__ f4 select4(unsigned occ, f4 v, float fill) {
-  f4 o;
-  o.x = (occ & 1u) ? fill : v.x;
-  o.y = (occ & 2u) ? fill : v.y;
-  o.z = (occ & 4u) ? fill : v.z;
-  o.w = (occ & 8u) ? fill : v.w;
-  return o;
-}
-
-struct NormDev {
-  float mean[3], std[3], fill[3];
-  float rstd[3];     // 1 / std
-  int enable;
-  int rstd_exact;    // every std is a power of two: v / std == v * rstd bit for bit (the reference's NormModel: std = 0.5)
-};
-
-inline NormDev make_norm(const dp_norm_t *n) {
-  NormDev d;
-  d.enable = n->enable;
-  for (int c = 0; c < 3; ++c) {
-    d.mean[c] = n->mean[c];
-    d.std[c] = n->std[c];
-    // occluded pixel value after the (optional) normalisation: (fill - mean) / std
-    d.fill[c] = n->enable ? (n->fill - n->mean[c]) / n->std[c] : n->fill;
-    d.rstd[c] = 1.f / n->std[c];
-  }
-  d.rstd_exact = 1;
-  for (int c = 0; c < 3; ++c) {
-    int e = 0;
-    const float m = frexpf(n->std[c], &e);
-    if (!(m == 0.5f && e > -100 && e < 100)) d.rstd_exact = 0;
-  }
-  return d;
-}
-
-// grid: x = tiles of kBlock*G float4 groups of the image plane, y = S-chunks, z = image.
-// Each thread owns G float4 groups (4 consecutive pixels each, kBlock groups apart so that
-// every wave-instruction still covers 1 KiB of contiguous addresses) of all 3 channels,
-// reads + normalises them once, then streams `s_per_block` occluded copies (3*G 16-byte
-// stores per sample; s_per_block = 1 in the shipped configuration, see kApplyFwdDefaultVariant).  NT selects non-temporal stores (the output is consumed by another
-// kernel much later, never re-read by this one).
-template <int G, bool NT>
-__global__ __launch_bounds__(kBlock) void k_apply_fwd(
-    const float *__restrict__ adv_x, const int32_t *__restrict__ table, int R,
-    const int32_t *__restrict__ idx, const int32_t *__restrict__ idx2, int idx_bstride,
-    int S, int H, int W, int s_per_block, NormDev nd, float *__restrict__ out, int xcd_units) {
-  const int P = H * W, P4 = P >> 2;
-  int tile = blockIdx.x, chunk = blockIdx.y, b = blockIdx.z;
-  if (xcd_units > 0) {
-    // 1-D launch, XCD-aware walk (A/B variant, not the default: see launch_apply_fwd).  Workgroup L runs on XCD L % 8
-    // (round-robin dispatch, MI355X_MICROARCH.md): the S-chunks of one (image, tile) unit are consecutive workgroups OF
-    // ONE XCD, so the unit's 12 KiB of source pixels come from HBM once and from that XCD's L2 for the other chunks.
-    const int tiles = cdiv_dev(P4, kBlock * G), nchunk = cdiv_dev(S, s_per_block);
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int ju = j / nchunk;
-    const int u = ju * 8 + xcd;
-    if (u >= xcd_units) return;
-    chunk = j - ju * nchunk;
-    b = u / tiles;
-    tile = u - b * tiles;
-  }
-  const int g0 = tile * (kBlock * G) + threadIdx.x;
-  const int s_begin = chunk * s_per_block;
-  const int s_end = min(S, s_begin + s_per_block);
-
-  const f4 *src = reinterpret_cast<const f4 *>(adv_x + (size_t)b * 3 * P);
-  f4 v[G][3];
-  int hh[G], ww[G];
-#pragma unroll
-  for (int k = 0; k < G; ++k) {
-    const int g = g0 + k * kBlock;
-    const int gc = g < P4 ? g : P4 - 1;  // clamp: tail lanes load a valid group, never store
-    const int pix = gc << 2;
-    hh[k] = pix / W;
-    ww[k] = pix - hh[k] * W;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      f4 t = src[c * P4 + gc];
-      if (nd.enable) t = (t - nd.mean[c]) / nd.std[c];  // reference NormModel: true division
-      v[k][c] = t;
-    }
-  }
-  const int32_t *ib = idx + (size_t)b * idx_bstride;
-  const int32_t *ib2 = idx2 ? idx2 + (size_t)b * idx_bstride : nullptr;
-  f4 *dst = reinterpret_cast<f4 *>(out + ((size_t)b * S + s_begin) * 3 * P);
-  for (int s = s_begin; s < s_end; ++s) {
-    const int m1 = ib[s];
-    const int m2 = ib2 ? ib2[s] : -1;
-#pragma unroll
-    for (int k = 0; k < G; ++k) {
-      const int g = g0 + k * kBlock;
-      if (g < P4) {
-        unsigned occ = occluded4(table, R, m1, hh[k], ww[k]);
-        if (m2 >= 0) occ |= occluded4(table, R, m2, hh[k], ww[k]);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const f4 o = select4(occ, v[k][c], nd.fill[c]);
-          if (NT) __builtin_nontemporal_store(o, dst + c * P4 + g);
-          else dst[c * P4 + g] = o;
-        }
-      }
-    }
-    dst += 3 * P4;
-  }
-}
-
-// Channel-split variant: grid z = image * 3 + channel, a workgroup owns kBlock * G consecutive float4 groups of ONE
-// channel plane and streams, per sample, G * 4 KiB of contiguous output (G = 7: 28 KiB; 12544 groups per 224 x 224
-// plane = 7 tiles exactly).  Rationale (profiles/r02d_kbench_calibration_store_flavours.txt): a write-only stream
-// reaches 5.6-5.7 TB/s on this GPU when every workgroup writes one contiguous 32 KiB run, 4.2 TB/s when workgroups
-// interleave 4 KiB pieces; the store flavour (plain / nt / sc1 ...) moves it by < 3 %.
-template <int G, bool NT>
-__global__ __launch_bounds__(kBlock) void k_apply_fwd_ch(
-    const float *__restrict__ adv_x, const int32_t *__restrict__ table, int R,
-    const int32_t *__restrict__ idx, const int32_t *__restrict__ idx2, int idx_bstride,
-    int S, int H, int W, int s_per_block, NormDev nd, float *__restrict__ out) {
-  const int P = H * W, P4 = P >> 2;
-  const int g0 = blockIdx.x * (kBlock * G) + threadIdx.x;
-  const int b = blockIdx.z / 3, c = blockIdx.z - 3 * b;
-  const int s_begin = blockIdx.y * s_per_block;
-  const int s_end = min(S, s_begin + s_per_block);
-  const f4 *src = reinterpret_cast<const f4 *>(adv_x + ((size_t)b * 3 + c) * P);
-  const float mean = nd.mean[c], stdv = nd.std[c], fill = nd.fill[c];
-  f4 v[G];
-  int hh[G], ww[G];
-#pragma unroll
-  for (int k = 0; k < G; ++k) {
-    const int g = g0 + k * kBlock;
-    const int gc = g < P4 ? g : P4 - 1;
-    const int pix = gc << 2;
-    hh[k] = pix / W;
-    ww[k] = pix - hh[k] * W;
-    f4 t = src[gc];
-    if (nd.enable) t = (t - mean) / stdv;  // reference NormModel: true division
-    v[k] = t;
-  }
-  const int32_t *ib = idx + (size_t)b * idx_bstride;
-  const int32_t *ib2 = idx2 ? idx2 + (size_t)b * idx_bstride : nullptr;
-  f4 *dst = reinterpret_cast<f4 *>(out + (((size_t)b * S + s_begin) * 3 + c) * P);
-  for (int s = s_begin; s < s_end; ++s) {
-    const int m1 = ib[s];
-    const int m2 = ib2 ? ib2[s] : -1;
-#pragma unroll
-    for (int k = 0; k < G; ++k) {
-      const int g = g0 + k * kBlock;
-      unsigned occ = occluded4(table, R, m1, hh[k], ww[k]);
-      if (m2 >= 0) occ |= occluded4(table, R, m2, hh[k], ww[k]);
-      const f4 o = select4(occ, v[k], fill);
-      if (g < P4) {
-        if (NT) __builtin_nontemporal_store(o, dst + g);
-        else dst[g] = o;
-      }
-    }
-    dst += 3 * P4;
-  }
-}
-
-// grid: x = float4-group tiles, y = S-slab, z = image.  Reads G once, skips the
-// 16 B of fully occluded groups, reduces over the slab's samples in s order.
-__global__ __launch_bounds__(kBlock) void k_apply_bwd(
-    const float *__restrict__ G, const int32_t *__restrict__ table, int R,
-    const int32_t *__restrict__ idx, const int32_t *__restrict__ idx2, int idx_bstride,
-    int B, int S, int H, int W, int s_per_slab, NormDev nd, float *__restrict__ slabs) {
-  const int P = H * W, P4 = P >> 2;
-  const int g = blockIdx.x * kBlock + threadIdx.x;
-  if (g >= P4) return;
-  const int b = blockIdx.z, z = blockIdx.y;
-  const int s_begin = z * s_per_slab;
-  const int s_end = min(S, s_begin + s_per_slab);
-  const int pix = g << 2;
-  const int h = pix / W, w = pix - h * W;
-  const int32_t *ib = idx + (size_t)b * idx_bstride;
-  const int32_t *ib2 = idx2 ? idx2 + (size_t)b * idx_bstride : nullptr;
-  const f4 *src = reinterpret_cast<const f4 *>(G + ((size_t)b * S + s_begin) * 3 * P);
-  f4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
-#pragma unroll 4
-  for (int s = s_begin; s < s_end; ++s) {
-    unsigned occ = occluded4(table, R, ib[s], h, w);
-    if (ib2) occ |= occluded4(table, R, ib2[s], h, w);
-    if (occ != 0xFu) {
-      const f4 g0 = __builtin_nontemporal_load(src + g);
-      const f4 g1 = __builtin_nontemporal_load(src + P4 + g);
-      const f4 g2 = __builtin_nontemporal_load(src + 2 * P4 + g);
-      a0 += select4(occ, g0, 0.f);
-      a1 += select4(occ, g1, 0.f);
-      a2 += select4(occ, g2, 0.f);
-    }
-    src += 3 * P4;
-  }
-  if (nd.enable) {  // d/dx (x - mean)/std = 1/std  (autograd: grad / std)
-    a0 = a0 / nd.std[0];
-    a1 = a1 / nd.std[1];
-    a2 = a2 / nd.std[2];
-  }
-  f4 *dst = reinterpret_cast<f4 *>(slabs + ((size_t)z * B + b) * 3 * P);
-  dst[g] = a0;
-  dst[P4 + g] = a1;
-  dst[2 * P4 + g] = a2;
-}
-
-// ----------------------------------------------------------------------------
-// EXTENSION (not in the reference; BASELINE.json north_star "random affine placement"): per-sample affine
-// placement of the patch perturbation, fused with the occlusion apply.  The reference blends the patch at identity
-// (adv_x = x + delta, attack.py:184-185); here sample (b, s) sees  x + warp(delta, theta[b,s]),  where theta is a
-// 2 x 3 map from OUTPUT pixel coordinates to SOURCE (delta) pixel coordinates, bilinear, zero outside
-// (torch: F.grid_sample(delta, F.affine_grid(theta_norm), 'bilinear', 'zeros', align_corners=False)).  Identity
-// theta reproduces dp_apply_fwd / dp_apply_bwd exactly.
-//   forward  out[b,s,c,o] = occluded ? fill : norm(x[b,c,o] + sum_{4 taps p} w(o,p) * delta[b,c,p])
-//   backward g_delta[b,c,p] = sum_s sum_{o : w(o,p) > 0, o kept} w(o,p) * G[b,s,c,o] / std_c
-// The backward is the exact adjoint written as a GATHER: the outputs whose tap footprint covers source pixel p
-// are the integer points of the parallelogram theta^-1([p-1, p+1]^2); its bounding box is walked in a fixed order
-// (no float atomics: the optimiser takes sign(grad)).
-// ----------------------------------------------------------------------------
-struct Affine {
-  float a00, a01, t0, a10, a11, t1;  // src_x = a00*ox + a01*oy + t0 ; src_y = a10*ox + a11*oy + t1
-};
-
-__device__ __forceinline__ Affine load_affine(const float *__restrict__ theta, size_t n) {
-  const float *t = theta + n * 6;  // wave-uniform: scalar loads
-  return Affine{t[0], t[1], t[2], t[3], t[4], t[5]};
-}
-
-// THE source coordinate of an output pixel: every weight of the forward and of its adjoint comes from this one expression
-// (explicit fma: the file is built with -ffp-contract=off; the row term is shared by the pixels of a row).
-__device__ __forceinline__ void affine_src(const Affine &A, int ox, int oy, float &sx, float &sy) {
-  sx = __builtin_fmaf(A.a00, (float)ox, __builtin_fmaf(A.a01, (float)oy, A.t0));
-  sy = __builtin_fmaf(A.a10, (float)ox, __builtin_fmaf(A.a11, (float)oy, A.t1));
-}
-
-// Tiling (round 3).  Round 2's kernels issued 48 scalar global gathers per lane (forward: 1.24 ms per 64 x 32 x 224^2
-// launch = 13 % of the HBM roofline) and walked a 6 x 6 box of candidate outputs per source pixel, re-deriving every tap
-// and re-testing every occlusion window (backward: 4.19 ms = 3.8 %) — profiles/r03a_kbench_affine.txt.  Now a workgroup
-// owns a 32 x 32 tile and stages what it gathers from in LDS:
-//   forward   the tile's source footprint in delta — the bounding box of the 4 mapped tile corners + 1 tap + 1 margin
-//             pixel, zero outside the image, 3 channels — is loaded once with coalesced row segments; every lane then
-//             takes its 4 x 4 x 3 taps from LDS and writes its 3 float4 with non-temporal stores;
-//   backward  (exact adjoint, GATHER form, fixed order: no float atomics) per sample of the slab the workgroup stages the
-//             OUTPUT region that can touch its 32 x 16 source tile: the incoming gradient with the occlusion already
-//             applied (3 floats), and per output pixel its tap record — floor(src) relative to the tile and the two
-//             fractional weights, computed ONCE per output by the forward's own expression instead of once per
-//             (source pixel, candidate).  A source pixel then tests its 2kx x 2ky candidate outputs (kx = ceil of the
-//             inverse map's row sum: 4 x 4 for the default placement range) with one LDS read each and accumulates the
-//             hits in row-major order of the outputs, samples ascending: deterministic.
-// A footprint that does not fit the LDS budget (extreme scale / rotation) takes the round-2 per-pixel code (slow path:
-// the same tap positions and weights — both paths take them from affine_src — but the forward's staged path accumulates
-// its 4 taps with an fma chain where the per-pixel path uses separate multiplies and adds, so a sample that changes path
-// may differ in the last bit; the backward's two paths add the same products in the same order).  Identity placement
-// stays bit-identical to dp_apply_fwd / dp_apply_bwd.
-// Both kernels WALK several samples per workgroup: the next sample's loads are issued right after the barrier that
-// publishes the current one and land in registers during the current sample's LDS phase, and everything block-uniform
-// per sample (maps, footprint / region box, which occlusion windows touch it) is computed once per walk, one sample per
-// lane, then broadcast with v_readlane (forward 0.50 -> 0.33 ms, backward 1.55 -> 1.17 ms with 4 instead of 3
-// workgroups per CU; profiles/r03k ... r03w_kbench_affine.txt).
-constexpr int kAffT = 32;            // tile side (forward: 32 x 32 outputs; backward: 32 x kAffTB source pixels)
-constexpr int kAffTB = 16;
-constexpr int kAffRowsF = 3;         // forward: footprint of at most 64 x 48 source pixels, staged 16 rows x 16 float4 per pass
-constexpr int kAffCapF = 64 * 16 * kAffRowsF;  // ... per channel: 36 KiB of LDS for the 3 channels
-constexpr int kAffRowsB = 2;         // backward: staged output region of at most 64 x 32 pixels in 2 passes of 16 rows ...
-constexpr int kAffCapB = 1664;       // ... and at most this many pixels, 6 dwords each: 39 KiB = 4 workgroups per CU (the
-                                     // default placement range needs <= 52 x 32; 2048 = 48 KiB = 3 per CU is the kbench variant:
-                                     // 1.42 vs 1.17 ms, profiles/r03v_kbench_affine.txt)
-
-// Bits [c0 - x, c1 - x) clamped to the 4 pixels (h, x .. x + 3) of a lane, if row h lies in [r0, r1): a bit-field mask
-// instead of 4 x 2 compares per window (c1 > c0 and r1 > r0 required: callers test liveness first).
-__device__ __forceinline__ unsigned window_bits4(int r0, int r1, int c0, int c1, int h, int x) {
-  const int lo = min(max(c0 - x, 0), 4), hi = min(max(c1 - x, 0), 4);
-  const unsigned m = ((1u << (hi - lo)) - 1u) << lo;
-  return ((unsigned)(h - r0) < (unsigned)(r1 - r0)) ? m : 0u;
-}
-
-// Is window t = {r0, r1, c0, c1} non-empty and does it intersect rows [h0, h1) x columns [x0, x1)?
-__device__ __forceinline__ bool window_live(const int32_t *__restrict__ t, int h0, int h1, int x0, int x1) {
-  const int r0 = t[0], r1 = t[1], c0 = t[2], c1 = t[3];
-  return r1 > r0 && c1 > c0 && r0 < h1 && r1 > h0 && c0 < x1 && c1 > x0;
-}
-
-__device__ __forceinline__ bool occluded1(const int32_t *__restrict__ t, int R, int h, int w) {
-  bool occ = false;
-  for (int r = 0; r < R; ++r)
-    occ |= (h >= t[4 * r] && h < t[4 * r + 1] && w >= t[4 * r + 2] && w < t[4 * r + 3]);
-  return occ;
-}
-
-// Bilinear taps of one output pixel straight from global memory (the slow path; round 2's arithmetic, tap order
-// (y0,x0), (y0,x1), (y1,x0), (y1,x1), out-of-image taps skipped).
-__device__ __forceinline__ void affine_taps_global(const Affine &A, const float *__restrict__ db, int P, int H, int W,
-                                                   int ox, int oy, float acc[3]) {
-  float sx, sy;
-  affine_src(A, ox, oy, sx, sy);
-  const float fx0 = floorf(sx), fy0 = floorf(sy);
-  const int x0 = (int)fx0, y0 = (int)fy0;
-  const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-  const bool inx0 = x0 >= 0 && x0 < W, inx1 = x0 + 1 >= 0 && x0 + 1 < W;
-  const bool iny0 = y0 >= 0 && y0 < H, iny1 = y0 + 1 >= 0 && y0 + 1 < H;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const float *dc = db + (size_t)c * P;
-    float a = 0.f;
-    if (iny0 && inx0) a += (wy0 * wx0) * dc[y0 * W + x0];
-    if (iny0 && inx1) a += (wy0 * wx1) * dc[y0 * W + x0 + 1];
-    if (iny1 && inx0) a += (wy1 * wx0) * dc[(y0 + 1) * W + x0];
-    if (iny1 && inx1) a += (wy1 * wx1) * dc[(y0 + 1) * W + x0 + 1];
-    acc[c] = a;
-  }
-}
-
-// Value of lane `lane` (wave-uniform index) in every lane: v_readlane_b32, the result lives in an SGPR.
-__device__ __forceinline__ int lane_bcast(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
-__device__ __forceinline__ float lane_bcast(float v, int lane) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
-}
-
-// 16-byte loads through a raw buffer descriptor over [p, p + bytes): a byte offset at or beyond `bytes` returns zeros
-// (hardware range check), so "this float4 lies outside the image" costs one select on the OFFSET instead of four on the
-// data, and the address is a 32-bit offset instead of a 64-bit pointer.  Descriptor word 3 = 0x00020000: raw dword data
-// format for gfx9 / CDNA.
-constexpr unsigned kBufOutOfRange = 0x80000000u;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_plane_buffer(const float *p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ f4 buffer_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
-}
-
-// Source footprint of a 32 x 32 output tile under one sample's map: the map is affine, so its extremes are at the tile's
-// corners.  Box = [floor(lo) - 1, floor(hi) + 2] (the +1 tap and one pixel of margin either side: rounding of interior
-// points); the left edge is aligned down to a multiple of 4 pixels so that every lane stages whole, 16-byte aligned float4s.
-struct AffFoot {
-  int rx0, ry0, RW4, RH;   // origin, width in float4s (LDS row pitch = 4 * RW4), height
-  bool staged;             // fits the LDS budget (block-uniform)
-};
-
-__device__ __forceinline__ AffFoot affine_footprint(const Affine &A, int tx0, int ty0, int H, int W) {
-  const int cx1 = min(tx0 + kAffT - 1, W - 1), cy1 = min(ty0 + kAffT - 1, H - 1);
-  float sx00, sy00, sx01, sy01, sx10, sy10, sx11, sy11;
-  affine_src(A, tx0, ty0, sx00, sy00);
-  affine_src(A, cx1, ty0, sx01, sy01);
-  affine_src(A, tx0, cy1, sx10, sy10);
-  affine_src(A, cx1, cy1, sx11, sy11);
-  const float fx_lo = fminf(fminf(sx00, sx01), fminf(sx10, sx11)), fx_hi = fmaxf(fmaxf(sx00, sx01), fmaxf(sx10, sx11));
-  const float fy_lo = fminf(fminf(sy00, sy01), fminf(sy10, sy11)), fy_hi = fmaxf(fmaxf(sy00, sy01), fmaxf(sy10, sy11));
-  const bool finite = fabsf(fx_lo) < 1e6f && fabsf(fx_hi) < 1e6f && fabsf(fy_lo) < 1e6f && fabsf(fy_hi) < 1e6f;
-  AffFoot F;
-  F.rx0 = finite ? ((int)floorf(fx_lo) - 1) & ~3 : 0;
-  F.ry0 = finite ? (int)floorf(fy_lo) - 1 : 0;
-  F.RW4 = finite ? (((int)floorf(fx_hi) + 2 - F.rx0) >> 2) + 1 : 1 << 20;
-  F.RH = finite ? (int)floorf(fy_hi) + 2 - F.ry0 + 1 : 1;
-  F.staged = F.RW4 <= 16 && F.RH <= kAffRowsF * 16 && (F.RW4 << 2) * F.RH <= kAffCapF;
-  return F;
-}
-
-// Lane (row = tid / 16, col4 = tid % 16) requests one float4 of 16 footprint rows per pass, 3 channels: ALL 3 * kAffRowsF
-// loads are issued back to back (first tiled version: dword loads, a load / store pair per loop iteration = ~11 serialised
-// round trips and 4x the instructions: 0.63 ms, profiles/r03b_kbench_affine.txt).  Zeros stand for out-of-image pixels:
-// `db` is a buffer descriptor over the image's 3 planes and an outside float4 gets an out-of-range offset.
-__device__ __forceinline__ void affine_foot_load(const AffFoot &F, __amdgpu_buffer_rsrc_t db, int P, int H, int W,
-                                                 f4 v[kAffRowsF][3]) {
-  const int col4 = threadIdx.x & 15, row = threadIdx.x >> 4;
-  const int gx = F.rx0 + (col4 << 2);
-  const bool colok = col4 < F.RW4 && gx >= 0 && gx < W;     // aligned and W % 4 == 0: a float4 is inside or outside as a whole
-  const int o0 = __mul24(F.ry0 + row, W) + gx;              // 24-bit multiplies: v_mul_lo_u32 is a quarter-rate instruction
-#pragma unroll
-  for (int i = 0; i < kAffRowsF; ++i) {
-    const int ry = row + i * 16, gy = F.ry0 + ry;
-    const bool ok = colok && gy >= 0 && gy < H && ry < F.RH;
-    const unsigned o = ok ? (unsigned)(o0 + i * 16 * W) << 2 : kBufOutOfRange;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) v[i][c] = buffer_load4(db, o + (unsigned)c * ((unsigned)P << 2));
-  }
-}
-
-__device__ __forceinline__ void affine_foot_store(const AffFoot &F, const f4 v[kAffRowsF][3], float *__restrict__ sd) {
-  const int col4 = threadIdx.x & 15, row = threadIdx.x >> 4;
-  if (col4 < F.RW4) {
-    const int e0 = __mul24(row, F.RW4 << 2) + (col4 << 2);
-#pragma unroll
-    for (int i = 0; i < kAffRowsF; ++i) {
-      const int ry = row + i * 16;
-      if (ry < F.RH) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) *reinterpret_cast<f4 *>(sd + c * kAffCapF + e0 + i * 16 * (F.RW4 << 2)) = v[i][c];
-      }
-    }
-  }
-}
-
-// grid: x = 32 x 32 output tiles (row-major), y = chunk of s_per_block samples, z = image.  Thread (ly = tid / 8,
-// lx = 4 * (tid % 8)) owns output pixels (ty0 + ly, tx0 + lx .. + 3) of all 3 channels.  The workgroup walks its samples
-// with the NEXT sample's footprint in flight (registers) while it takes the CURRENT sample's taps from LDS: the
-// one-sample-per-workgroup version spent 40 % of a wave's cycles parked at the footprint's waitcnt / the barrier with
-// only 4 workgroups per CU (36 KiB of LDS each) to cover for it (profiles/r03j_sq_counters_affine_kernels.txt).  The
-// tile of x is read once per chunk instead of once per sample.
-__global__ __launch_bounds__(kBlock) void k_apply_affine_fwd(
-    const float *__restrict__ x, const float *__restrict__ delta, const float *__restrict__ theta,
-    const int32_t *__restrict__ table, int R, const int32_t *__restrict__ idx,
-    const int32_t *__restrict__ idx2, int idx_bstride, int S, int H, int W, int tiles_x, int s_per_block, NormDev nd,
-    float *__restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float sd[3 * kAffCapF];
-  const int P = H * W;
-  const int b = blockIdx.z;
-  const int s_begin = blockIdx.y * s_per_block, s_end = min(S, s_begin + s_per_block);
-  const int tx0 = (blockIdx.x % tiles_x) * kAffT, ty0 = (blockIdx.x / tiles_x) * kAffT;
-  const float *xb = x + (size_t)b * 3 * P, *db = delta + (size_t)b * 3 * P;
-
-  // this lane's own pixels of x: requested before the staging traffic, consumed after the first barrier
-  const int oy = ty0 + (threadIdx.x >> 3), ox = tx0 + ((threadIdx.x & 7) << 2);
-  const bool mine = oy < H && ox < W;
-  const int g = mine ? (oy * W + ox) >> 2 : 0;
-  f4 xv[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) xv[c] = reinterpret_cast<const f4 *>(xb + (size_t)c * P)[g];
-  const __amdgpu_buffer_rsrc_t dbuf = make_plane_buffer(db, (unsigned)(3 * P) << 2);
-
-  // Per-sample block-uniform values of ALL the chunk's samples, once: lane l of every wave takes sample s_begin + l; a
-  // sample's values are then broadcast from its lane (v_readlane into SGPRs).
-  //  * the map and the tile's footprint (~60 vector instructions on uniform values — per sample that was a fifth of the
-  //    kernel); RW4 = 0 encodes "not staged";
-  //  * which of the sample's <= 2 * DP_MAX_RECTS occlusion windows touch this tile at all (bit r: window r of idx, bit
-  //    DP_MAX_RECTS + r: of idx2).  Most (tile, window) pairs do not: such a sample costs one v_readlane and a scalar
-  //    branch; a live window costs 4 scalar loads and 11 vector instructions.  (First version: both entries' windows in
-  //    32 SGPRs per sample, every slot tested per pixel: a quarter of the vector instructions, and SGPR spills.)
-  const int lane = threadIdx.x & 63;
-  const int sl = min(s_begin + lane, s_end - 1);
-  const int m1l = idx[(size_t)b * idx_bstride + sl], m2l = idx2 ? idx2[(size_t)b * idx_bstride + sl] : 0;
-  unsigned livel = 0u;
-  for (int r = 0; r < R; ++r) {
-    livel |= (unsigned)window_live(table + ((size_t)m1l * R + r) * 4, ty0, ty0 + kAffT, tx0, tx0 + kAffT) << r;
-    if (idx2)
-      livel |= (unsigned)window_live(table + ((size_t)m2l * R + r) * 4, ty0, ty0 + kAffT, tx0, tx0 + kAffT) << (DP_MAX_RECTS + r);
-  }
-  const Affine Al = [&] {
-    const float *t = theta + ((size_t)b * S + min(s_begin + lane, s_end - 1)) * 6;
-    return Affine{t[0], t[1], t[2], t[3], t[4], t[5]};
-  }();
-  AffFoot Fl = affine_footprint(Al, tx0, ty0, H, W);
-  if (!Fl.staged) Fl.RW4 = 0;
-  auto foot_of = [&](int k) {
-    AffFoot F;
-    F.rx0 = lane_bcast(Fl.rx0, k);
-    F.ry0 = lane_bcast(Fl.ry0, k);
-    F.RW4 = lane_bcast(Fl.RW4, k);
-    F.RH = lane_bcast(Fl.RH, k);
-    F.staged = F.RW4 > 0;
-    return F;
-  };
-
-  AffFoot Fn = foot_of(0);
-  f4 fv[kAffRowsF][3];
-  if (Fn.staged) affine_foot_load(Fn, dbuf, P, H, W, fv);
-
-  for (int s = s_begin; s < s_end; ++s) {
-    const int k = s - s_begin;
-    const AffFoot F = Fn;
-    __syncthreads();   // the previous sample's taps are done with the buffer
-    if (F.staged) affine_foot_store(F, fv, sd);
-    __syncthreads();
-    if (s + 1 < s_end) {   // next sample's footprint: in flight while this sample's taps are taken (block-uniform branches)
-      Fn = foot_of(k + 1);
-      if (Fn.staged) affine_foot_load(Fn, dbuf, P, H, W, fv);
-    }
-    const Affine A = Affine{lane_bcast(Al.a00, k), lane_bcast(Al.a01, k), lane_bcast(Al.t0, k),
-                            lane_bcast(Al.a10, k), lane_bcast(Al.a11, k), lane_bcast(Al.t1, k)};
-    const unsigned live = (unsigned)lane_bcast((int)livel, k);   // block-uniform
-    const int m1 = lane_bcast(m1l, k), m2 = lane_bcast(m2l, k);
-    if (!mine) continue;
-    unsigned occ = 0u;
-    if (live) {
-      const int32_t *t1 = table + (size_t)m1 * R * 4, *t2 = table + (size_t)m2 * R * 4;
-#pragma unroll
-      for (int r = 0; r < DP_MAX_RECTS; ++r) {
-        if (live >> r & 1u) occ |= window_bits4(t1[4 * r], t1[4 * r + 1], t1[4 * r + 2], t1[4 * r + 3], oy, ox);
-        if (live >> (DP_MAX_RECTS + r) & 1u) occ |= window_bits4(t2[4 * r], t2[4 * r + 1], t2[4 * r + 2], t2[4 * r + 3], oy, ox);
-      }
-    }
-    float v[3][4];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      v[c][0] = xv[c].x; v[c][1] = xv[c].y; v[c][2] = xv[c].z; v[c][3] = xv[c].w;
-    }
-    if (F.staged) {   // block-uniform, tested once (inside the pixel loop the compiler kept a branch per pixel)
-      const int RW = F.RW4 << 2;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float sx, sy;
-        affine_src(A, ox + j, oy, sx, sy);
-        const float fx0 = floorf(sx), fy0 = floorf(sy);
-        const float wx1 = sx - fx0, wy1 = sy - fy0, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
-        // clamped for memory safety only: with the margin a tap never leaves the staged box
-        const int ix = min(max((int)fx0 - F.rx0, 0), RW - 2), iy = min(max((int)fy0 - F.ry0, 0), F.RH - 2);
-        const float *t = sd + __mul24(iy, RW) + ix;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {  // tap order fixed: (y0,x0), (y0,x1), (y1,x0), (y1,x1); zeros stand for out-of-image taps
-          const float *tc = t + c * kAffCapF;
-          v[c][j] += __builtin_fmaf(wy1 * wx1, tc[RW + 1],
-                                    __builtin_fmaf(wy1 * wx0, tc[RW], __builtin_fmaf(wy0 * wx1, tc[1], (wy0 * wx0) * tc[0])));
-        }
-      }
-    } else {
-      for (int j = 0; j < 4; ++j) {
-        float acc[3];
-        affine_taps_global(A, db, P, H, W, ox + j, oy, acc);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) v[c][j] += acc[c];
-      }
-    }
-    float *ob = out + ((size_t)b * S + s) * 3 * P;
-    const bool any = live != 0u;   // block-uniform: a tile no window touches stores without the 4 selects per channel
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      f4 t = f4{v[c][0], v[c][1], v[c][2], v[c][3]};
-      if (nd.enable) {   // reference NormModel: true division; a power-of-two std makes the reciprocal multiply identical
-        if (nd.rstd_exact) t = (t - nd.mean[c]) * nd.rstd[c];
-        else t = (t - nd.mean[c]) / nd.std[c];
-      }
-      __builtin_nontemporal_store(any ? select4(occ, t, nd.fill[c]) : t, reinterpret_cast<f4 *>(ob + (size_t)c * P) + g);
-    }
-  }
-}
-
-// Contribution of ONE sample to ONE source pixel by the round-2 walk over the candidate outputs' bounding box (the
-// backward's slow path; reads G from global memory, re-derives every tap and occlusion test).
-__device__ __forceinline__ void affine_bwd_pixel_global(const Affine &A, const Affine &Ai, const float *__restrict__ Gs,
-                                                        const int32_t *__restrict__ t1, const int32_t *__restrict__ t2,
-                                                        int R, int P, int H, int W, int px, int py, float acc[3]) {
-  float cx, cy;
-  affine_src(Ai, px, py, cx, cy);  // output-space centre of the footprint
-  const float ex = fabsf(Ai.a00) + fabsf(Ai.a01), ey = fabsf(Ai.a10) + fabsf(Ai.a11);
-  const int ox0 = max(0, (int)floorf(cx - ex) - 1), ox1 = min(W - 1, (int)ceilf(cx + ex) + 1);
-  const int oy0 = max(0, (int)floorf(cy - ey) - 1), oy1 = min(H - 1, (int)ceilf(cy + ey) + 1);
-  for (int oy = oy0; oy <= oy1; ++oy)
-    for (int ox = ox0; ox <= ox1; ++ox) {
-      float sx, sy;
-      affine_src(A, ox, oy, sx, sy);  // the forward's own expression: identical weights
-      const float fx0 = floorf(sx), fy0 = floorf(sy);
-      const int x0 = (int)fx0, y0 = (int)fy0;
-      float wgt;
-      if (px == x0) wgt = 1.f - (sx - fx0);
-      else if (px == x0 + 1) wgt = sx - fx0;
-      else continue;
-      if (py == y0) wgt = (1.f - (sy - fy0)) * wgt;
-      else if (py == y0 + 1) wgt = (sy - fy0) * wgt;
-      else continue;
-      if (occluded1(t1, R, oy, ox) || (t2 && occluded1(t2, R, oy, ox))) continue;
-      const size_t o = (size_t)oy * W + ox;
-      acc[0] += wgt * Gs[o];
-      acc[1] += wgt * Gs[P + o];
-      acc[2] += wgt * Gs[2 * (size_t)P + o];
-    }
-}
-
-// Output region that can touch a 32 x 16 source tile under one sample's map (block-uniform values, computed one sample
-// per lane).  Box = bounding box of the inverse-mapped tile expanded by one pixel (an output contributes iff floor(src)
-// lies in it), + 2 pixels of margin, clipped to the image; the left edge aligned down to whole float4s.
-struct AffRegion {
-  int qx0a, qy0, QW4, QH;   // origin, width in float4s (LDS row pitch = 4 * QW4), height; QH = 0: no output maps near
-  int kxy;                  // kx | ky << 8: half-widths of a source pixel's candidate window; 0: NOT staged (slow path)
-};
-
-__device__ __forceinline__ AffRegion affine_region(const Affine &Ai, int tx0, int ty0, int H, int W, int cap) {
-  const float bx0 = (float)(tx0 - 1), bx1 = (float)min(tx0 + kAffT, W), by0 = (float)(ty0 - 1), by1 = (float)min(ty0 + kAffTB, H);
-  const float qxa = Ai.a00 * bx0, qxb = Ai.a00 * bx1, qxc = Ai.a01 * by0, qxd = Ai.a01 * by1;
-  const float qya = Ai.a10 * bx0, qyb = Ai.a10 * bx1, qyc = Ai.a11 * by0, qyd = Ai.a11 * by1;
-  const float qx_lo = (fminf(qxa, qxb) + fminf(qxc, qxd)) + Ai.t0, qx_hi = (fmaxf(qxa, qxb) + fmaxf(qxc, qxd)) + Ai.t0;
-  const float qy_lo = (fminf(qya, qyb) + fminf(qyc, qyd)) + Ai.t1, qy_hi = (fmaxf(qya, qyb) + fmaxf(qyc, qyd)) + Ai.t1;
-  const bool finite = fabsf(qx_lo) < 1e6f && fabsf(qx_hi) < 1e6f && fabsf(qy_lo) < 1e6f && fabsf(qy_hi) < 1e6f;
-  const int qx0 = finite ? max(0, (int)floorf(qx_lo) - 2) : 0, qx1 = finite ? min(W - 1, (int)ceilf(qx_hi) + 2) : W - 1;
-  const int qy0 = finite ? max(0, (int)floorf(qy_lo) - 2) : 0, qy1 = finite ? min(H - 1, (int)ceilf(qy_hi) + 2) : H - 1;
-  const float ex = fabsf(Ai.a00) + fabsf(Ai.a01), ey = fabsf(Ai.a10) + fabsf(Ai.a11);
-  const int kx = (int)ceilf(ex + 0.01f), ky = (int)ceilf(ey + 0.01f);
-  AffRegion Q;
-  Q.qx0a = qx0 & ~3;
-  Q.qy0 = qy0;
-  Q.QW4 = ((qx1 - Q.qx0a) >> 2) + 1;
-  Q.QH = qy1 - qy0 + 1;
-  if (finite && (qx1 < qx0 || qy1 < qy0)) Q.QH = 0;   // empty: the sample contributes nothing to this tile
-  const bool staged = finite && Q.QW4 >= 1 && Q.QW4 <= 16 && Q.QH <= kAffRowsB * 16 && (Q.QW4 << 2) * Q.QH <= cap && kx <= 4 && ky <= 4;
-  Q.kxy = staged ? (kx | ky << 8) : 0;
-  return Q;
-}
-
-// Lane (row = tid / 16, col4 = tid % 16) requests 4 consecutive outputs of 16 region rows per pass, 3 channels; the
-// aligned region never leaves the image (qx0a >= 0, aligned right edge <= W - 1 since W % 4 == 0).
-__device__ __forceinline__ void affine_region_load(const AffRegion &Q, const float *__restrict__ Gs, int P, int W,
-                                                   f4 gv[kAffRowsB][3]) {
-  const int col4 = threadIdx.x & 15, row = threadIdx.x >> 4;
-  const bool colok = col4 < Q.QW4;
-  const int o0 = __mul24(Q.qy0 + row, W) + Q.qx0a + (col4 << 2);
-#pragma unroll
-  for (int i = 0; i < kAffRowsB; ++i) {
-    const bool ok = colok && row + i * 16 < Q.QH;
-    const int o = (ok ? o0 + i * 16 * W : __mul24(Q.qy0, W) + Q.qx0a) >> 2;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) gv[i][c] = reinterpret_cast<const f4 *>(Gs + (size_t)c * P)[o];
-  }
-}
-
-// grid: x = 32 x 16 SOURCE tiles, y = S-slab, z = image.  Thread (ly = tid / 16, lx = 2 * (tid % 16)) owns source pixels
-// (ty0 + ly, tx0 + lx .. + 1) x 3 channels.  theta_inv (B,S,6) is the inverse map supplied by the host; it only
-// positions the staged region and the candidate windows (both carry a margin), never a weight.
-// Like the forward, the workgroup walks its samples with the NEXT sample's region of G in flight while it gathers from the
-// current one, and takes every per-sample block-uniform value (both maps, the region, which occlusion windows touch the
-// region) from a lane that computed it once, up to 64 samples at a time (first tiled version: ~80 vector instructions and
-// three dependent scalar-load round trips at the head of every sample, the loads waited for immediately).
-template <int CAP>
-__global__ __launch_bounds__(kBlock) void k_apply_affine_bwd(
-    const float *__restrict__ G, const float *__restrict__ theta, const float *__restrict__ theta_inv,
-    const int32_t *__restrict__ table, int R, const int32_t *__restrict__ idx,
-    const int32_t *__restrict__ idx2, int idx_bstride, int B, int S, int H, int W, int tiles_x, int s_per_slab,
-    NormDev nd, float *__restrict__ slabs, int g_dev_gather) {
-  __shared__ __attribute__((aligned(16))) float sg[3 * CAP];
-  __shared__ __attribute__((aligned(16))) float swx[CAP], swy[CAP];
-  __shared__ __attribute__((aligned(16))) int stap[CAP];
-  const int P = H * W;
-  const int b = blockIdx.z, z = blockIdx.y;
-  const int tx0 = (blockIdx.x % tiles_x) * kAffT, ty0 = (blockIdx.x / tiles_x) * kAffTB;
-  const int py = ty0 + (threadIdx.x >> 4), px0 = tx0 + ((threadIdx.x & 15) << 1);
-  const bool mine = py < H && px0 < W;   // W % 4 == 0: px0 + 1 < W as well
-  const int s_begin = z * s_per_slab, s_end = min(S, s_begin + s_per_slab);
-  const int lane = threadIdx.x & 63;
-  const int col4 = threadIdx.x & 15, row = threadIdx.x >> 4;
-  float acc[2][3];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) acc[j][c] = 0.f;
-
-  for (int c_begin = s_begin; c_begin < s_end; c_begin += 64) {   // chunks of <= 64 samples: one lane per sample
-    const int c_end = min(s_end, c_begin + 64);
-    const int sl = min(c_begin + lane, c_end - 1);
-    const float *tp = theta + ((size_t)b * S + sl) * 6, *tip = theta_inv + ((size_t)b * S + sl) * 6;
-    const Affine Al = Affine{tp[0], tp[1], tp[2], tp[3], tp[4], tp[5]};
-    const Affine Ail = Affine{tip[0], tip[1], tip[2], tip[3], tip[4], tip[5]};
-    const AffRegion Ql = affine_region(Ail, tx0, ty0, H, W, CAP);
-    const int m1l = idx[(size_t)b * idx_bstride + sl], m2l = idx2 ? idx2[(size_t)b * idx_bstride + sl] : 0;
-    unsigned livel = 0u;   // bit r: window r of idx touches the staged region; bit DP_MAX_RECTS + r: of idx2
-    for (int r = 0; r < R; ++r) {
-      livel |= (unsigned)window_live(table + ((size_t)m1l * R + r) * 4, Ql.qy0, Ql.qy0 + Ql.QH, Ql.qx0a, Ql.qx0a + (Ql.QW4 << 2)) << r;
-      if (idx2)
-        livel |= (unsigned)window_live(table + ((size_t)m2l * R + r) * 4, Ql.qy0, Ql.qy0 + Ql.QH, Ql.qx0a, Ql.qx0a + (Ql.QW4 << 2))
-                 << (DP_MAX_RECTS + r);
-    }
-    auto region_of = [&](int k) {
-      AffRegion Q;
-      Q.qx0a = lane_bcast(Ql.qx0a, k);
-      Q.qy0 = lane_bcast(Ql.qy0, k);
-      Q.QW4 = lane_bcast(Ql.QW4, k);
-      Q.QH = lane_bcast(Ql.QH, k);
-      Q.kxy = lane_bcast(Ql.kxy, k);
-      return Q;
-    };
-
-    AffRegion Qn = region_of(0);
-    f4 gv[kAffRowsB][3];
-    if (Qn.kxy && Qn.QH) affine_region_load(Qn, G + ((size_t)b * S + c_begin) * 3 * P, P, W, gv);
-
-    for (int s = c_begin; s < c_end; ++s) {
-      const int k = s - c_begin;
-      const AffRegion Q = Qn;
-      const Affine A = Affine{lane_bcast(Al.a00, k), lane_bcast(Al.a01, k), lane_bcast(Al.t0, k),
-                              lane_bcast(Al.a10, k), lane_bcast(Al.a11, k), lane_bcast(Al.t1, k)};
-      const Affine Ai = Affine{lane_bcast(Ail.a00, k), lane_bcast(Ail.a01, k), lane_bcast(Ail.t0, k),
-                               lane_bcast(Ail.a10, k), lane_bcast(Ail.a11, k), lane_bcast(Ail.t1, k)};
-      const unsigned live = (unsigned)lane_bcast((int)livel, k);
-      const int m1 = lane_bcast(m1l, k), m2 = lane_bcast(m2l, k);
-      const int32_t *t1 = table + (size_t)m1 * R * 4, *t2 = idx2 ? table + (size_t)m2 * R * 4 : nullptr;
-      const float *Gs = G + ((size_t)b * S + s) * 3 * P;
-      const bool staged = Q.kxy != 0, empty = Q.QH == 0;
-      const int QWp = Q.QW4 << 2;
-
-      __syncthreads();   // the previous sample's gather is done with the staging buffers
-      if (staged && !empty) {
-        // tap records of the region's outputs, computed ONCE per output by the forward's own expression
-        const int ox = Q.qx0a + (col4 << 2);
-        const int e0 = __mul24(row, QWp) + (col4 << 2);
-#pragma unroll
-        for (int i = 0; i < kAffRowsB; ++i) {
-          const int qy = row + i * 16;
-          if (!(col4 < Q.QW4 && qy < Q.QH)) continue;
-          const int oy = Q.qy0 + qy;
-          unsigned occ = 0u;
-          if (live) {   // block-uniform; a window that misses the region costs nothing
-#pragma unroll
-            for (int r = 0; r < DP_MAX_RECTS; ++r) {
-              if (live >> r & 1u) occ |= window_bits4(t1[4 * r], t1[4 * r + 1], t1[4 * r + 2], t1[4 * r + 3], oy, ox);
-              if (live >> (DP_MAX_RECTS + r) & 1u)
-                occ |= window_bits4(t2[4 * r], t2[4 * r + 1], t2[4 * r + 2], t2[4 * r + 3], oy, ox);
-            }
-          }
-          float fxs[4], fys[4];
-          int tap[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float sx, sy;
-            affine_src(A, ox + j, oy, sx, sy);   // the forward's own expression: identical weights
-            const float fx0 = floorf(sx), fy0 = floorf(sy);
-            // tap record: floor(src) relative to (tile origin - 2), 0 = not a neighbour of this tile
-            const float rx = fx0 - (float)(tx0 - 2), ry = fy0 - (float)(ty0 - 2);
-            const bool near = rx >= 0.f && rx < (float)(kAffT + 4) && ry >= 0.f && ry < (float)(kAffTB + 4);
-            tap[j] = near ? (1 + (int)rx + ((int)ry << 8)) : 0;
-            fxs[j] = sx - fx0;
-            fys[j] = sy - fy0;
-          }
-          const int e = e0 + i * 16 * QWp;
-          *reinterpret_cast<i4 *>(stap + e) = i4{tap[0], tap[1], tap[2], tap[3]};
-          *reinterpret_cast<f4 *>(swx + e) = f4{fxs[0], fxs[1], fxs[2], fxs[3]};
-          *reinterpret_cast<f4 *>(swy + e) = f4{fys[0], fys[1], fys[2], fys[3]};
-#pragma unroll
-          for (int c = 0; c < 3; ++c) *reinterpret_cast<f4 *>(sg + c * CAP + e) = select4(occ, gv[i][c], 0.f);
-        }
-      }
-      __syncthreads();
-      if (s + 1 < c_end) {   // next sample's region of G: in flight during this sample's gather
-        Qn = region_of(k + 1);
-        if (Qn.kxy && Qn.QH) affine_region_load(Qn, Gs + (size_t)3 * P, P, W, gv);
-      }
-      if (!mine || empty) continue;
-      if (!staged) {   // slow path: per-pixel walk over global memory
-#pragma unroll
-        for (int j = 0; j < 2; ++j) affine_bwd_pixel_global(A, Ai, Gs, t1, t2, R, P, H, W, px0 + j, py, acc[j]);
-        continue;
-      }
-      // the thread's two pixels share one candidate window (their inverse images are one output step apart): every
-      // staged record is read once and tested against both.  o - floor(c) lies in [1 - k, k] for either pixel.
-      const int kx = Q.kxy & 0xff, ky = Q.kxy >> 8;
-      float c0x, c0y, c1x, c1y;
-      affine_src(Ai, px0, py, c0x, c0y);
-      affine_src(Ai, px0 + 1, py, c1x, c1y);
-      const int fx_a = (int)floorf(fminf(c0x, c1x)), fx_b = (int)floorf(fmaxf(c0x, c1x));
-      const int fy_a = (int)floorf(fminf(c0y, c1y)), fy_b = (int)floorf(fmaxf(c0y, c1y));
-      const int cqx0 = max(fx_a + 1 - kx - Q.qx0a, 0), cqx1 = min(fx_b + kx - Q.qx0a, QWp - 1);
-      const int cqy0 = max(fy_a + 1 - ky - Q.qy0, 0), cqy1 = min(fy_b + ky - Q.qy0, Q.QH - 1);
-      const int want0 = 1 + (px0 - (tx0 - 2)) + ((py - (ty0 - 2)) << 8);   // record of an output whose floor(src) == (px0, py)
-      // one candidate: d = (px - x0) + 256 * (py - y0) is 0, 1, 256 or 257 for the four taps of an output
-      auto candidate = [&](int e, int rec) {
-        const int d0 = want0 - rec, d1 = d0 + 1;
-        const bool hit0 = ((unsigned)d0 & ~0x101u) == 0u, hit1 = ((unsigned)d1 & ~0x101u) == 0u;
-        if (!(hit0 || hit1)) return;
-        const float fx = swx[e], fy = swy[e];
-        const float g0 = sg[e], g1 = sg[CAP + e], g2 = sg[2 * CAP + e];
-        if (hit0) {
-          float wgt = (d0 & 1) ? fx : 1.f - fx;
-          wgt = ((d0 >> 8) ? fy : 1.f - fy) * wgt;
-          acc[0][0] += wgt * g0;
-          acc[0][1] += wgt * g1;
-          acc[0][2] += wgt * g2;
-        }
-        if (hit1) {
-          float wgt = (d1 & 1) ? fx : 1.f - fx;
-          wgt = ((d1 >> 8) ? fy : 1.f - fy) * wgt;
-          acc[1][0] += wgt * g0;
-          acc[1][1] += wgt * g1;
-          acc[1][2] += wgt * g2;
-        }
-      };
-      if (g_dev_gather == 2 && cqx1 - cqx0 < 8 && cqy1 - cqy0 < 8) {
-      // Round 5: HIT COMPACTION.  The branchy loop below visits every candidate slot in turn, and with 64
-      // lanes nearly every slot is some lane's hit: ~30 slots x (branch + LDS round trip for the hit's weights / gradients)
-      // per sample, the wave parked on each (SQ counters: VALU active 26 %, waves parked 44 %).  Here pass 1 only reads the
-      // window's tap records (rows of <= 8 requested back to back) and sets bit 8 r + i of a 64-bit mask for a record that is
-      // a tap of either of the thread's two pixels; pass 2 walks the lane's OWN set bits in ascending order — one LDS round
-      // trip (record, two weights, three gradients) per iteration, ~6 iterations instead of ~30 slots.  Same candidates, same
-      // order (rows ascending, records ascending), same expressions: bit-identical.
-      const int ncol = cqx1 - cqx0 + 1;
-      unsigned long long hits = 0ull;
-      for (int qy = cqy0; qy <= (cqx0 <= cqx1 ? cqy1 : cqy0 - 1); ++qy) {
-        const int er = __mul24(qy, QWp) + cqx0;
-        int rec[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) rec[u] = stap[er + min(u, ncol - 1)];
-        unsigned rowbits = 0u;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int d0 = want0 - rec[u];
-          const bool hit = (((unsigned)d0 & ~0x101u) == 0u || ((unsigned)(d0 + 1) & ~0x101u) == 0u) && u < ncol;
-          rowbits |= (hit ? 1u : 0u) << u;
-        }
-        hits |= (unsigned long long)rowbits << ((qy - cqy0) << 3);
-      }
-      while (hits) {
-        const int c = __ffsll((long long)hits) - 1;
-        hits &= hits - 1ull;
-        const int e = __mul24(cqy0 + (c >> 3), QWp) + cqx0 + (c & 7);
-        const int rec = stap[e];
-        const float fx = swx[e], fy = swy[e];
-        const float g0 = sg[e], g1 = sg[CAP + e], g2 = sg[2 * CAP + e];
-        const int d0 = want0 - rec, d1 = d0 + 1;
-        if (((unsigned)d0 & ~0x101u) == 0u) {
-          float wgt = (d0 & 1) ? fx : 1.f - fx;
-          wgt = ((d0 >> 8) ? fy : 1.f - fy) * wgt;
-          acc[0][0] += wgt * g0;
-          acc[0][1] += wgt * g1;
-          acc[0][2] += wgt * g2;
-        }
-        if (((unsigned)d1 & ~0x101u) == 0u) {
-          float wgt = (d1 & 1) ? fx : 1.f - fx;
-          wgt = ((d1 >> 8) ? fy : 1.f - fy) * wgt;
-          acc[1][0] += wgt * g0;
-          acc[1][1] += wgt * g1;
-          acc[1][2] += wgt * g2;
-        }
-      }
-      } else if (g_dev_gather != 1) {   // the round-3 gather: a branch per candidate
-      // A row of the window is <= 2 kx + 2 records (6 for the default placement range): its first 6 records are read
-      // back to back before any is tested (one LDS round trip per row instead of one per candidate — the gather spent
-      // its time waiting on them); order of accumulation unchanged: rows ascending, records ascending.
-      constexpr int kRowAhead = 6;
-      for (int qy = cqy0; qy <= (cqx0 <= cqx1 ? cqy1 : cqy0 - 1); ++qy) {   // (an empty column range: no rows)
-        const int er = __mul24(qy, QWp), e0 = er + cqx0, e1 = er + cqx1;
-        int rec[kRowAhead];
-#pragma unroll
-        for (int u = 0; u < kRowAhead; ++u) rec[u] = stap[min(e0 + u, e1)];
-#pragma unroll
-        for (int u = 0; u < kRowAhead; ++u)
-          if (e0 + u <= e1) candidate(e0 + u, rec[u]);
-        for (int e = e0 + kRowAhead; e <= e1; ++e) candidate(e, stap[e]);
-      }
-      } else {
-      // A/B variant (DP_DEBUG_AFFINE_GATHER = 1; round 4, measured and NOT kept): the same candidates in the same order,
-      // BRANCH-FREE.  Hypothesis: the loop above is latency-bound (SQ counters: VALU active 26 %, waves parked 44 %) — every
-      // candidate is a data-dependent branch around five dependent LDS reads — so request a row's 6 records AND their
-      // weights / gradients (36 dwords) back to back, unconditionally, and fold them in with selects: two LDS round trips per
-      // row instead of ~7, no branches, block-uniform trip counts (2 ky + 1 rows, ceil((2 kx + 2) / 6) column groups), a
-      // slot outside the thread's own window reads a clamped address and is discarded; acc = hit ? acc + w g : acc keeps
-      // every bit.  Result (64 x 32 x 224^2, profiles/r04d_kbench_affine.txt): 1.58 ms against 1.18 — waves parked 44 -> 27 %,
-      // but VALU active 26 -> 35 % of a longer run: three of four (pixel, candidate) pairs are misses, and the branchy loop
-      // skips their weight / accumulate arithmetic while this one executes it.  The gather form's cost is the 3:1 ratio
-      // of tested to hit candidates, not its round trips.
-      constexpr int kCols = 6;
-      const int nrow = (cqx0 <= cqx1) ? (cqy1 - cqy0 + 1) : 0, ncol = cqx1 - cqx0 + 1;
-      const int rows_max = 2 * ky + 1, cols_max = 2 * kx + 2;
-      const int qy_safe = min(max(cqy0, 0), Q.QH - 1), qx_safe = min(max(cqx0, 0), QWp - 1);
-      for (int r = 0; r < rows_max; ++r) {
-        const bool rok = r < nrow;
-        const int er = __mul24(rok ? cqy0 + r : qy_safe, QWp);
-        for (int cb = 0; cb < cols_max; cb += kCols) {
-          int rec[kCols];
-          float fxs[kCols], fys[kCols], ga[kCols], gb[kCols], gc[kCols];
-#pragma unroll
-          for (int u = 0; u < kCols; ++u) {
-            const bool ok = rok && cb + u < ncol;
-            const int e = er + (ok ? cqx0 + cb + u : qx_safe);
-            rec[u] = stap[e];
-            fxs[u] = swx[e];
-            fys[u] = swy[e];
-            ga[u] = sg[e];
-            gb[u] = sg[CAP + e];
-            gc[u] = sg[2 * CAP + e];
-          }
-#pragma unroll
-          for (int u = 0; u < kCols; ++u) {
-            const bool ok = rok && cb + u < ncol;
-            const int d0 = want0 - rec[u], d1 = d0 + 1;
-            const bool hit0 = ok && ((unsigned)d0 & ~0x101u) == 0u, hit1 = ok && ((unsigned)d1 & ~0x101u) == 0u;
-            const float fx = fxs[u], fy = fys[u];
-            float w0 = (d0 & 1) ? fx : 1.f - fx;
-            w0 = (((d0 >> 8) & 1) ? fy : 1.f - fy) * w0;
-            float w1 = (d1 & 1) ? fx : 1.f - fx;
-            w1 = (((d1 >> 8) & 1) ? fy : 1.f - fy) * w1;
-            acc[0][0] = hit0 ? acc[0][0] + w0 * ga[u] : acc[0][0];
-            acc[0][1] = hit0 ? acc[0][1] + w0 * gb[u] : acc[0][1];
-            acc[0][2] = hit0 ? acc[0][2] + w0 * gc[u] : acc[0][2];
-            acc[1][0] = hit1 ? acc[1][0] + w1 * ga[u] : acc[1][0];
-            acc[1][1] = hit1 ? acc[1][1] + w1 * gb[u] : acc[1][1];
-            acc[1][2] = hit1 ? acc[1][2] + w1 * gc[u] : acc[1][2];
-          }
-        }
-      }
-      }
-    }
-  }
-  if (!mine) return;
-  float *dst = slabs + ((size_t)z * B + b) * 3 * P + (size_t)py * W + px0;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    float o0 = acc[0][c], o1 = acc[1][c];
-    if (nd.enable) { o0 = o0 / nd.std[c]; o1 = o1 / nd.std[c]; }
-    dst[(size_t)c * P] = o0;
-    dst[(size_t)c * P + 1] = o1;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_sum_slabs(const float *__restrict__ slabs,
-                                                      int nslab, int64_t n4,
-                                                      float *__restrict__ out,
-                                                      int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n4) return;
-  const f4 *s4 = reinterpret_cast<const f4 *>(slabs);
-  f4 *o4 = reinterpret_cast<f4 *>(out);
-  f4 acc = {0.f, 0.f, 0.f, 0.f};
-  if (accumulate) acc = o4[i];
-  for (int z = 0; z < nslab; ++z) acc += s4[(int64_t)z * n4 + i];
-  o4[i] = acc;
-}
-
-// ----------------------------------------------------------------------------
-// a-7: CW loss, its gradient, argmax — one wave per logits row
-// ----------------------------------------------------------------------------
-
-struct ArgMax {
-  float v;
-  int i;
-};
-
-__device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {
-  // larger value wins; on ties the smaller index wins (first occurrence)
-  const bool take_b = (b.v > a.v) || (b.v == a.v && b.i < a.i);
-  return take_b ? b : a;
-}
-
-__device__ __forceinline__ ArgMax wave_argmax(ArgMax a) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    ArgMax o;
-    o.v = __shfl_xor(a.v, off, 64);
-    o.i = __shfl_xor(a.i, off, 64);
-    a = better(a, o);
-  }
-  return a;  // valid in every lane
-}
-
-__global__ __launch_bounds__(kBlock) void k_cw_loss(
-    const float *__restrict__ logits, const int64_t *__restrict__ y,
-    const int32_t *__restrict__ targeted_b, int N, int C, int S, float confidence,
-    float upstream, float *__restrict__ loss,
-    float *__restrict__ dlogits, int32_t *__restrict__ pred) {
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (n >= N) return;
-  const float *row = logits + (size_t)n * C;
-  const int label = (int)y[n / S];
-  const bool targeted = targeted_b[n / S] != 0;
-  const int kIntMax = 0x7fffffff;
-  ArgMax all = {-INFINITY, kIntMax}, oth = {-INFINITY, kIntMax};
-  for (int k = lane; k < C; k += 64) {
-    const ArgMax cur = {row[k], k};
-    all = better(all, cur);
-    if (k != label) oth = better(oth, cur);
-  }
-  all = wave_argmax(all);
-  oth = wave_argmax(oth);
-  if (pred && lane == 0) pred[n] = all.i;
-  if (!loss) return;
-  const float real = row[label];
-  // reference: ((1-onehot)*logits - onehot*1e4).max(1): the label slot holds -1e4
-  float other = oth.v;
-  int kstar = oth.i;
-  if (!(other >= -1e4f)) {  // label slot is the max (or no other class): no grad path
-    other = -1e4f;
-    kstar = -1;
-  }
-  const float margin = targeted ? (confidence + other) - real : (confidence + real) - other;
-  const bool active = margin >= 0.f;  // clamp(min=0) backward passes grad where x >= 0
-  if (lane == 0) loss[n] = active ? margin : 0.f;
-  if (!dlogits) return;
-  const float g_real = active ? (targeted ? -upstream : upstream) : 0.f;
-  const float g_other = active ? (targeted ? upstream : -upstream) : 0.f;
-  float *drow = dlogits + (size_t)n * C;
-  for (int k = lane; k < C; k += 64) {
-    float gk = 0.f;
-    if (k == label) gk = g_real;
-    if (k == kstar) gk = g_other;
-    drow[k] = gk;
-  }
-}
-
-// ----------------------------------------------------------------------------
-// a-5: structural (TV-like) terms — LDS tile + 1-pixel halo
-// ----------------------------------------------------------------------------
-
-constexpr int TW = 32, TH = 8;          // tile = 8 rows x 32 cols = 256 threads
-constexpr int TWP = TW + 2, THP = TH + 2;
-
-struct Tile3 {
-  float v[3][THP][TWP];
-};
-
-// Cooperative load of a 3-channel tile whose interior origin is (h0, w0);
-// local index [ly][lx] <-> pixel (h0 + ly - 1, w0 + lx - 1).  Out of image -> 0.
-__device__ __forceinline__ void load_tile3(const float *__restrict__ img, int H, int W,
-                                           int h0, int w0, Tile3 &t) {
-  for (int i = threadIdx.x; i < 3 * THP * TWP; i += kBlock) {
-    const int c = i / (THP * TWP);
-    const int r = i - c * (THP * TWP);
-    const int ly = r / TWP, lx = r - ly * TWP;
-    const int h = h0 + ly - 1, w = w0 + lx - 1;
-    float val = 0.f;
-    if (h >= 0 && h < H && w >= 0 && w < W) val = img[((size_t)c * H + h) * W + w];
-    t.v[c][ly][lx] = val;
-  }
-}
-
-// reference attack.py:33-39: a = |x[j] - x[j+1]| along w (last column keeps raw x),
-// b likewise along h (last row keeps raw x).  (ly, lx) is the local index of (h, w).
-__device__ __forceinline__ void grad_pair(const Tile3 &t, int c, int ly, int lx, int h, int w,
-                                          int H, int W, float &a, float &b) {
-  const float v = t.v[c][ly][lx];
-  a = (w < W - 1) ? fabsf(v - t.v[c][ly][lx + 1]) : v;
-  b = (h < H - 1) ? fabsf(v - t.v[c][ly + 1][lx]) : v;
-}
-
-__global__ __launch_bounds__(kBlock) void k_local_variance(const float *__restrict__ x, int H,
-                                                           int W, float *__restrict__ lv) {
-  __shared__ Tile3 t;
-  const int b = blockIdx.z;
-  const int h0 = blockIdx.y * TH, w0 = blockIdx.x * TW;
-  load_tile3(x + (size_t)b * 3 * H * W, H, W, h0, w0, t);
-  __syncthreads();
-  const int tx = threadIdx.x & (TW - 1), ty = threadIdx.x / TW;
-  const int h = h0 + ty, w = w0 + tx;
-  if (h >= H || w >= W) return;
-  float acc = 0.f;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    float a, bb;
-    grad_pair(t, c, ty + 1, tx + 1, h, w, H, W, a, bb);
-    acc += a + bb;
-  }
-  lv[((size_t)b * H + h) * W + w] = acc / 3.f;
-}
-
-__global__ __launch_bounds__(kBlock) void k_struct_loss(const float *__restrict__ adv_x,
-                                                        const float *__restrict__ lv_x, int H,
-                                                        int W, float *__restrict__ partials) {
-  __shared__ Tile3 t;
-  __shared__ float sm4[4];
-  const int b = blockIdx.z;
-  const int h0 = blockIdx.y * TH, w0 = blockIdx.x * TW;
-  load_tile3(adv_x + (size_t)b * 3 * H * W, H, W, h0, w0, t);
-  __syncthreads();
-  const int tx = threadIdx.x & (TW - 1), ty = threadIdx.x / TW;
-  const int h = h0 + ty, w = w0 + tx;
-  float contrib = 0.f;
-  if (h < H && w < W) {
-    float acc = 0.f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float a, bb;
-      grad_pair(t, c, ty + 1, tx + 1, h, w, H, W, a, bb);
-      // attack.py:45  local_var * where(gl > gu, gu, gl)
-      acc += (a + bb) * ((a > bb) ? bb : a);
-    }
-    contrib = (acc / 3.f) / (lv_x[((size_t)b * H + h) * W + w] + 1e-5f);
-  }
-  const float tot = block_sum(contrib, sm4);
-  if (threadIdx.x == 0) {
-    const int ntile = gridDim.x * gridDim.y;
-    partials[(size_t)b * ntile + blockIdx.y * gridDim.x + blockIdx.x] = tot;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_reduce_rows(const float *__restrict__ in, int B,
-                                                        int n, float scale,
-                                                        float *__restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (b >= B) return;
-  float acc = 0.f;
-  for (int k = lane; k < n; k += 64) acc += in[(size_t)b * n + k];
-  acc = wave_sum(acc);
-  if (lane == 0) out[b] = acc * scale;
-}
-
-// ----------------------------------------------------------------------------
-// a-6: mask statistics.  Two launches: k_mask_bands (one workgroup per row band of cells or of
-// density windows, (ncy + nwy) * B workgroups) and k_mask_finish (one workgroup per image).
-// ----------------------------------------------------------------------------
-
-// blockIdx.x <  ncy : conv_group(mask**2) for cell row cy = blockIdx.x (attack.py:72-74, 243-244):
-//                     the unit x W band is staged in LDS with coalesced float4 loads, then one
-//                     thread per cell sums its unit x unit values in (row, col) order.
-// blockIdx.x >= ncy : conv_density(mask) for window row ky = blockIdx.x - ncy (attack.py:77-80,
-//                     237): one wave per window, lanes strided over the win x win pixels.
-__global__ __launch_bounds__(kBlock) void k_mask_bands(
-    const float *__restrict__ mask, int H, int W, int unit, int win, int ncy, int ncx, int nwy,
-    int nwx, float *__restrict__ cell_sumsq, float *__restrict__ win_sum) {
-  extern __shared__ __attribute__((aligned(16))) float band[];  // unit * W floats
-  const int b = blockIdx.y;
-  const float *m = mask + (size_t)b * H * W;
-  if ((int)blockIdx.x < ncy) {
-    const int cy = blockIdx.x;
-    const int W4 = W >> 2, n4 = unit * W4;
-    const f4 *src = reinterpret_cast<const f4 *>(m + (size_t)cy * unit * W);  // rows are contiguous
-    f4 *dst = reinterpret_cast<f4 *>(band);
-    for (int i = threadIdx.x; i < n4; i += kBlock) dst[i] = src[i];
-    __syncthreads();
-    for (int cx = threadIdx.x; cx < ncx; cx += kBlock) {
-      float acc = 0.f;
-      for (int i = 0; i < unit; ++i) {
-        const float *rowp = band + i * W + cx * unit;
-        for (int j = 0; j < unit; ++j) acc += rowp[j] * rowp[j];
-      }
-      cell_sumsq[((size_t)b * ncy + cy) * ncx + cx] = acc;
-    }
-  } else {
-    const int ky = blockIdx.x - ncy;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    for (int kx = wid; kx < nwx; kx += kBlock / 64) {
-      float acc = 0.f;
-      for (int i = lane; i < win * win; i += 64) {
-        const int r = i / win, c = i - r * win;
-        acc += m[(size_t)(ky * win + r) * W + kx * win + c];
-      }
-      acc = wave_sum(acc);
-      if (lane == 0) win_sum[((size_t)b * nwy + ky) * nwx + kx] = acc;
-    }
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_mask_finish(
-    const float *__restrict__ cell_sumsq, const float *__restrict__ win_sum, int unit, int ncell,
-    int nwindow, float *__restrict__ group_lasso, float *__restrict__ density) {
-  __shared__ float sm4[4];
-  const int b = blockIdx.x;
-  float gl_acc = 0.f;
-  for (int cell = threadIdx.x; cell < ncell; cell += kBlock)
-    gl_acc += sqrtf(cell_sumsq[(size_t)b * ncell + cell]);
-  const float gl_tot = block_sum(gl_acc, sm4);
-  if (threadIdx.x == 0) {
-    group_lasso[b] = (float)unit * gl_tot;  // attack.py:243-244
-    const float *ws = win_sum + (size_t)b * nwindow;
-    float mean = 0.f;
-    for (int k = 0; k < nwindow; ++k) mean += ws[k];
-    mean /= (float)nwindow;
-    float var = 0.f;
-    for (int k = 0; k < nwindow; ++k) {
-      const float d = ws[k] - mean;
-      var += d * d;
-    }
-    density[b] = var / (float)(nwindow - 1);  // torch.var: unbiased (attack.py:237)
-  }
-}
-
-// ----------------------------------------------------------------------------
-// a-2 bwd + a-5 grad + a-6 grads + a-9 signed update: one fused tile kernel
-// ----------------------------------------------------------------------------
-
-struct UpdateArgs {
-  const float *x, *adv_x, *lv_x, *g_adv;
-  const float *scale, *structured, *coeff_gl, *lr;
-  const float *cell_sumsq, *win_sum;
-  const int32_t *save_best;
-  float *pattern, *mask, *best_pattern, *best_mask, *g_pattern_out, *g_mask_out;
-  int H, W, stage, unit, win, ncy, ncx, nwy, nwx, do_update;
-  float density, clip_min, clip_max;
-};
-
-__global__ __launch_bounds__(kBlock) void k_project_update(UpdateArgs A) {
-  __shared__ Tile3 t;
-  __shared__ float s_lv[TH + 1][TW + 1];  // [ly][lx] <-> pixel (h0 + ly - 1, w0 + lx - 1)
-  __shared__ float s_wmean;
-  const int H = A.H, W = A.W, P = H * W;
-  const int b = blockIdx.z;
-  const int h0 = blockIdx.y * TH, w0 = blockIdx.x * TW;
-  load_tile3(A.adv_x + (size_t)b * 3 * P, H, W, h0, w0, t);
-  for (int i = threadIdx.x; i < (TH + 1) * (TW + 1); i += kBlock) {
-    const int ly = i / (TW + 1), lx = i - ly * (TW + 1);
-    const int h = h0 + ly - 1, w = w0 + lx - 1;
-    float val = 0.f;
-    if (h >= 0 && h < H && w >= 0 && w < W) val = A.lv_x[((size_t)b * H + h) * W + w];
-    s_lv[ly][lx] = val;
-  }
-  const int nwindow = A.nwy * A.nwx;
-  if (A.stage == 0 && threadIdx.x == 0) {
-    float mean = 0.f;
-    for (int k = 0; k < nwindow; ++k) mean += A.win_sum[(size_t)b * nwindow + k];
-    s_wmean = mean / (float)nwindow;
-  }
-  __syncthreads();
-
-  const int tx = threadIdx.x & (TW - 1), ty = threadIdx.x / TW;
-  const int h = h0 + ty, w = w0 + tx;
-  if (h >= H || w >= W) return;
-  const int ly = ty + 1, lx = tx + 1;
-  const size_t pix = (size_t)h * W + w;
-
-  const float s = A.scale[b];
-  const float coef = A.structured[b];
-  // autograd chain of  loss += structured * mean_{h,w}( mean_c(L) / (lv + 1e-5) ):
-  // (structured / P) / (lv + 1e-5) / 3  at the position of L
-  const float base = coef / (float)P;
-  const float up_left = (w >= 1) ? (base / (s_lv[ly][lx - 1] + 1e-5f)) / 3.f : 0.f;
-  const float up_up = (h >= 1) ? (base / (s_lv[ly - 1][lx] + 1e-5f)) / 3.f : 0.f;
-
-  const float m = A.mask[(size_t)b * P + pix];
-  float gm = 0.f;
-  float gp[3], pv[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const size_t off = ((size_t)b * 3 + c) * P + pix;
-    float g = A.g_adv[off];
-    if (coef != 0.f) {
-      // gradient reaches adv_x[h,w] only as the *subtracted neighbour* of the
-      // pixel to its left and of the pixel above (attack.py:35-38: the minuend
-      // is a detached clone).
-      const float xc = t.v[c][ly][lx];
-      float gs = 0.f;
-      if (w >= 1) {
-        float a, bb;
-        grad_pair(t, c, ly, lx - 1, h, w - 1, H, W, a, bb);
-        const float mn = (a > bb) ? bb : a;
-        const float dLda = mn + ((a > bb) ? 0.f : (a + bb));
-        gs -= up_left * dLda * sgn(t.v[c][ly][lx - 1] - xc);
-      }
-      if (h >= 1) {
-        float a, bb;
-        grad_pair(t, c, ly - 1, lx, h - 1, w, H, W, a, bb);
-        const float mn = (a > bb) ? bb : a;
-        const float dLdb = mn + ((a > bb) ? (a + bb) : 0.f);
-        gs -= up_up * dLdb * sgn(t.v[c][ly - 1][lx] - xc);
-      }
-      g += gs;
-    }
-    // utils.clip backward (scale detached): d delta = g * s; d pattern = d delta * mask;
-    // d mask = sum_c d delta * (pattern - x)
-    const float p = A.pattern[off];
-    const float gd = g * s;
-    gp[c] = gd * m;
-    gm += gd * (p - A.x[off]);
-    pv[c] = p;
-  }
-
-  if (A.stage == 0) {
-    if (A.density != 0.f) {
-      const int ky = h / A.win, kx = w / A.win;
-      if (ky < A.nwy && kx < A.nwx) {
-        const float ck = A.win_sum[(size_t)b * nwindow + ky * A.nwx + kx];
-        // var backward: grad * 2/(n-1) * (c - mean)
-        gm += (2.f / (float)(nwindow - 1)) * A.density * (ck - s_wmean);
-      }
-    }
-    const int cy = h / A.unit, cx = w / A.unit;
-    if (cy < A.ncy && cx < A.ncx) {
-      const float cs = A.cell_sumsq[(size_t)b * A.ncy * A.ncx + cy * A.ncx + cx];
-      // (coeff * unit) / (2 sqrt(cs)) * (2 m): 0 * inf = NaN for an all-zero cell,
-      // which torch.sign maps to 0 => the cell is frozen (attack.py:243-245).
-      const float gsq = (A.coeff_gl[b] * (float)A.unit) / (2.f * sqrtf(cs));
-      gm += gsq * (2.f * m);
-    }
-  }
-
-  if (A.g_pattern_out) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) A.g_pattern_out[((size_t)b * 3 + c) * P + pix] = gp[c];
-  }
-  if (A.g_mask_out) A.g_mask_out[(size_t)b * P + pix] = (A.stage == 0) ? gm : 0.f;
-
-  const bool save = A.save_best && A.save_best[b] != 0;
-  if (save) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) A.best_pattern[((size_t)b * 3 + c) * P + pix] = pv[c];
-    if (A.stage == 0) A.best_mask[(size_t)b * P + pix] = m;
-  }
-  if (!A.do_update) return;
-  const float lr = A.lr[b];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    float p = pv[c] - lr * sgn(gp[c]);
-    p = fminf(fmaxf(p, A.clip_min), A.clip_max);
-    A.pattern[((size_t)b * 3 + c) * P + pix] = p;
-  }
-  if (A.stage == 0) {
-    float mm = m - lr * sgn(gm);
-    mm = fminf(fmaxf(mm, A.clip_min), A.clip_max);
-    A.mask[(size_t)b * P + pix] = mm;
-  }
-}
-
-// The same step with 16-byte lanes (W % 4 == 0, 16-byte aligned tensors: every shape the backbone takes).  A workgroup
-// owns a 32 x 32 pixel tile; one lane = 4 consecutive pixels of a row x 3 channels, so g_adv, pattern, x, mask, lv_x and
-// the best-so-far copies move as float4 (the scalar kernel above issues 4-byte requests: 38 % of the HBM roofline on a
-// 0.9 GB working set; this one 54 % in stage 0, 61 % in stage 1).  adv_x (1-pixel halo all round) and lv_x (halo up /
-// left) are staged in LDS with float4 interior loads; the arithmetic per pixel is the scalar kernel's, expression for
-// expression (bit-identical results: tests compare the two).
-// Measured and not kept (round 4, profiles/r04c_kbench_update_*_1d_variant.txt): the same lanes over 1024 CONSECUTIVE
-// pixels per workgroup (every array one ascending 4 KiB run, LDS window of 1024 + 2 W + 8 pixels) — 50 % / 59 %: the
-// window's 45 % halo (re-read from another XCD's L2 or HBM) costs more than the tidier streams gain; and issuing the
-// lane's 10 streaming loads before the tile staging instead of after the barrier changed nothing (0.2146 ms both ways):
-// the kernel is not latency-bound.
-constexpr int UW = 32, UH = 32;      // tile; 256 lanes = 32 rows x 8 float4 columns (224 = 7 tiles, 384 = 12)
-constexpr int URS = UW + 8;          // LDS row stride: pixel (., w0 + lx) at [4 + lx]; left halo [3], right halo [4 + UW]
-
-struct TileU {
-  float v[3][UH + 2][URS];           // [ly] <-> row h0 + ly - 1
-};
-
-__global__ __launch_bounds__(kBlock) void k_project_update_v4(UpdateArgs A) {
-  __shared__ __attribute__((aligned(16))) TileU t;
-  __shared__ __attribute__((aligned(16))) float s_lv[UH + 1][URS];   // [ly] <-> row h0 + ly - 1; same column layout
-  __shared__ float s_wmean;
-  const int H = A.H, W = A.W, P = H * W;
-  const int b = blockIdx.z;
-  const int h0 = blockIdx.y * UH, w0 = blockIdx.x * UW;
-  const float *img = A.adv_x + (size_t)b * 3 * P;
-  const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  // the lane's own streaming operands first: 10 independent 16-byte loads in flight while the tile is staged (issued
-  // after the barrier they would wait behind it: 0.214 -> see KERNELS.md)
-  const int q = threadIdx.x & (UW / 4 - 1), ty = threadIdx.x / (UW / 4);
-  const int h = h0 + ty, wq = w0 + 4 * q;
-  const bool mine = h < H && wq < W;
-  const size_t pix = mine ? (size_t)h * W + wq : 0;
-  const f4 m4 = *reinterpret_cast<const f4 *>(A.mask + (size_t)b * P + pix);
-  f4 g4[3], pv4[3], x4[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const size_t off = ((size_t)b * 3 + c) * P + pix;
-    g4[c] = *reinterpret_cast<const f4 *>(A.g_adv + off);
-    pv4[c] = *reinterpret_cast<const f4 *>(A.pattern + off);
-    x4[c] = *reinterpret_cast<const f4 *>(A.x + off);
-  }
-  for (int i = threadIdx.x; i < 3 * (UH + 2) * (UW / 4); i += kBlock) {
-    const int c = i / ((UH + 2) * (UW / 4));
-    const int r = i - c * ((UH + 2) * (UW / 4));
-    const int ly = r / (UW / 4), q = r - ly * (UW / 4);
-    const int h = h0 + ly - 1, w = w0 + 4 * q;
-    f4 val = zero4;
-    if (h >= 0 && h < H && w < W) val = *reinterpret_cast<const f4 *>(img + ((size_t)c * H + h) * W + w);
-    *reinterpret_cast<f4 *>(&t.v[c][ly][4 + 4 * q]) = val;
-  }
-  for (int i = threadIdx.x; i < 3 * (UH + 2) * 2; i += kBlock) {      // the two halo columns
-    const int c = i / ((UH + 2) * 2);
-    const int r = i - c * ((UH + 2) * 2);
-    const int ly = r >> 1, side = r & 1;
-    const int h = h0 + ly - 1, w = side ? (w0 + UW) : (w0 - 1);
-    float val = 0.f;
-    if (h >= 0 && h < H && w >= 0 && w < W) val = img[((size_t)c * H + h) * W + w];
-    t.v[c][ly][side ? (4 + UW) : 3] = val;
-  }
-  const float *lvp = A.lv_x + (size_t)b * P;
-  for (int i = threadIdx.x; i < (UH + 1) * (UW / 4); i += kBlock) {
-    const int ly = i / (UW / 4), q = i - ly * (UW / 4);
-    const int h = h0 + ly - 1, w = w0 + 4 * q;
-    f4 val = zero4;
-    if (h >= 0 && h < H && w < W) val = *reinterpret_cast<const f4 *>(lvp + (size_t)h * W + w);
-    *reinterpret_cast<f4 *>(&s_lv[ly][4 + 4 * q]) = val;
-  }
-  if (threadIdx.x < UH + 1) {
-    const int ly = threadIdx.x, h = h0 + ly - 1, w = w0 - 1;
-    s_lv[ly][3] = (h >= 0 && h < H && w >= 0) ? lvp[(size_t)h * W + w] : 0.f;
-  }
-  const int nwindow = A.nwy * A.nwx;
-  if (A.stage == 0 && threadIdx.x == 64) {
-    float mean = 0.f;
-    for (int k = 0; k < nwindow; ++k) mean += A.win_sum[(size_t)b * nwindow + k];
-    s_wmean = mean / (float)nwindow;
-  }
-  __syncthreads();
-
-  if (!mine) return;
-  const int ly = ty + 1;
-
-  const float s = A.scale[b];
-  const float coef = A.structured[b];
-  const float base = coef / (float)P;
-  f4 gm4 = zero4;
-  f4 gp4[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const f4 p4 = pv4[c];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int w = wq + k, lx = 4 + 4 * q + k;
-      float g = g4[c][k];
-      if (coef != 0.f) {
-        const float up_left = (w >= 1) ? (base / (s_lv[ly][lx - 1] + 1e-5f)) / 3.f : 0.f;
-        const float up_up = (h >= 1) ? (base / (s_lv[ly - 1][lx] + 1e-5f)) / 3.f : 0.f;
-        const float xc = t.v[c][ly][lx];
-        float gs = 0.f;
-        if (w >= 1) {          // L at (h, w - 1): a = |v - right| (right = this pixel), b = |v - down|
-          const float v = t.v[c][ly][lx - 1];
-          const float a = fabsf(v - xc);                                          // w - 1 < W - 1 always
-          const float bb = (h < H - 1) ? fabsf(v - t.v[c][ly + 1][lx - 1]) : v;
-          const float mn = (a > bb) ? bb : a;
-          const float dLda = mn + ((a > bb) ? 0.f : (a + bb));
-          gs -= up_left * dLda * sgn(v - xc);
-        }
-        if (h >= 1) {          // L at (h - 1, w): a = |v - right|, b = |v - down| (down = this pixel)
-          const float v = t.v[c][ly - 1][lx];
-          const float a = (w < W - 1) ? fabsf(v - t.v[c][ly - 1][lx + 1]) : v;
-          const float bb = fabsf(v - xc);                                         // h - 1 < H - 1 always
-          const float mn = (a > bb) ? bb : a;
-          const float dLdb = mn + ((a > bb) ? (a + bb) : 0.f);
-          gs -= up_up * dLdb * sgn(v - xc);
-        }
-        g += gs;
-      }
-      const float gd = g * s;
-      gp4[c][k] = gd * m4[k];
-      gm4[k] += gd * (p4[k] - x4[c][k]);
-    }
-  }
-
-  if (A.stage == 0) {
-    if (A.density != 0.f) {
-      const int ky = h / A.win;
-      int kx = wq / A.win, rx = wq - kx * A.win;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (ky < A.nwy && kx < A.nwx) {
-          const float ck = A.win_sum[(size_t)b * nwindow + ky * A.nwx + kx];
-          gm4[k] += (2.f / (float)(nwindow - 1)) * A.density * (ck - s_wmean);
-        }
-        if (++rx == A.win) { rx = 0; ++kx; }
-      }
-    }
-    const int cy = h / A.unit;
-    int cx = wq / A.unit, rx = wq - cx * A.unit;
-    const float cgl = A.coeff_gl[b];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (cy < A.ncy && cx < A.ncx) {
-        const float cs = A.cell_sumsq[(size_t)b * A.ncy * A.ncx + cy * A.ncx + cx];
-        const float gsq = (cgl * (float)A.unit) / (2.f * sqrtf(cs));       // 0 * inf = NaN: frozen cell (see above)
-        gm4[k] += gsq * (2.f * m4[k]);
-      }
-      if (++rx == A.unit) { rx = 0; ++cx; }
-    }
-  }
-
-  if (A.g_pattern_out) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) *reinterpret_cast<f4 *>(A.g_pattern_out + ((size_t)b * 3 + c) * P + pix) = gp4[c];
-  }
-  if (A.g_mask_out) *reinterpret_cast<f4 *>(A.g_mask_out + (size_t)b * P + pix) = (A.stage == 0) ? gm4 : zero4;
-
-  const bool save = A.save_best && A.save_best[b] != 0;
-  if (save) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) *reinterpret_cast<f4 *>(A.best_pattern + ((size_t)b * 3 + c) * P + pix) = pv4[c];
-    if (A.stage == 0) *reinterpret_cast<f4 *>(A.best_mask + (size_t)b * P + pix) = m4;
-  }
-  if (!A.do_update) return;
-  const float lr = A.lr[b];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    f4 pn;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float p = pv4[c][k] - lr * sgn(gp4[c][k]);
-      pn[k] = fminf(fmaxf(p, A.clip_min), A.clip_max);
-    }
-    *reinterpret_cast<f4 *>(A.pattern + ((size_t)b * 3 + c) * P + pix) = pn;
-  }
-  if (A.stage == 0) {
-    f4 mn4;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float mm = m4[k] - lr * sgn(gm4[k]);
-      mn4[k] = fminf(fmaxf(mm, A.clip_min), A.clip_max);
-    }
-    *reinterpret_cast<f4 *>(A.mask + (size_t)b * P + pix) = mn4;
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_argmax(const float *__restrict__ logits, int N,
-                                                   int C, int32_t *__restrict__ pred) {
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (n >= N) return;
-  const float *row = logits + (size_t)n * C;
-  ArgMax all = {-INFINITY, 0x7fffffff};
-  for (int k = lane; k < C; k += 64) all = better(all, ArgMax{row[k], k});
-  all = wave_argmax(all);
-  if (lane == 0) pred[n] = all.i;
-}
-
-
-// ----------------------------------------------------------------------------
-// a-8 (backbone, HBM-bound part): GroupNorm + ReLU fused, forward and input-gradient
-// backward.  ResNetV2-50x1-BiT applies GroupNorm(32)+ReLU 49 times per forward
-// (timm 0.6.7 GroupNormAct; reference call sites utils.py:51-63, attack.py:222, 247).
-// Eager PyTorch spends 3 reads + 2 writes of the activation on the forward and
-// 6 reads + 2 writes on the backward; a group of one sample is at most 25 088 floats
-// at 224x224, so a workgroup keeps it in registers: forward = 1 read + 1 write,
-// backward = 2 reads + 1 write.  Frozen backbone: no gamma/beta gradients.
-// ----------------------------------------------------------------------------
-
-template <int T>
-__device__ __forceinline__ float block_allsum(float v, float *sm /* T/64 floats */) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  constexpr int NW = T / 64;
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-  __syncthreads();
-  float r = 0.f;
-#pragma unroll
-  for (int w = 0; w < NW; ++w) r += sm[w];  // same order in every thread: bit-identical total
-  return r;
-}
-
-struct GnArgs {
-  const float *x, *gamma, *beta;
-  const float *res;   // forward: optional residual, the normalised tensor is x + res (nullptr: x)
-  float *sum_out;     // forward: x + res is also written here (the next block's shortcut)
-  const float *dres;  // backward: optional extra gradient w.r.t. (x + res), added to the result
-  float *ab;          // forward: optional (N, C, 2) table of the affine coefficients a = rstd * gamma, b = beta - mean * a
-                      // (what the store phase applies), for convolutions that fold the apply into their operand staging
-                      // (k_conv1x1_mfma FOLD); with y == nullptr the forward is a statistics-only pass
-  int C, HW, Cg;      // channels, pixels per channel, channels per group
-  float eps, inv_hw;  // inv_hw = 1 / HW
-  // backward, gather form (dp_gn_relu_bwd_gather): output sample n takes its x / mean / rstd from SOURCE sample
-  // smap[n]; the source samples live in up to kGnMaxTabs slabs of tab_rows samples each (the micro-batches of one
-  // step's forward), so a backward over the samples that still carry gradient never copies an activation.
-  const int *smap;                 // nullptr: source = n, one slab (A.x)
-  const float *xtab[8];
-  int tab_rows;                    // 0: one slab (A.x)
-};
-constexpr int kGnMaxTabs = 8;
-
-struct GnSource {
-  const float *x;   // the (sample, group)'s first element
-  size_t stat;      // index of its mean / rstd
-};
-
-// Uniform (scalar) address arithmetic: one integer division by G per workgroup and a select chain over the slabs.
-__device__ __forceinline__ GnSource gn_source(const GnArgs &A, int ng, size_t L) {
-  GnSource S;
-  if (!A.smap) {
-    S.x = A.x + (size_t)ng * L;
-    S.stat = (size_t)ng;
-    return S;
-  }
-  const int G = A.C / A.Cg;
-  const int n = ng / G, g = ng - n * G;
-  const int src = A.smap[n];
-  S.stat = (size_t)src * G + g;
-  const float *base = A.x;
-  int row = src;
-  if (A.tab_rows) {
-    const int t = src / A.tab_rows;
-    row = src - t * A.tab_rows;
-    base = A.xtab[0];
-#pragma unroll
-    for (int k = 1; k < kGnMaxTabs; ++k)
-      if (t == k) base = A.xtab[k];
-  }
-  S.x = base + ((size_t)row * G + g) * L;
-  return S;
-}
-
-// channel (within the group) of flat element e of the group; exact for e < 2^20, HW >= 1
-__device__ __forceinline__ int chan_of(int e, float inv_hw) {
-  return (int)(((float)e + 0.5f) * inv_hw);
-}
-
-constexpr int kGnLdsCh = 64;  // channels per group whose gamma / beta are staged in LDS (ResNetV2-50: <= 64)
-
-// affine + relu coefficients of one float4 whose first element is group-element e.  ga / be point at the
-// group's gamma / beta: the LDS copy (LC, indexed from 0) or global memory (indexed from cbase).
-__device__ __forceinline__ void gn_coeffs(const float *ga, const float *be, float inv_hw, int e,
-                                          bool uniform, float mean, float rstd, float a[4], float b[4]) {
-  if (uniform) {  // HW % 4 == 0: the 4 lanes of a float4 share one channel
-    const int c = chan_of(e, inv_hw);
-    const float aa = rstd * ga[c];
-    const float bb = be[c] - mean * aa;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { a[j] = aa; b[j] = bb; }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = chan_of(e + j, inv_hw);
-      a[j] = rstd * ga[c];
-      b[j] = be[c] - mean * a[j];
-    }
-  }
-}
-
-// thread c (< Cg) of the (sample, group) workgroup writes channel cbase + c's coefficients — gn_coeffs' expressions
-__device__ __forceinline__ void gn_store_ab(const GnArgs &A, int ng, int cbase, const float *ga, const float *be,
-                                            float mean, float rstd) {
-  const int G = A.C / A.Cg, n = ng / G, c = threadIdx.x;
-  const float aa = rstd * ga[c];
-  const float bb = be[c] - mean * aa;
-  float *dst = A.ab + 2 * ((size_t)n * A.C + cbase + c);
-  dst[0] = aa;
-  dst[1] = bb;
-}
-
-template <bool NT>
-__device__ __forceinline__ f4 ld4(const f4 *p) {
-  if (NT) return __builtin_nontemporal_load(p);
-  return *p;
-}
-
-template <bool NT>
-__device__ __forceinline__ void st4(f4 *p, f4 v) {
-  if (NT) __builtin_nontemporal_store(v, p);
-  else *p = v;
-}
-
-// One workgroup per (sample, group); the group (L = Cg*HW floats, L % 4 == 0) lives in
-// registers: V float4 per thread, T threads, V*T*4 >= L.
-//
-// Memory-level parallelism is the whole game here (the kernels are pure HBM streams with two block
-// reductions in the middle): every load of a phase is issued BEFORE the first use of any of them — no
-// per-element `if (i < L4)` around a load (a branch per element makes the compiler wait for each load
-// before issuing the next: one 1 KiB request in flight per wave).  Out-of-range lanes load element 0
-// (always valid) and are masked out of the sums / skipped by the stores.
-//   NT: non-temporal loads / stores (every tensor here is >> the caches and is next touched by a
-//       different kernel);
-//   LC: the group's gamma / beta are staged in LDS once per workgroup (needs Cg <= kGnLdsCh) instead
-//       of 2 global gathers per float4 in the store phase;
-//   MW: minimum waves per SIMD asked of the register allocator.
-template <int V, int T, bool NT, bool LC, int MW>
-__global__ __launch_bounds__(T, MW) void k_gn_relu_fwd(GnArgs A, float *__restrict__ y,
-                                                       float *__restrict__ mean_out,
-                                                       float *__restrict__ rstd_out) {
-  __shared__ float sm1[T / 64], sm2[T / 64];
-  __shared__ float s_gb[LC ? 2 * kGnLdsCh : 2];
-  const int ng = blockIdx.x;
-  const int G = A.C / A.Cg;
-  const int cbase = (ng % G) * A.Cg;
-  const int L = A.Cg * A.HW, L4 = L >> 2;
-  if (LC && (int)threadIdx.x < A.Cg) {  // visible after the first reduction's barrier
-    s_gb[threadIdx.x] = A.gamma[cbase + threadIdx.x];
-    s_gb[kGnLdsCh + threadIdx.x] = A.beta[cbase + threadIdx.x];
-  }
-  const f4 *x4 = reinterpret_cast<const f4 *>(A.x + (size_t)ng * L);
-  f4 *y4 = reinterpret_cast<f4 *>(y + (size_t)ng * L);
-  f4 v[V];
-#pragma unroll
-  for (int k = 0; k < V; ++k) {
-    const int i = threadIdx.x + k * T;
-    v[k] = ld4<NT>(x4 + (i < L4 ? i : 0));
-  }
-  if (A.res) {  // fused residual add (block output + shortcut): one extra read, one extra write
-    const f4 *r4 = reinterpret_cast<const f4 *>(A.res + (size_t)ng * L);
-    f4 *s4 = reinterpret_cast<f4 *>(A.sum_out + (size_t)ng * L);
-    constexpr int CH = V <= 7 ? V : 6;  // residual loads in flight at once (registers: V + CH float4)
-#pragma unroll
-    for (int k0 = 0; k0 < V; k0 += CH) {
-      f4 r[CH];
-#pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const int i = threadIdx.x + (k0 + c) * T;
-        if (k0 + c < V) r[c] = ld4<NT>(r4 + (i < L4 ? i : 0));
-      }
-#pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const int k = k0 + c;
-        if (k < V) {
-          const int i = threadIdx.x + k * T;
-          v[k] += r[c];
-          if (i < L4) st4<NT>(s4 + i, v[k]);
-        }
-      }
-    }
-  }
-  float s = 0.f;
-#pragma unroll
-  for (int k = 0; k < V; ++k) {
-    const int i = threadIdx.x + k * T;
-    const float t = (v[k].x + v[k].y) + (v[k].z + v[k].w);
-    s += (i < L4) ? t : 0.f;
-  }
-  const float mean = block_allsum<T>(s, sm1) / (float)L;
-  float q = 0.f;
-#pragma unroll
-  for (int k = 0; k < V; ++k) {
-    const int i = threadIdx.x + k * T;
-    const f4 d = v[k] - mean;
-    const float t = (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
-    q += (i < L4) ? t : 0.f;
-  }
-  const float var = block_allsum<T>(q, sm2) / (float)L;  // biased, exact two-pass
-  const float rstd = 1.f / sqrtf(var + A.eps);
-  if (threadIdx.x == 0) {
-    mean_out[ng] = mean;
-    rstd_out[ng] = rstd;
-  }
-  const float *ga = LC ? s_gb : A.gamma + cbase;
-  const float *be = LC ? s_gb + kGnLdsCh : A.beta + cbase;
-  if (A.ab && (int)threadIdx.x < A.Cg) gn_store_ab(A, ng, cbase, ga, be, mean, rstd);
-  if (!y) return;                       // statistics-only pass (uniform): the consumer applies the affine + ReLU itself
-  const bool uniform = (A.HW & 3) == 0;
-#pragma unroll
-  for (int k = 0; k < V; ++k) {
-    const int i = threadIdx.x + k * T;
-    float a[4], b[4];
-    gn_coeffs(ga, be, A.inv_hw, (i < L4 ? i : 0) << 2, uniform, mean, rstd, a, b);
-    f4 o;
-    o.x = fmaxf(v[k].x * a[0] + b[0], 0.f);
-    o.y = fmaxf(v[k].y * a[1] + b[1], 0.f);
-    o.z = fmaxf(v[k].z * a[2] + b[2], 0.f);
-    o.w = fmaxf(v[k].w * a[3] + b[3], 0.f);
-    if (i < L4) st4<NT>(y4 + i, o);
-  }
-}
-
-// dx = rstd * (dxh - mean_L(dxh) - xh * mean_L(dxh * xh)),  dxh = dy * [z > 0] * gamma,
-// xh = (x - mean) * rstd,  z = x * a + b (the forward's own expression, so the gate is
-// bit-consistent with the y the forward wrote).  x and dy are requested up front (2V loads in flight per
-// lane); the shortcut gradient, if present, is fetched after the reductions in batches of <= 4 float4.
-template <int V, int T, bool NT, bool LC, int MW>
-__global__ __launch_bounds__(T, MW) void k_gn_relu_bwd(GnArgs A, const float *__restrict__ dy,
-                                                       const float *__restrict__ mean_in,
-                                                       const float *__restrict__ rstd_in,
-                                                       float *__restrict__ dx) {
-  __shared__ float sm1[T / 64], sm2[T / 64];
-  __shared__ float s_gb[LC ? 2 * kGnLdsCh : 2];
-  const int ng = blockIdx.x;
-  const int G = A.C / A.Cg;
-  const int cbase = (ng % G) * A.Cg;
-  const int L = A.Cg * A.HW, L4 = L >> 2;
-  const GnSource src = gn_source(A, ng, (size_t)L);
-  const f4 *x4 = reinterpret_cast<const f4 *>(src.x);
-  const f4 *g4 = reinterpret_cast<const f4 *>(dy + (size_t)ng * L);
-  f4 *o4 = reinterpret_cast<f4 *>(dx + (size_t)ng * L);
-  f4 xh[V], dh[V];  // raw x / dy first, transformed in place below
-#pragma unroll
-  for (int k = 0; k < V; ++k) {
-    const int i = threadIdx.x + k * T;
-    const int ic = i < L4 ? i : 0;
-    xh[k] = ld4<NT>(x4 + ic);
-    dh[k] = ld4<NT>(g4 + ic);
-  }
-  if (LC) {
-    if ((int)threadIdx.x < A.Cg) {
-      s_gb[threadIdx.x] = A.gamma[cbase + threadIdx.x];
-      s_gb[kGnLdsCh + threadIdx.x] = A.beta[cbase + threadIdx.x];
-    }
-    __syncthreads();  // the coefficients are needed before the first reduction
-  }
-  const float *ga = LC ? s_gb : A.gamma + cbase;
-  const float *be = LC ? s_gb + kGnLdsCh : A.beta + cbase;
-  const float mean = mean_in[src.stat], rstd = rstd_in[src.stat];
-  const bool uniform = (A.HW & 3) == 0;
-  float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-  for (int k = 0; k < V; ++k) {
-    const int i = threadIdx.x + k * T;
-    const bool ok = i < L4;
-    float a[4], b[4];
-    gn_coeffs(ga, be, A.inv_hw, (ok ? i : 0) << 2, uniform, mean, rstd, a, b);
-    const float xs[4] = {xh[k].x, xh[k].y, xh[k].z, xh[k].w};
-    const float gs[4] = {dh[k].x, dh[k].y, dh[k].z, dh[k].w};
-    float xo[4], go[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float z = xs[j] * a[j] + b[j];
-      xo[j] = (xs[j] - mean) * rstd;
-      // a = rstd * gamma  =>  dz * gamma = dz * a / rstd; keep gamma explicit via a * (1/rstd)
-      go[j] = (ok && z > 0.f) ? gs[j] * a[j] : 0.f;  // = dxh * rstd
-      s1 += go[j];
-      s2 += go[j] * xo[j];
-    }
-    xh[k] = f4{xo[0], xo[1], xo[2], xo[3]};
-    dh[k] = f4{go[0], go[1], go[2], go[3]};
-  }
-  const float m1 = block_allsum<T>(s1, sm1) / (float)L;
-  const float m2 = block_allsum<T>(s2, sm2) / (float)L;
-  if (A.dres) {  // gradient arriving through the shortcut (fused autograd add)
-    const f4 *d4 = reinterpret_cast<const f4 *>(A.dres + (size_t)ng * L);
-    constexpr int CH = V > 4 ? 4 : V;
-#pragma unroll
-    for (int k0 = 0; k0 < V; k0 += CH) {
-      f4 dr[CH];
-#pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const int i = threadIdx.x + (k0 + c) * T;
-        if (k0 + c < V) dr[c] = ld4<NT>(d4 + (i < L4 ? i : 0));
-      }
-#pragma unroll
-      for (int c = 0; c < CH; ++c) {
-        const int k = k0 + c;
-        if (k < V) {
-          const int i = threadIdx.x + k * T;
-          const f4 o = ((dh[k] - m1) - xh[k] * m2) + dr[c];  // rstd already folded into dh (a = rstd*gamma)
-          if (i < L4) st4<NT>(o4 + i, o);
-        }
-      }
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-      const int i = threadIdx.x + k * T;
-      const f4 o = (dh[k] - m1) - xh[k] * m2;
-      if (i < L4) st4<NT>(o4 + i, o);
-    }
-  }
-}
-
-// Backward for the large groups of 384 x 384 inputs: V = 9 (36 864 floats: 512 ch @ 48 x 48, 128 ch @ 96 x 96) and
-// V = 18 float4 per thread x 1024 threads (73 728 floats: 256 ch @ 96 x 96).  At V = 18, x and dy together are 590 KB —
-// more than a workgroup's registers (1024 threads x 128 VGPRs = 512 KB) — so the CU's two on-chip memories are used
-// together.  Per thread, of the V float4 of each operand:
-//   * dh = dy * gate * a (what both phases need) always stays in REGISTERS (V float4);
-//   * xh of the first XR float4 stays in registers, of the next XL float4 goes to LDS (XL * 16 KB of the CU's 160 KB;
-//     one float4 per lane per slot: conflict-free, own slots only: no barrier);
-//   * the remaining V - XR - XL float4 of x are re-read after the reductions (this workgroup's own lines: L2 / MALL).
-// V = 9: XR = 9 (everything on chip, 12 B/elem of HBM traffic).  V = 18: XR = 0, XL = 9: 12 B/elem + the re-read half of
-// x, vs 20 B/elem for the streaming kernel (x and dy twice).  Loads are issued in batches of BT float4 per operand, all
-// of a batch before the first use of any of it; addresses are (uniform base + 32-bit lane offset) so that an in-flight
-// load costs one address VGPR, not two — with 1024 threads the budget is 128 VGPRs and dh alone takes 72 at V = 18.
-// Two things keep hipcc from spilling (1000 B per lane without them): the per-float4 channel test is compile-time
-// (HW % 4 == 0 is required; the launcher sends other shapes to the streaming kernel) — a run-time branch per unrolled
-// element splits the kernel into ~70 basic blocks and the allocator gives up —, and every batch re-derives its lane index
-// from a laundered copy, so the 36 clamped offsets / predicates are not all kept alive from the first load to the last store.
-constexpr int kGnBigT = 1024;
-
-template <bool NT>
-__device__ __forceinline__ f4 ld4_at(const float *base, uint32_t elem4) {
-  const f4 *p = reinterpret_cast<const f4 *>(reinterpret_cast<const char *>(base) + (size_t)(elem4 * 16u));
-  return ld4<NT>(p);
-}
-
-template <int V, int XR, int XL, int BT>
-__global__ __launch_bounds__(kGnBigT, 1) void k_gn_relu_bwd_big(GnArgs A, const float *__restrict__ dy,
-                                                                const float *__restrict__ mean_in,
-                                                                const float *__restrict__ rstd_in,
-                                                                float *__restrict__ dx) {
-  constexpr int T = kGnBigT;
-  static_assert(V % BT == 0 && XR % BT == 0 && XL % BT == 0 && XR + XL <= V, "batches must not straddle the placements");
-  __shared__ float sm1[T / 64], sm2[T / 64];
-  __shared__ float s_gb[2 * kGnLdsCh];
-  __shared__ f4 s_xh[XL > 0 ? XL * T : 1];
-  const int ng = blockIdx.x;
-  const int G = A.C / A.Cg;
-  const int cbase = (ng % G) * A.Cg;
-  const int L = A.Cg * A.HW, L4 = L >> 2;
-  const GnSource src = gn_source(A, ng, (size_t)L);
-  const float *xb = src.x;
-  const float *gb = dy + (size_t)ng * L;
-  f4 *o4 = reinterpret_cast<f4 *>(dx + (size_t)ng * L);
-  if ((int)threadIdx.x < A.Cg) {
-    s_gb[threadIdx.x] = A.gamma[cbase + threadIdx.x];
-    s_gb[kGnLdsCh + threadIdx.x] = A.beta[cbase + threadIdx.x];
-  }
-  __syncthreads();
-  const float *ga = s_gb, *be = s_gb + kGnLdsCh;
-  const float mean = mean_in[src.stat], rstd = rstd_in[src.stat];
-  constexpr bool uniform = true;   // the launcher sends HW % 4 != 0 to the streaming kernel
-  f4 dh[V];
-  f4 xk[XR > 0 ? XR : 1];
-  float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-  for (int k0 = 0; k0 < V; k0 += BT) {
-    f4 xr[BT];
-    int tid = threadIdx.x;
-    DP_LAUNDER(tid);
-#pragma unroll
-    for (int c = 0; c < BT; ++c) {
-      const int i = tid + (k0 + c) * T;
-      const uint32_t ic = i < L4 ? (uint32_t)i : 0u;
-      xr[c] = ld4_at<true>(xb, ic);
-      dh[k0 + c] = ld4_at<true>(gb, ic);
-    }
-#pragma unroll
-    for (int c = 0; c < BT; ++c) {
-      const int k = k0 + c;
-      const int i = tid + k * T;
-      const bool ok = i < L4;
-      float a[4], b[4];
-      gn_coeffs(ga, be, A.inv_hw, (ok ? i : 0) << 2, uniform, mean, rstd, a, b);
-      const float xs[4] = {xr[c].x, xr[c].y, xr[c].z, xr[c].w};
-      const float gs[4] = {dh[k].x, dh[k].y, dh[k].z, dh[k].w};
-      float xo[4], go[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float z = xs[j] * a[j] + b[j];
-        xo[j] = (xs[j] - mean) * rstd;
-        go[j] = (ok && z > 0.f) ? gs[j] * a[j] : 0.f;
-        s1 += go[j];
-        s2 += go[j] * xo[j];
-      }
-      dh[k] = f4{go[0], go[1], go[2], go[3]};
-      if (k < XR) xk[k] = f4{xo[0], xo[1], xo[2], xo[3]};
-      else if (k < XR + XL) s_xh[(k - XR) * T + tid] = f4{xo[0], xo[1], xo[2], xo[3]};
-    }
-    __builtin_amdgcn_sched_barrier(0);  // keep the batches apart: hoisting the next batch's loads is what spills
-  }
-  const float m1 = block_allsum<T>(s1, sm1) / (float)L;
-  const float m2 = block_allsum<T>(s2, sm2) / (float)L;
-  const float *db = A.dres ? A.dres + (size_t)ng * L : nullptr;
-#pragma unroll
-  for (int k0 = 0; k0 < V; k0 += BT) {
-    f4 xr[BT], dr[BT];
-    int tid = threadIdx.x;
-    DP_LAUNDER(tid);
-#pragma unroll
-    for (int c = 0; c < BT; ++c) {
-      const int i = tid + (k0 + c) * T;
-      const uint32_t ic = i < L4 ? (uint32_t)i : 0u;
-      if (k0 + c >= XR + XL) xr[c] = ld4_at<false>(xb, ic);   // re-read: this workgroup touched it microseconds ago
-      if (db) dr[c] = ld4_at<true>(db, ic);
-    }
-#pragma unroll
-    for (int c = 0; c < BT; ++c) {
-      const int k = k0 + c;
-      const int i = tid + k * T;
-      f4 xh;
-      if (k < XR) xh = xk[k];
-      else if (k < XR + XL) xh = s_xh[(k - XR) * T + tid];
-      else xh = (xr[c] - mean) * rstd;                        // the first phase's own expression
-      f4 o = (dh[k] - m1) - xh * m2;
-      if (db) o = o + dr[c];
-      if (i < L4) st4<true>(o4 + i, o);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-
-// Streaming variants for groups too large for registers (e.g. 384x384 inputs): the group is
-// re-read from L2/HBM instead (forward 3 reads + 1 write, backward 4 reads + 1 write).
-constexpr int kGnStreamT = 1024;
-
-__global__ __launch_bounds__(kGnStreamT) void k_gn_relu_fwd_stream(GnArgs A, float *__restrict__ y,
-                                                                   float *__restrict__ mean_out,
-                                                                   float *__restrict__ rstd_out) {
-  constexpr int T = kGnStreamT;
-  __shared__ float sm1[T / 64], sm2[T / 64];
-  const int ng = blockIdx.x;
-  const int G = A.C / A.Cg;
-  const int cbase = (ng % G) * A.Cg;
-  const int L = A.Cg * A.HW, L4 = L >> 2;
-  const f4 *x4 = reinterpret_cast<const f4 *>(A.x + (size_t)ng * L);
-  f4 *y4 = reinterpret_cast<f4 *>(y + (size_t)ng * L);
-  float s = 0.f;
-  if (A.res) {  // pass 0 materialises x + res; the later passes re-read it (each thread its own elements)
-    const f4 *r4 = reinterpret_cast<const f4 *>(A.res + (size_t)ng * L);
-    f4 *s4 = reinterpret_cast<f4 *>(A.sum_out + (size_t)ng * L);
-    for (int i = threadIdx.x; i < L4; i += T) {
-      const f4 v = x4[i] + r4[i];
-      s4[i] = v;
-      s += (v.x + v.y) + (v.z + v.w);
-    }
-    x4 = s4;
-  } else {
-    for (int i = threadIdx.x; i < L4; i += T) {
-      const f4 v = x4[i];
-      s += (v.x + v.y) + (v.z + v.w);
-    }
-  }
-  const float mean = block_allsum<T>(s, sm1) / (float)L;
-  float q = 0.f;
-  for (int i = threadIdx.x; i < L4; i += T) {
-    const f4 d = x4[i] - mean;
-    q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
-  }
-  const float var = block_allsum<T>(q, sm2) / (float)L;
-  const float rstd = 1.f / sqrtf(var + A.eps);
-  if (threadIdx.x == 0) {
-    mean_out[ng] = mean;
-    rstd_out[ng] = rstd;
-  }
-  if (A.ab && (int)threadIdx.x < A.Cg) gn_store_ab(A, ng, cbase, A.gamma + cbase, A.beta + cbase, mean, rstd);
-  if (!y) return;
-  const bool uniform = (A.HW & 3) == 0;
-  for (int i = threadIdx.x; i < L4; i += T) {
-    const f4 v = x4[i];
-    float a[4], b[4];
-    gn_coeffs(A.gamma + cbase, A.beta + cbase, A.inv_hw, i << 2, uniform, mean, rstd, a, b);
-    f4 o;
-    o.x = fmaxf(v.x * a[0] + b[0], 0.f);
-    o.y = fmaxf(v.y * a[1] + b[1], 0.f);
-    o.z = fmaxf(v.z * a[2] + b[2], 0.f);
-    o.w = fmaxf(v.w * a[3] + b[3], 0.f);
-    y4[i] = o;
-  }
-}
-
-__global__ __launch_bounds__(kGnStreamT) void k_gn_relu_bwd_stream(
-    GnArgs A, const float *__restrict__ dy, const float *__restrict__ mean_in,
-    const float *__restrict__ rstd_in, float *__restrict__ dx) {
-  constexpr int T = kGnStreamT;
-  __shared__ float sm1[T / 64], sm2[T / 64];
-  const int ng = blockIdx.x;
-  const int G = A.C / A.Cg;
-  const int cbase = (ng % G) * A.Cg;
-  const int L = A.Cg * A.HW, L4 = L >> 2;
-  const GnSource src = gn_source(A, ng, (size_t)L);
-  const f4 *x4 = reinterpret_cast<const f4 *>(src.x);
-  const f4 *g4 = reinterpret_cast<const f4 *>(dy + (size_t)ng * L);
-  f4 *o4 = reinterpret_cast<f4 *>(dx + (size_t)ng * L);
-  const float mean = mean_in[src.stat], rstd = rstd_in[src.stat];
-  const bool uniform = (A.HW & 3) == 0;
-  float s1 = 0.f, s2 = 0.f;
-  for (int i = threadIdx.x; i < L4; i += T) {
-    const f4 xv = x4[i], gv = g4[i];
-    float a[4], b[4];
-    gn_coeffs(A.gamma + cbase, A.beta + cbase, A.inv_hw, i << 2, uniform, mean, rstd, a, b);
-    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-    const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float z = xs[j] * a[j] + b[j];
-      const float go = (z > 0.f) ? gs[j] * a[j] : 0.f;
-      s1 += go;
-      s2 += go * ((xs[j] - mean) * rstd);
-    }
-  }
-  const float m1 = block_allsum<T>(s1, sm1) / (float)L;
-  const float m2 = block_allsum<T>(s2, sm2) / (float)L;
-  for (int i = threadIdx.x; i < L4; i += T) {
-    const f4 xv = x4[i], gv = g4[i];
-    float a[4], b[4];
-    gn_coeffs(A.gamma + cbase, A.beta + cbase, A.inv_hw, i << 2, uniform, mean, rstd, a, b);
-    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-    const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
-    float o[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float z = xs[j] * a[j] + b[j];
-      const float go = (z > 0.f) ? gs[j] * a[j] : 0.f;
-      o[j] = (go - m1) - ((xs[j] - mean) * rstd) * m2;
-    }
-    f4 ov = f4{o[0], o[1], o[2], o[3]};
-    if (A.dres) ov += reinterpret_cast<const f4 *>(A.dres + (size_t)ng * L)[i];
-    o4[i] = ov;
-  }
-}
-
-
-// ----------------------------------------------------------------------------
-// a-8 (backbone stem): ConstantPad2d(1, 0) + MaxPool2d(3, stride 2), fused, forward and
-// backward (the "fixed" BiT stem, timm 0.6.7 resnetv2 create_resnetv2_stem; reference call
-// sites utils.py:51-63, attack.py:222, 247).  Eager PyTorch materialises the padded tensor
-// and its max-pool backward scatters; here the forward reads the conv output once and emits
-// the pooled map + a 1-byte argmax code, the backward is a gather (no atomics, float4 stores).
-// Window of output (oh, ow): input rows 2oh-1..2oh+1, cols 2ow-1..2ow+1, out-of-range = 0 and
-// participates in the max exactly like the padded tensor does; ties: first in row-major
-// window order (strict >), NaN wins — torch's max_pool2d rule.  code = 3*r + c of the winner.
-// Requires Hin even, Win % 8 == 0 (so an output row is whole float4s and no bottom/right pad).
-// ----------------------------------------------------------------------------
-
-// Launch geometry of both pooling kernels: blockDim (16, 8), grid (NC, rows / 8): a thread's plane, row and
-// 8-pixel column group come straight from the block / thread indices.  (A flat 1-D index needs two 64-bit
-// divisions per thread, which made these kernels instruction-bound: ~550 instructions per 32 bytes stored.)
-constexpr int kPoolRunGroups = 8;
-constexpr int kPoolTX = 16, kPoolTY = 8;   // 8 rows: 56 and 112 are multiples (a 16-row block idles 1/8 of the forward)
-
-// MODE (which rows a workgroup owns; tools/kbench sweeps them, the C ABI uses kPoolDefaultMode):
-//   0  grid (plane, row group): consecutive workgroups touch DIFFERENT planes (round-2 form: 3.5 KiB pieces of 32 768
-//      planes interleaved — 3.6 TB/s for the backward in every step trace, profiles/r03a_kbench_pool.txt reproduces it
-//      with cold 512-sample operands);
-//   1  grid.x = plane * row groups + row group: consecutive workgroups write consecutive 3.5 KiB pieces (a linear stream);
-//   2  one workgroup per plane, looping over its row groups (50 KiB contiguous per workgroup, but the workgroups in
-//      flight are again spread over thousands of planes: as slow as 0);
-//   4  linear order like 1, each workgroup a run of kPoolRunGroups consecutive row groups (28 KiB contiguous in the
-//      backward): the write-only calibration reaches 5.7 TB/s for exactly that shape (32 KiB per workgroup, in order).
-template <int MODE>
-__global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_fwd(const float *__restrict__ x, int Hin,
-                                                                       int Win, int nrg, float *__restrict__ y,
-                                                                       uint32_t *__restrict__ code4) {
-  const int Ho = Hin >> 1, Wq = Win >> 3;  // Wo/4 quads per output row
-  long nc;
-  int rg0, rg_step;
-  int rg_end = nrg;
-  if (MODE == 0) { nc = blockIdx.x; rg0 = blockIdx.y; rg_step = nrg; }
-  else if (MODE == 1) { nc = blockIdx.x / (unsigned)nrg; rg0 = (int)(blockIdx.x - (unsigned)nc * (unsigned)nrg); rg_step = nrg; }
-  else if (MODE == 4) {
-    const unsigned runs = (unsigned)((nrg + kPoolRunGroups - 1) / kPoolRunGroups);
-    nc = blockIdx.x / runs;
-    rg0 = (int)(blockIdx.x - (unsigned)nc * runs) * kPoolRunGroups;
-    rg_step = 1;
-    rg_end = min(nrg, rg0 + kPoolRunGroups);
-  } else { nc = blockIdx.x; rg0 = 0; rg_step = 1; }
-  for (int rg = rg0; rg < rg_end; rg += rg_step) {
-  const int oh = rg * kPoolTY + threadIdx.y;
-  if (oh >= Ho) continue;
-  for (int q = threadIdx.x; q < Wq; q += kPoolTX) {
-  const long tid = (nc * Ho + oh) * Wq + q;
-  const float *xp = x + nc * (long)Hin * Win;
-  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-  unsigned code[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const int ih = 2 * oh - 1 + r;
-    float v[9];
-    if (ih >= 0) {  // ih <= Hin - 1 always (Hin even)
-      const float *row = xp + (long)ih * Win + 8 * q;
-      const f4 a = *reinterpret_cast<const f4 *>(row);
-      const f4 b = *reinterpret_cast<const f4 *>(row + 4);
-      v[0] = q > 0 ? row[-1] : 0.f;  // left pad
-      v[1] = a.x; v[2] = a.y; v[3] = a.z; v[4] = a.w;
-      v[5] = b.x; v[6] = b.y; v[7] = b.z; v[8] = b.w;
-    } else {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) v[k] = 0.f;  // top pad row
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float val = v[2 * j + c];
-        if (val > best[j] || val != val) {
-          best[j] = val;
-          code[j] = (unsigned)(3 * r + c);
-        }
-      }
-    }
-  }
-  reinterpret_cast<f4 *>(y)[tid] = f4{best[0], best[1], best[2], best[3]};
-  code4[tid] = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
-  }
-  }
-}
-
-// One thread = 8 consecutive input pixels of one row (two float4 stores).  They are covered by the 5 windows
-// ow = 4t .. 4t + 4 of each of the (1 or 2) output rows whose window contains the input row: per output row one
-// aligned float4 of dy + one aligned 4-byte word of codes + the halo element of each (3x fewer memory
-// instructions per byte than a thread per float4 with scalar dy / byte-wide code loads).
-template <int MODE>
-__global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_bwd(const float *__restrict__ dy,
-                                                                       const uint8_t *__restrict__ code,
-                                                                       int Hin, int Win, int nrg,
-                                                                       float *__restrict__ dx) {
-  const int Ho = Hin >> 1, Wo = Win >> 1, W8 = Win >> 3;
-  long nc;
-  int rg0, rg_step;
-  int rg_end = nrg;
-  if (MODE == 0) { nc = blockIdx.x; rg0 = blockIdx.y; rg_step = nrg; }
-  else if (MODE == 1) { nc = blockIdx.x / (unsigned)nrg; rg0 = (int)(blockIdx.x - (unsigned)nc * (unsigned)nrg); rg_step = nrg; }
-  else if (MODE == 4) {
-    const unsigned runs = (unsigned)((nrg + kPoolRunGroups - 1) / kPoolRunGroups);
-    nc = blockIdx.x / runs;
-    rg0 = (int)(blockIdx.x - (unsigned)nc * runs) * kPoolRunGroups;
-    rg_step = 1;
-    rg_end = min(nrg, rg0 + kPoolRunGroups);
-  } else { nc = blockIdx.x; rg0 = 0; rg_step = 1; }
-  for (int rg = rg0; rg < rg_end; rg += rg_step) {
-  const int h = rg * kPoolTY + threadIdx.y;
-  if (h >= Hin) continue;
-  for (int t = threadIdx.x; t < W8; t += kPoolTX) {
-  const long tid = (nc * Hin + h) * W8 + t;
-  const float *dyp = dy + nc * (long)Ho * Wo;
-  const uint8_t *cp = code + nc * (long)Ho * Wo;
-  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const int a = h >> 1;
-  // (oh, r) pairs whose window contains input row h: even h -> (a, 1); odd h -> (a, 2) then (a + 1, 0)
-  const int n_rows = (h & 1) ? 2 : 1;
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    if (k >= n_rows) break;
-    const int oh = (h & 1) ? a + k : a;
-    const int r = (h & 1) ? (k == 0 ? 2 : 0) : 1;
-    if (oh >= Ho) continue;
-    const long base = (long)oh * Wo + 4 * t;  // Wo % 4 == 0: 16-byte aligned floats, 4-byte aligned codes
-    const f4 g4 = *reinterpret_cast<const f4 *>(dyp + base);
-    const uint32_t c4 = *reinterpret_cast<const uint32_t *>(cp + base);
-    const bool has4 = (4 * t + 4) < Wo;
-    const float g[5] = {g4.x, g4.y, g4.z, g4.w, has4 ? dyp[base + 4] : 0.f};
-    const unsigned c[5] = {c4 & 255u, (c4 >> 8) & 255u, (c4 >> 16) & 255u, c4 >> 24, has4 ? cp[base + 4] : 255u};
-    const unsigned rc = 3u * (unsigned)r;
-    // input col 8t + 2l     (even): window l, position c = 1
-    // input col 8t + 2l + 1 (odd):  window l (c = 2), then window l + 1 (c = 0)
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-      o[2 * l] += (c[l] == rc + 1u) ? g[l] : 0.f;
-      o[2 * l + 1] += (c[l] == rc + 2u) ? g[l] : 0.f;
-      o[2 * l + 1] += (c[l + 1] == rc + 0u) ? g[l + 1] : 0.f;
-    }
-  }
-  f4 *dst = reinterpret_cast<f4 *>(dx) + 2 * tid;
-  __builtin_nontemporal_store(f4{o[0], o[1], o[2], o[3]}, dst);
-  __builtin_nontemporal_store(f4{o[4], o[5], o[6], o[7]}, dst + 1);
-  }
-  }
-}
-
-// MODE 5 of the backward: MODE 1's work distribution, but the two float4 of a thread (32 adjacent bytes) are exchanged
-// through LDS so that every store INSTRUCTION writes lane-contiguous 16-byte pieces (1 KiB per wave, whole 128-byte lines)
-// instead of the first / second half of 64 thirty-two-byte chunks.  Win <= 128 (one column group per thread).
-__global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_bwd_t(const float *__restrict__ dy,
-                                                                         const uint8_t *__restrict__ code,
-                                                                         int Hin, int Win, int nrg,
-                                                                         float *__restrict__ dx) {
-  __shared__ f4 sst[kPoolTX * kPoolTY * 2];
-  const int Ho = Hin >> 1, Wo = Win >> 1, W8 = Win >> 3;
-  const long nc = blockIdx.x / (unsigned)nrg;
-  const int rg = (int)(blockIdx.x - (unsigned)nc * (unsigned)nrg);
-  const int h = rg * kPoolTY + threadIdx.y, t = threadIdx.x;
-  const bool live = h < Hin && t < W8;
-  const float *dyp = dy + nc * (long)Ho * Wo;
-  const uint8_t *cp = code + nc * (long)Ho * Wo;
-  float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (live) {
-    const int a = h >> 1;
-    const int n_rows = (h & 1) ? 2 : 1;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      if (k >= n_rows) break;
-      const int oh = (h & 1) ? a + k : a;
-      const int r = (h & 1) ? (k == 0 ? 2 : 0) : 1;
-      if (oh >= Ho) continue;
-      const long base = (long)oh * Wo + 4 * t;
-      const f4 g4 = *reinterpret_cast<const f4 *>(dyp + base);
-      const uint32_t c4 = *reinterpret_cast<const uint32_t *>(cp + base);
-      const bool has4 = (4 * t + 4) < Wo;
-      const float g[5] = {g4.x, g4.y, g4.z, g4.w, has4 ? dyp[base + 4] : 0.f};
-      const unsigned c[5] = {c4 & 255u, (c4 >> 8) & 255u, (c4 >> 16) & 255u, c4 >> 24, has4 ? cp[base + 4] : 255u};
-      const unsigned rc = 3u * (unsigned)r;
-#pragma unroll
-      for (int l = 0; l < 4; ++l) {
-        o[2 * l] += (c[l] == rc + 1u) ? g[l] : 0.f;
-        o[2 * l + 1] += (c[l] == rc + 2u) ? g[l] : 0.f;
-        o[2 * l + 1] += (c[l + 1] == rc + 0u) ? g[l + 1] : 0.f;
-      }
-    }
-  }
-  const int tl = threadIdx.y * kPoolTX + threadIdx.x;
-  sst[2 * tl] = f4{o[0], o[1], o[2], o[3]};
-  sst[2 * tl + 1] = f4{o[4], o[5], o[6], o[7]};
-  __syncthreads();
-  const int wbase = tl & ~63, lane = tl & 63;
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int q = k * 64 + lane;             // 16-byte piece of this wave's 2 KiB, in address order
-    const int src = wbase + (q >> 1), half = q & 1;
-    const int sy = src / kPoolTX, sx = src - sy * kPoolTX;
-    const int hs = rg * kPoolTY + sy;
-    if (hs < Hin && sx < W8) {
-      f4 *dst = reinterpret_cast<f4 *>(dx) + 2 * ((nc * Hin + hs) * W8 + sx) + half;
-      __builtin_nontemporal_store(sst[2 * src + half], dst);
-    }
-  }
-}
-
-// MODE 3 of the backward: one thread = 8 consecutive input pixels of BOTH rows 2a and 2a + 1 (four float4 stores).  The
-// pair needs output rows a and a + 1 only (the even row's single window row is shared with the odd row), i.e. 2 instead
-// of 3 (dy float4 + code word + halo) load groups per 64 bytes stored, and ALL of them are issued before the first use
-// (the per-row form fetched the odd rows' second window row only after finishing the first: two dependent round trips).
-// Same summation order per pixel as the per-row form: bit-identical.  Workgroups in linear order (as MODE 1).
-__global__ __launch_bounds__(kPoolTX * kPoolTY) void k_pad_maxpool_bwd_pair(const float *__restrict__ dy,
-                                                                            const uint8_t *__restrict__ code,
-                                                                            int Hin, int Win, int nrg,
-                                                                            float *__restrict__ dx) {
-  const int Ho = Hin >> 1, Wo = Win >> 1, W8 = Win >> 3;
-  const long nc = blockIdx.x / (unsigned)nrg;
-  const int rg = (int)(blockIdx.x - (unsigned)nc * (unsigned)nrg);
-  const int a = rg * kPoolTY + threadIdx.y;
-  if (a >= Ho) return;
-  const float *dyp = dy + nc * (long)Ho * Wo;
-  const uint8_t *cp = code + nc * (long)Ho * Wo;
-  for (int t = threadIdx.x; t < W8; t += kPoolTX) {
-    const bool has_b = a + 1 < Ho, has4 = (4 * t + 4) < Wo;
-    const long base_a = (long)a * Wo + 4 * t, base_b = (long)(has_b ? a + 1 : a) * Wo + 4 * t;
-    const f4 ga4 = *reinterpret_cast<const f4 *>(dyp + base_a);
-    const f4 gb4 = *reinterpret_cast<const f4 *>(dyp + base_b);
-    const uint32_t ca4 = *reinterpret_cast<const uint32_t *>(cp + base_a);
-    const uint32_t cb4 = *reinterpret_cast<const uint32_t *>(cp + base_b);
-    const float gah = dyp[base_a + (has4 ? 4 : 0)], gbh = dyp[base_b + (has4 ? 4 : 0)];
-    const unsigned cah = cp[base_a + (has4 ? 4 : 0)], cbh = cp[base_b + (has4 ? 4 : 0)];
-    const float ga[5] = {ga4.x, ga4.y, ga4.z, ga4.w, has4 ? gah : 0.f};
-    const float gb[5] = {gb4.x, gb4.y, gb4.z, gb4.w, has4 ? gbh : 0.f};
-    const unsigned ca[5] = {ca4 & 255u, (ca4 >> 8) & 255u, (ca4 >> 16) & 255u, ca4 >> 24, has4 ? cah : 255u};
-    const unsigned cb[5] = {has_b ? (cb4 & 255u) : 255u, has_b ? ((cb4 >> 8) & 255u) : 255u, has_b ? ((cb4 >> 16) & 255u) : 255u,
-                            has_b ? (cb4 >> 24) : 255u, (has_b && has4) ? cbh : 255u};
-    float e[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {  // even input row 2a: window row a at r = 1 (codes 3, 4, 5)
-      e[2 * l] += (ca[l] == 4u) ? ga[l] : 0.f;
-      e[2 * l + 1] += (ca[l] == 5u) ? ga[l] : 0.f;
-      e[2 * l + 1] += (ca[l + 1] == 3u) ? ga[l + 1] : 0.f;
-    }
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {  // odd input row 2a + 1: window row a at r = 2 (codes 6, 7, 8) ...
-      o[2 * l] += (ca[l] == 7u) ? ga[l] : 0.f;
-      o[2 * l + 1] += (ca[l] == 8u) ? ga[l] : 0.f;
-      o[2 * l + 1] += (ca[l + 1] == 6u) ? ga[l + 1] : 0.f;
-    }
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {  // ... then window row a + 1 at r = 0 (codes 0, 1, 2)
-      o[2 * l] += (cb[l] == 1u) ? gb[l] : 0.f;
-      o[2 * l + 1] += (cb[l] == 2u) ? gb[l] : 0.f;
-      o[2 * l + 1] += (cb[l + 1] == 0u) ? gb[l + 1] : 0.f;
-    }
-    f4 *dst0 = reinterpret_cast<f4 *>(dx) + 2 * ((nc * Hin + 2 * a) * W8 + t);
-    f4 *dst1 = dst0 + 2 * W8;
-    __builtin_nontemporal_store(f4{e[0], e[1], e[2], e[3]}, dst0);
-    __builtin_nontemporal_store(f4{e[4], e[5], e[6], e[7]}, dst0 + 1);
-    __builtin_nontemporal_store(f4{o[0], o[1], o[2], o[3]}, dst1);
-    __builtin_nontemporal_store(f4{o[4], o[5], o[6], o[7]}, dst1 + 1);
-  }
-}
-
-constexpr int kPoolDefaultMode = 1;      // forward (profiles/r03b_kbench_pool.txt)
-constexpr int kPoolBwdDefaultMode = 5;   // backward: LDS-transposed stores 0.450 ms vs 0.508 (mode 1) vs 0.837 (row pairs, 3) — profiles/r03e_kbench_pool.txt.
-                                         // (A variant over linear 8-pixel items — no idle lanes on 14-of-16 column groups —
-                                         // measured exactly the same 0.453 ms and was removed.)
-
-int launch_pad_maxpool_fwd(int mode, const float *x, int64_t NC, int Hin, int Win, float *y, uint32_t *code4,
-                           hipStream_t st) {
-  const int nrg = cdiv(Hin >> 1, kPoolTY);
-  DP_REQUIRE(((mode >= 0 && mode <= 2) || mode == 4) && (mode == 0 || mode == 2 || NC * nrg <= 0x7fffffffL));
-  const dim3 block(kPoolTX, kPoolTY);
-  if (mode == 4) {
-    hipLaunchKernelGGL(k_pad_maxpool_fwd<4>, dim3((unsigned)(NC * cdiv(nrg, kPoolRunGroups))), block, 0, st, x, Hin, Win, nrg, y, code4);
-    return launch_status();
-  }
-  if (mode == 0) hipLaunchKernelGGL(k_pad_maxpool_fwd<0>, dim3((unsigned)NC, (unsigned)nrg), block, 0, st, x, Hin, Win, nrg, y, code4);
-  else if (mode == 1) hipLaunchKernelGGL(k_pad_maxpool_fwd<1>, dim3((unsigned)(NC * nrg)), block, 0, st, x, Hin, Win, nrg, y, code4);
-  else hipLaunchKernelGGL(k_pad_maxpool_fwd<2>, dim3((unsigned)NC), block, 0, st, x, Hin, Win, nrg, y, code4);
-  return launch_status();
-}
-
-int launch_pad_maxpool_bwd(int mode, const float *dy, const uint8_t *code, int64_t NC, int Hin, int Win, float *dx,
-                           hipStream_t st) {
-  const int nrg = cdiv(Hin, kPoolTY);
-  DP_REQUIRE(mode >= 0 && mode <= 5 && (mode == 0 || mode == 2 || NC * nrg <= 0x7fffffffL));
-  if (mode == 5 && (Win >> 3) > kPoolTX) mode = 1;      // the LDS-transposed stores handle one column group per thread
-  if (mode == 5) {
-    hipLaunchKernelGGL(k_pad_maxpool_bwd_t, dim3((unsigned)(NC * nrg)), dim3(kPoolTX, kPoolTY), 0, st, dy, code, Hin, Win, nrg, dx);
-    return launch_status();
-  }
-  if (mode == 4) {
-    hipLaunchKernelGGL(k_pad_maxpool_bwd<4>, dim3((unsigned)(NC * cdiv(nrg, kPoolRunGroups))), dim3(kPoolTX, kPoolTY), 0, st, dy, code, Hin, Win, nrg, dx);
-    return launch_status();
-  }
-  const dim3 block(kPoolTX, kPoolTY);
-  if (mode == 3) {
-    const int nrg2 = cdiv(Hin >> 1, kPoolTY);
-    hipLaunchKernelGGL(k_pad_maxpool_bwd_pair, dim3((unsigned)(NC * nrg2)), block, 0, st, dy, code, Hin, Win, nrg2, dx);
-    return launch_status();
-  }
-  if (mode == 0) hipLaunchKernelGGL(k_pad_maxpool_bwd<0>, dim3((unsigned)NC, (unsigned)nrg), block, 0, st, dy, code, Hin, Win, nrg, dx);
-  else if (mode == 1) hipLaunchKernelGGL(k_pad_maxpool_bwd<1>, dim3((unsigned)(NC * nrg)), block, 0, st, dy, code, Hin, Win, nrg, dx);
-  else hipLaunchKernelGGL(k_pad_maxpool_bwd<2>, dim3((unsigned)NC), block, 0, st, dy, code, Hin, Win, nrg, dx);
-  return launch_status();
-}
-
-
-// ----------------------------------------------------------------------------
-// a-8 (backbone stem): input gradient of the 7x7 / stride 2 / pad 3 stem convolution,
-// d loss / d image (N,3,H,W) from d loss / d stem-out (N,K,H/2,W/2) — the last conv of the
-// backward pass and the tensor dp_apply_bwd consumes (reference attack.py:247).  With only 3 output
-// channels it is a poor fit for library implicit-GEMM / Winograd kernels (4 ms per 256 samples
-// measured for MIOpen's); here it is a direct gather on the fp32 VALU:
-//   * a thread owns a 2x2 output quad (h = 2a+ph, w = 2b+pw) x 3 channels = 12 accumulators;
-//     the four parities use disjoint filter taps: i = ph + 5 - 2r, j = pw + 5 - 2s over the 4x4
-//     patch dy[a-1+r][b-1+s]  (3x3, 3x4, 4x3, 4x4 taps: all 49 weights exactly once per (k, c));
-//   * the filter is read through wave-uniform scalar loads (SGPR operands of v_fmac), so the
-//     inner loop is 147 FMAs per 16 LDS reads per input channel k;
-//   * dy tiles (16x16 quads + 3 halo) are staged through LDS one k-plane at a time.
-// fmaf is used explicitly (one rounding per MAC; the file is built with -ffp-contract=off).
-// ----------------------------------------------------------------------------
-
-constexpr int SQ = 16;            // quads per tile side; a thread owns 2 vertically adjacent quads -> 128 threads
-constexpr int ST = SQ + 3;        // dy tile side (halo: 1 before, 2 after)
-constexpr int STP = 24;           // LDS row pitch: 2 * STP mod 32 == 16 -> the 4 quad-row pairs of a wave hit disjoint banks
-constexpr int kStemBlock = (SQ / 2) * SQ;
-
-// Thread (ta, tb) owns the U vertically adjacent output quads (U ta .. U ta + U - 1, tb) of the tile x 3 channels x 2 x 2
-// parities = 12 U accumulators, fed from a (U + 3) x 4 patch of the dy tile; the tile is 8 U x 16 quads, 128 threads.
-// U = 2 (shipped): 20 LDS reads and 147 scalar dwords per input channel for 294 FMAs.
-// What bounds it (round 3, tools/kbench fma_rate): on this GPU v_fmac_f32 / v_fma_f32 with all-VGPR operands sustain
-// 127 / 103-110 TFLOP/s and v_pk_fma_f32 121-123, but an FMA with an SGPR operand (either opcode) or a DPP-broadcast
-// operand (row_newbcast) only 71.5 — the half-rate path.  This kernel's FMAs take their tap from an SGPR: the 68 TFLOP/s
-// measured here is 95 % of THAT ceiling (43 % of the 157.3 TFLOP/s spec, which needs all-VGPR or packed operands).
-// U = 4 (half the scalar loads per FMA, 103 VGPRs, 4 waves/SIMD, a 32-row tile that wastes 1/8 of a 112-row plane) was
-// tried on the hypothesis that the scalar cache was the limit: 1.012 vs 0.887 ms — slower, bit-identical — and stays only
-// as kbench variant 2.  Getting past 72 TFLOP/s needs the taps as plain VGPR operands: a v_mov per tap eats the gain at 2
-// quads per thread, LDS broadcast reads of the taps would need twice the LDS bandwidth there is, DPP is half-rate too —
-// which leaves the matrix-core formulation (k_stem_dgrad_mfma below, ceiling 89).
-// The filter taps are wave-uniform: they arrive through scalar loads and are SGPR operands of the FMAs.
-// One input channel's 147 taps exceed the ~100 SGPRs a wave has, and a compiler left to schedule them all at
-// once spills SGPRs into VGPR lanes (v_writelane / v_readlane: as many instructions as the FMAs themselves —
-// the r01 kernel, 24.9 % of the fp32 VALU peak); so the taps are consumed one output channel (49) at a time,
-// fenced by scheduling barriers.
-template <int U>
-__global__ __launch_bounds__(kStemBlock) void k_stem_dgrad(const float *__restrict__ dy,
-                                                           const float *__restrict__ w, int K, int Ho,
-                                                           int Wo, float *__restrict__ dx) {
-  constexpr int SR = (kStemBlock / SQ) * U;   // quad rows per tile (16 or 32)
-  constexpr int STR = SR + 3;                 // dy tile rows (halo: 1 before, 2 after)
-  __shared__ float tile[2][STR + 1][STP];     // + 1 row: the dummy slot of lanes that stage nothing
-  const int n = blockIdx.z;
-  const int a0 = blockIdx.y * SR, b0 = blockIdx.x * SQ;
-  const int ta = threadIdx.x / SQ, tb = threadIdx.x % SQ;  // ta: group of quad rows U ta .. U ta + U - 1
-  const float *dyn = dy + (size_t)n * K * Ho * Wo;
-  float acc[U][3][2][2];
-#pragma unroll
-  for (int u = 0; u < U; ++u)
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int ph = 0; ph < 2; ++ph)
-#pragma unroll
-        for (int pw = 0; pw < 2; ++pw) acc[u][c][ph][pw] = 0.f;
-
-  // Staging of the 19 x 19 dy tile: a thread moves up to 3 elements per input channel.  Their tile / plane
-  // offsets do not depend on k, so they are computed once; the loads for channel k + 1 are issued BEFORE the
-  // FMAs of channel k and only written to LDS after them (software pipeline: their latency hides behind 294 FMAs
-  // instead of stalling the wave three times per channel).
-  constexpr int kStage = (STR * ST + kStemBlock - 1) / kStemBlock;  // 3 (U = 2), 6 (U = 4)
-  // Branch-free on purpose (one basic block per channel, so the order loads -> FMAs -> LDS stores survives the
-  // compiler): lanes with nothing to stage write a dummy slot behind the tile, halo lanes read element 0 of the
-  // plane and select 0.
-  int lds_off[kStage], g_off[kStage];
-  bool g_ok[kStage];
-#pragma unroll
-  for (int j = 0; j < kStage; ++j) {
-    const int e = threadIdx.x + j * kStemBlock;
-    const int r = e / ST, c = e - r * ST;
-    const int oh = a0 - 1 + r, ow = b0 - 1 + c;
-    lds_off[j] = e < STR * ST ? r * STP + c : STR * STP;
-    g_ok[j] = e < STR * ST && oh >= 0 && oh < Ho && ow >= 0 && ow < Wo;
-    g_off[j] = g_ok[j] ? oh * Wo + ow : 0;
-  }
-  float pre[kStage];
-  auto stage_load = [&](int k) {
-    const float *plane = dyn + (size_t)k * Ho * Wo;
-#pragma unroll
-    for (int j = 0; j < kStage; ++j) pre[j] = plane[g_off[j]];
-  };
-  auto stage_store = [&](int buf) {
-    float *t = &tile[buf][0][0];
-#pragma unroll
-    for (int j = 0; j < kStage; ++j) t[lds_off[j]] = g_ok[j] ? pre[j] : 0.f;
-  };
-
-  stage_load(0);
-  stage_store(0);
-  __syncthreads();
-  for (int k = 0; k < K; ++k) {
-    const int buf = k & 1;
-    stage_load(k + 1 < K ? k + 1 : k);  // in flight during this channel's FMAs (last channel: a harmless re-read)
-    __builtin_amdgcn_sched_barrier(0);
-    float p[U + 3][4];
-#pragma unroll
-    for (int r = 0; r < U + 3; ++r)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) p[r][q] = tile[buf][U * ta + r][tb + q];
-    const float *wk = w + (size_t)k * 147;  // wave-uniform: scalar loads
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      __builtin_amdgcn_sched_barrier(0);
-      float wc[49];
-#pragma unroll
-      for (int t = 0; t < 49; ++t) wc[t] = wk[c * 49 + t];
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph)
-#pragma unroll
-          for (int pw = 0; pw < 2; ++pw)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const int i = ph + 5 - 2 * r, j = pw + 5 - 2 * q;
-                if (i >= 0 && i <= 6 && j >= 0 && j <= 6)
-                  acc[u][c][ph][pw] = __builtin_fmaf(p[u + r][q], wc[i * 7 + j], acc[u][c][ph][pw]);
-              }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    stage_store(buf ^ 1);  // the other buffer was last read before the previous barrier
-    __syncthreads();
-  }
-  const int b = b0 + tb;
-  if (b >= Wo) return;
-  const int H = 2 * Ho, W = 2 * Wo;
-  float *dxn = dx + (size_t)n * 3 * H * W;
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int a = a0 + U * ta + u;
-    if (a >= Ho) continue;
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int ph = 0; ph < 2; ++ph) {
-        float2 o;
-        o.x = acc[u][c][ph][0];
-        o.y = acc[u][c][ph][1];
-        *reinterpret_cast<float2 *>(dxn + ((size_t)c * H + 2 * a + ph) * W + 2 * b) = o;
-      }
-  }
-}
-
-// The same input gradient on the MATRIX cores (round 3, VERDICT r2 item 8: "89 TFLOP/s on paper vs today's 67: try it").
-// One GEMM instead of four: rows = 16 output quads along a row, columns = the 12 outputs of a quad (2 x 2 parities x 3
-// channels, padded to 16), K = (input channel, tap of the 4 x 4 dy patch); taps a parity does not use get a ZERO weight,
-// so 147 * 4 of the 16 * 16 MACs per (quad, channel) are useful: 57 % of the f32 MFMA rate (= the vector rate).
-//   v_mfma_f32_16x16x4_f32:  A[i][k] in lane i + 16 k,  B[k][j] in lane j + 16 k,  D[i][j] in lane j + 16 (i / 4), reg i % 4
-// A workgroup = 16 x 16 quads of one sample, 4 waves x 4 quad rows each (4 accumulators of 4 VGPRs); per group of 4
-// input channels it stages the 19 x 19 x 4 dy patch and the zero-padded 4 x 16 x 16 weight block in LDS (one barrier
-// pair), then every wave issues 16 taps x 4 rows = 64 MFMAs, each fed by one LDS read (A; B is read once per tap).
-constexpr int kMT = 16;                 // quads per tile side
-constexpr int kMP = kMT + 3;            // dy patch side
-constexpr int kMPP = 20;                // LDS row pitch of the patch
-
-__global__ __launch_bounds__(256) void k_stem_dgrad_mfma(const float *__restrict__ dy, const float *__restrict__ w,
-                                                         int K, int Ho, int Wo, float *__restrict__ dx) {
-  __shared__ float s_dy[4][kMP][kMPP];
-  __shared__ float s_w[4][16][16];      // [kk][tap = 4 r + s][col = 3 (2 ph + pw) + c]
-  const int n = blockIdx.z;
-  const int a0 = blockIdx.y * kMT, b0 = blockIdx.x * kMT;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int li = lane & 15, lk = lane >> 4;
-  const float *dyn = dy + (size_t)n * K * Ho * Wo;
-  f4 acc[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < K; k0 += 4) {
-    __syncthreads();   // the previous group's MFMAs are done with the LDS blocks
-    for (int e = threadIdx.x; e < 4 * kMP * kMP; e += 256) {
-      const int kk = e / (kMP * kMP), rem = e - kk * (kMP * kMP);
-      const int pr = rem / kMP, pc = rem - pr * kMP;
-      const int a = a0 - 1 + pr, b = b0 - 1 + pc;
-      const bool ok = a >= 0 && a < Ho && b >= 0 && b < Wo;
-      s_dy[kk][pr][pc] = ok ? dyn[((size_t)(k0 + kk) * Ho + a) * Wo + b] : 0.f;
-    }
-    for (int e = threadIdx.x; e < 4 * 16 * 16; e += 256) {
-      const int kk = e >> 8, tap = (e >> 4) & 15, col = e & 15;
-      const int r = tap >> 2, q = tap & 3;
-      const int par = col / 3, c = col - 3 * par, ph = par >> 1, pw = par & 1;
-      const int i = ph + 5 - 2 * r, j = pw + 5 - 2 * q;
-      const bool ok = col < 12 && i >= 0 && i <= 6 && j >= 0 && j <= 6;
-      s_w[kk][tap][col] = ok ? w[((size_t)(k0 + kk) * 3 + c) * 49 + i * 7 + j] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int tap = 0; tap < 16; ++tap) {
-      const int r = tap >> 2, q = tap & 3;
-      const float bv = s_w[lk][tap][li];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float av = s_dy[lk][4 * wv + t + r][li + q];   // dy[k0 + lk][a - 1 + r][b0 + li - 1 + q], a = a0 + 4 wv + t
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
-      }
-    }
-  }
-  if (li >= 12) return;   // padding columns
-  const int par = li / 3, c = li - 3 * par, ph = par >> 1, pw = par & 1;
-  const int H = 2 * Ho, W = 2 * Wo;
-  float *dxc = dx + ((size_t)n * 3 + c) * H * W;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int a = a0 + 4 * wv + t;
-    if (a >= Ho) continue;
-    const float vals[4] = {acc[t].x, acc[t].y, acc[t].z, acc[t].w};
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int b = b0 + 4 * lk + rr;
-      if (b < Wo) dxc[(size_t)(2 * a + ph) * W + 2 * b + pw] = vals[rr];
-    }
-  }
-}
-
-
-// ----------------------------------------------------------------------------
-// a-8 + a-4 backward, fused: the stem input gradient of every EOT sample of an image, occlusion-masked and summed
-// over the samples in the same launch (k_stem_dgrad followed by k_apply_bwd, without the (N,3,H,W) per-sample
-// gradient ever reaching HBM: 602 112 B written + read per sample @224 saved, reference attack.py:247 through
-// the autograd of attack.py:206-220).  grid z = image * nslab + slab; a workgroup walks the slab's samples in
-// ascending order, runs k_stem_dgrad's channel loop for each (the dy planes of consecutive samples are
-// consecutive in memory, so the staging pipeline runs straight through), then adds the sample's 24 per-thread
-// results into the image accumulators where the pixel is not occluded.  Arithmetic and summation order are
-// exactly those of the two separate kernels (same slab partition): results are bit-identical.
-// ----------------------------------------------------------------------------
-__global__ __launch_bounds__(kStemBlock, 5) void k_stem_dgrad_reduce(
-    const float *__restrict__ dy, const float *__restrict__ w, const int32_t *__restrict__ table, int R,
-    const int32_t *__restrict__ idx, const int32_t *__restrict__ idx2, int idx_bstride, int B, int S,
-    int s_per_slab, int K, int Ho, int Wo, NormDev nd, float *__restrict__ slabs) {
-  __shared__ float tile[2][ST + 1][STP];
-  const int nslab = (S + s_per_slab - 1) / s_per_slab;
-  const int b = blockIdx.z / nslab, z = blockIdx.z - b * nslab;
-  const int s_begin = z * s_per_slab;
-  const int s_end = min(S, s_begin + s_per_slab);
-  const int a0 = blockIdx.y * SQ, b0 = blockIdx.x * SQ;
-  const int ta = threadIdx.x / SQ, tb = threadIdx.x % SQ;
-  const size_t plane_sz = (size_t)Ho * Wo;
-  const float *plane0 = dy + ((size_t)b * S + s_begin) * K * plane_sz;  // plane j of the slab = plane0 + j * plane_sz
-  const int n_planes = (s_end - s_begin) * K;
-  float acc[2][3][2][2], img[2][3][2][2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int ph = 0; ph < 2; ++ph)
-#pragma unroll
-        for (int pw = 0; pw < 2; ++pw) acc[u][c][ph][pw] = img[u][c][ph][pw] = 0.f;
-
-  constexpr int kStage = (ST * ST + kStemBlock - 1) / kStemBlock;
-  int lds_off[kStage], g_off[kStage];
-  bool g_ok[kStage];
-#pragma unroll
-  for (int j = 0; j < kStage; ++j) {
-    const int e = threadIdx.x + j * kStemBlock;
-    const int r = e / ST, c = e - r * ST;
-    const int oh = a0 - 1 + r, ow = b0 - 1 + c;
-    lds_off[j] = e < ST * ST ? r * STP + c : ST * STP;
-    g_ok[j] = e < ST * ST && oh >= 0 && oh < Ho && ow >= 0 && ow < Wo;
-    g_off[j] = g_ok[j] ? oh * Wo + ow : 0;
-  }
-  float pre[kStage];
-  auto stage_load = [&](int j) {
-    const float *plane = plane0 + (size_t)j * plane_sz;
-#pragma unroll
-    for (int q = 0; q < kStage; ++q) pre[q] = plane[g_off[q]];
-  };
-  auto stage_store = [&](int buf) {
-    float *t = &tile[buf][0][0];
-#pragma unroll
-    for (int q = 0; q < kStage; ++q) t[lds_off[q]] = g_ok[q] ? pre[q] : 0.f;
-  };
-
-  const int32_t *ib = idx + (size_t)b * idx_bstride;
-  const int32_t *ib2 = idx2 ? idx2 + (size_t)b * idx_bstride : nullptr;
-  const int h_base = 2 * (a0 + 2 * ta), w_base = 2 * (b0 + tb);  // pixel (h_base + 2u + ph, w_base + pw)
-
-  stage_load(0);
-  stage_store(0);
-  __syncthreads();
-  int k = 0, s = s_begin;
-  for (int j = 0; j < n_planes; ++j) {
-    const int buf = j & 1;
-    stage_load(j + 1 < n_planes ? j + 1 : j);
-    __builtin_amdgcn_sched_barrier(0);
-    float p[5][4];
-#pragma unroll
-    for (int r = 0; r < 5; ++r)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) p[r][q] = tile[buf][2 * ta + r][tb + q];
-    const float *wk = w + (size_t)k * 147;  // wave-uniform: scalar loads
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      __builtin_amdgcn_sched_barrier(0);
-      float wc[49];
-#pragma unroll
-      for (int t = 0; t < 49; ++t) wc[t] = wk[c * 49 + t];
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int ph = 0; ph < 2; ++ph)
-#pragma unroll
-          for (int pw = 0; pw < 2; ++pw)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const int i = ph + 5 - 2 * r, jj = pw + 5 - 2 * q;
-                if (i >= 0 && i <= 6 && jj >= 0 && jj <= 6)
-                  acc[u][c][ph][pw] = __builtin_fmaf(p[u + r][q], wc[i * 7 + jj], acc[u][c][ph][pw]);
-              }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (++k == K) {  // sample s complete: occlusion-masked accumulation into the image gradient (a-4 backward)
-      const int32_t *t1 = table + (size_t)ib[s] * R * 4;
-      const int32_t *t2 = ib2 ? table + (size_t)ib2[s] * R * 4 : nullptr;
-      unsigned occ = 0u;  // bit (u*2 + ph)*2 + pw
-      for (int pass = 0; pass < 2; ++pass) {
-        const int32_t *t = pass == 0 ? t1 : t2;
-        if (!t) continue;
-        for (int r = 0; r < R; ++r) {
-          const int r0 = t[4 * r + 0], r1 = t[4 * r + 1], c0 = t[4 * r + 2], c1 = t[4 * r + 3];
-#pragma unroll
-          for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int ph = 0; ph < 2; ++ph)
-#pragma unroll
-              for (int pw = 0; pw < 2; ++pw) {
-                const int h = h_base + 2 * u + ph, ww = w_base + pw;
-                occ |= (unsigned)((h >= r0) & (h < r1) & (ww >= c0) & (ww < c1)) << ((u * 2 + ph) * 2 + pw);
-              }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-          for (int ph = 0; ph < 2; ++ph)
-#pragma unroll
-            for (int pw = 0; pw < 2; ++pw) {
-              const bool o = (occ >> ((u * 2 + ph) * 2 + pw)) & 1u;
-              img[u][c][ph][pw] += o ? 0.f : acc[u][c][ph][pw];
-              acc[u][c][ph][pw] = 0.f;
-            }
-      k = 0;
-      ++s;
-    }
-    stage_store(buf ^ 1);
-    __syncthreads();
-  }
-  const int bq = b0 + tb;
-  if (bq >= Wo) return;
-  const int H = 2 * Ho, W = 2 * Wo;
-  float *dst = slabs + ((size_t)z * B + b) * 3 * H * W;
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int a = a0 + 2 * ta + u;
-    if (a >= Ho) continue;
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int ph = 0; ph < 2; ++ph) {
-        float2 o;
-        o.x = img[u][c][ph][0];
-        o.y = img[u][c][ph][1];
-        if (nd.enable) {  // d/dx (x - mean)/std = 1/std, applied once after the S-sum like k_apply_bwd
-          o.x = o.x / nd.std[c];
-          o.y = o.y / nd.std[c];
-        }
-        *reinterpret_cast<float2 *>(dst + ((size_t)c * H + 2 * a + ph) * W + 2 * bq) = o;
-      }
-  }
-}
-
-// ----------------------------------------------------------------------------
-// a-8 (backbone, strided 1x1 downsample convolutions): even-pixel subsampling and its accumulating adjoint.
-// One thread per pair of output pixels of one row: a 16-byte load of 4 input pixels yields outputs (.x, .z)
-// (W % 4 == 0), or one thread per output pixel with an 8-byte load (W % 4 == 2).
-// ----------------------------------------------------------------------------
-template <bool WIDE>
-__global__ __launch_bounds__(kBlock) void k_subsample2(const float *__restrict__ x, int H, int W, long total,
-                                                       float *__restrict__ y) {
-  const long tid = (long)blockIdx.x * kBlock + threadIdx.x;
-  if (tid >= total) return;
-  const int Ho = H >> 1, Wo = W >> 1;
-  if (WIDE) {
-    const int Wp = Wo >> 1;  // output pairs per row
-    const int t = (int)(tid % Wp);
-    const long row = tid / Wp;  // nc * Ho + oh
-    const long nc = row / Ho;
-    const int oh = (int)(row - nc * Ho);
-    const f4 v = *reinterpret_cast<const f4 *>(x + (nc * H + 2 * oh) * (long)W + 4 * t);
-    float2 o;
-    o.x = v.x;
-    o.y = v.z;
-    *reinterpret_cast<float2 *>(y + row * Wo + 2 * t) = o;
-  } else {
-    const int t = (int)(tid % Wo);
-    const long row = tid / Wo;
-    const long nc = row / Ho;
-    const int oh = (int)(row - nc * Ho);
-    const float2 v = *reinterpret_cast<const float2 *>(x + (nc * H + 2 * oh) * (long)W + 2 * t);
-    y[row * Wo + t] = v.x;
-  }
-}
-
-template <bool WIDE>
-__global__ __launch_bounds__(kBlock) void k_subsample2_add(const float *__restrict__ dy, int H, int W,
-                                                           long total, float *__restrict__ g) {
-  const long tid = (long)blockIdx.x * kBlock + threadIdx.x;
-  if (tid >= total) return;
-  const int Ho = H >> 1, Wo = W >> 1;
-  if (WIDE) {
-    const int Wp = Wo >> 1;
-    const int t = (int)(tid % Wp);
-    const long row = tid / Wp;
-    const long nc = row / Ho;
-    const int oh = (int)(row - nc * Ho);
-    const float2 d = *reinterpret_cast<const float2 *>(dy + row * Wo + 2 * t);
-    f4 *p = reinterpret_cast<f4 *>(g + (nc * H + 2 * oh) * (long)W + 4 * t);
-    f4 v = *p;
-    v.x += d.x;
-    v.z += d.y;
-    *p = v;
-  } else {
-    const int t = (int)(tid % Wo);
-    const long row = tid / Wo;
-    const long nc = row / Ho;
-    const int oh = (int)(row - nc * Ho);
-    float *p = g + (nc * H + 2 * oh) * (long)W + 2 * t;
-    *p = *p + dy[row * Wo + t];
-  }
-}
-
-// (V float4 per thread, T threads) combinations that are instantiated, smallest first; the
-// group must fit: V*T >= L4.  V >= 7 only with T = 1024 (launch bounds cap it at 128 VGPRs; at
-// T = 256/512 the compiler spends > 160 VGPRs on V = 7).  V = 0 => streaming kernel.
-inline void gn_pick(int L4, int &V, int &T) {
-  // (9, 1024) and (18, 1024) serve the forward of 384 x 384 inputs (groups of 36 864 and 73 728 floats)
-  static const int combos[8][2] = {{1, 256}, {2, 256}, {4, 256}, {4, 512}, {4, 1024}, {7, 1024}, {9, 1024}, {18, 1024}};
-  for (const auto &c : combos)
-    if (c[0] * c[1] >= L4) {
-      V = c[0];
-      T = c[1];
-      return;
-    }
-  V = 0;
-  T = kGnStreamT;
-}
-
-// GroupNorm kernel variant bits (tools/kbench.cpp sweeps them; the C ABI uses kGnDefaultVariant):
-//   1 = NT loads/stores, 2 = gamma/beta through LDS, 4 = forward V=7 kernel compiled for 8 waves/SIMD.
-// Measured on MI355X (profiles/r02b_kbench_gn_variants.txt, 256 samples): NT + LC is fastest on 17 of the 20
-// (shape, direction, residual) cases, by 8-21 % over neither; MW8 wins only for the forward without residual
-// (256ch@56x56: 0.270 vs 0.284 ms) and loses with it, so it is applied to that case alone.
-//   8 = (kbench A/B only) groups larger than V = 7 through the streaming backward, as in round 2.
-//  16 = (kbench A/B) the large-group backward loads all of an operand half at once (9 float4 per batch instead of 3).
-constexpr int kGnNT = 1, kGnLC = 2, kGnMW8 = 4, kGnStreamLarge = 8, kGnBigBatch = 16;
-constexpr int kGnDefaultVariant = kGnNT | kGnLC;
-
-#define DP_GN_FWD_VT(V_, T_, NT_, LC_, MW_) \
-  hipLaunchKernelGGL((k_gn_relu_fwd<V_, T_, NT_, LC_, MW_>), grid, dim3(T_), 0, st, A, y, mean, rstd)
-#define DP_GN_FWD_FLAGS(V_, T_, MW_)                                   \
-  do {                                                                 \
-    if (nt && lc) DP_GN_FWD_VT(V_, T_, true, true, MW_);               \
-    else if (nt) DP_GN_FWD_VT(V_, T_, true, false, MW_);               \
-    else if (lc) DP_GN_FWD_VT(V_, T_, false, true, MW_);               \
-    else DP_GN_FWD_VT(V_, T_, false, false, MW_);                      \
-  } while (0)
-
-int launch_gn_fwd(int variant, const GnArgs &A, int N, float *y, float *mean, float *rstd, hipStream_t st) {
-  const int L4 = (A.Cg * A.HW) >> 2;
-  int V, T;
-  gn_pick(L4, V, T);
-  const dim3 grid((unsigned)(N * (A.C / A.Cg)));
-  if (V > 7 && A.Cg > kGnLdsCh) V = 0;  // the large-group kernels stage gamma / beta in LDS
-  if (V == 0) {
-    hipLaunchKernelGGL(k_gn_relu_fwd_stream, grid, dim3(kGnStreamT), 0, st, A, y, mean, rstd);
-    return launch_status();
-  }
-  const bool nt = (variant & kGnNT) != 0, lc = (variant & kGnLC) != 0 && A.Cg <= kGnLdsCh;
-  if (T == 256 && V == 1) DP_GN_FWD_FLAGS(1, 256, 1);
-  else if (T == 256 && V == 2) DP_GN_FWD_FLAGS(2, 256, 1);
-  else if (T == 256) DP_GN_FWD_FLAGS(4, 256, 1);
-  else if (T == 512) DP_GN_FWD_FLAGS(4, 512, 1);
-  else if (V == 4) DP_GN_FWD_FLAGS(4, 1024, 1);
-  else if (V == 7 && ((variant & kGnMW8) || (variant == kGnDefaultVariant && !A.res))) DP_GN_FWD_FLAGS(7, 1024, 8);
-  else if (V == 7) DP_GN_FWD_FLAGS(7, 1024, 1);
-  else if (V == 9) DP_GN_FWD_VT(9, 1024, true, true, 1);
-  else DP_GN_FWD_VT(18, 1024, true, true, 1);
-  return launch_status();
-}
-
-#define DP_GN_BWD_VT(V_, T_, NT_, LC_) \
-  hipLaunchKernelGGL((k_gn_relu_bwd<V_, T_, NT_, LC_, 1>), grid, dim3(T_), 0, st, A, dy, mean, rstd, dx)
-#define DP_GN_BWD_FLAGS(V_, T_)                                        \
-  do {                                                                 \
-    if (nt && lc) DP_GN_BWD_VT(V_, T_, true, true);                    \
-    else if (nt) DP_GN_BWD_VT(V_, T_, true, false);                    \
-    else if (lc) DP_GN_BWD_VT(V_, T_, false, true);                    \
-    else DP_GN_BWD_VT(V_, T_, false, false);                           \
-  } while (0)
-
-int launch_gn_bwd(int variant, const GnArgs &A, int N, const float *dy, const float *mean, const float *rstd,
-                  float *dx, hipStream_t st) {
-  const int L4 = (A.Cg * A.HW) >> 2;
-  int V, T;
-  gn_pick(L4, V, T);
-  const dim3 grid((unsigned)(N * (A.C / A.Cg)));
-  // The backward needs x and dy on chip (2 x V float4 per thread): registers up to V = 9 (72 VGPRs of the 128 a
-  // 1024-thread workgroup may use); V = 18 splits them between registers and LDS (k_gn_relu_bwd_big).  Both stage
-  // gamma / beta in LDS, so groups of more than kGnLdsCh channels (and anything larger) take the streaming kernel.
-  if (V > 7 && (A.Cg > kGnLdsCh || (A.HW & 3) != 0 || (variant & kGnStreamLarge))) V = 0;
-  if (V == 9) {
-    if (variant & kGnBigBatch) hipLaunchKernelGGL((k_gn_relu_bwd_big<9, 9, 0, 9>), grid, dim3(kGnBigT), 0, st, A, dy, mean, rstd, dx);
-    else hipLaunchKernelGGL((k_gn_relu_bwd_big<9, 9, 0, 3>), grid, dim3(kGnBigT), 0, st, A, dy, mean, rstd, dx);
-    return launch_status();
-  }
-  if (V == 18) {   // batches of 3 float4 per operand (120 B of scratch per lane) or of 9 (156 B, a third of the round trips)
-    if (variant & kGnBigBatch) hipLaunchKernelGGL((k_gn_relu_bwd_big<18, 0, 9, 9>), grid, dim3(kGnBigT), 0, st, A, dy, mean, rstd, dx);
-    else hipLaunchKernelGGL((k_gn_relu_bwd_big<18, 0, 9, 3>), grid, dim3(kGnBigT), 0, st, A, dy, mean, rstd, dx);
-    return launch_status();
-  }
-  if (V == 0) {
-    hipLaunchKernelGGL(k_gn_relu_bwd_stream, grid, dim3(kGnStreamT), 0, st, A, dy, mean, rstd, dx);
-    return launch_status();
-  }
-  const bool nt = (variant & kGnNT) != 0, lc = (variant & kGnLC) != 0 && A.Cg <= kGnLdsCh;
-  if (T == 256 && V == 1) DP_GN_BWD_FLAGS(1, 256);
-  else if (T == 256 && V == 2) DP_GN_BWD_FLAGS(2, 256);
-  else if (T == 256) DP_GN_BWD_FLAGS(4, 256);
-  else if (T == 512) DP_GN_BWD_FLAGS(4, 512);
-  else if (V == 4) DP_GN_BWD_FLAGS(4, 1024);
-  else if (V == 7) DP_GN_BWD_FLAGS(7, 1024);
-  else DP_REQUIRE(false);
-  return launch_status();
-}
-
-// Variant = G (float4 groups per thread: 1, 2 or 4) + 8 * NT (non-temporal stores) + 16 (channel-split kernel)
-// + 32 (one sample per workgroup) / 64 (four).  dp_apply_fwd uses kApplyFwdDefaultVariant; tools/kbench.cpp sweeps
-// the others (profiles/r02i_kbench_apply.txt, 64 x 32 x 224^2): one sample per workgroup — 100 352 short-lived
-// workgroups of 3 stores per lane, the 38.5 MB of source images re-read from L2 — reaches 6.42 TB/s (80 % of the
-// 8 TB/s spec, above this GPU's plain-copy rate) where the round-1 form (a workgroup streams all 32 samples of its
-// tile) reaches 5.4; four samples per workgroup 5.8; the channel-split kernel 4.9-5.2.
-constexpr int kApplyFwdDefaultVariant = 1 + 8 + 32;
-
-int launch_apply_fwd(int variant, const float *adv_x, const int32_t *table, int R,
-                     const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H,
-                     int W, const dp_norm_t *norm, float *out, dp_stream_t stream,
-                     hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
-  const int G = variant & 7;
-  const bool nt = (variant & 8) != 0;
-  const int P4 = (H * W) >> 2;
-  if (variant & 16) {  // channel-split kernel: G in {4, 7} float4 groups of one channel per thread
-    DP_REQUIRE((G == 4 || G == 7) && B <= 65535 / 3);
-    const int tiles = cdiv(P4, kBlock * G);
-    int nchunk = cdiv(2048, tiles * B * 3);
-    if (nchunk < 1) nchunk = 1;
-    if (nchunk > S) nchunk = S;
-    const int s_per_block = cdiv(S, nchunk);
-    nchunk = cdiv(S, s_per_block);
-    DP_REQUIRE(nchunk <= 65535);
-    const dim3 grid(tiles, nchunk, B * 3), block(kBlock);
-    const NormDev nd = make_norm(norm);
-    hipStream_t st = as_stream(stream);
-#define DP_LAUNCH_FWD_CH(G_, NT_)                                                                       \
-  hipExtLaunchKernelGGL((k_apply_fwd_ch<G_, NT_>), grid, block, 0, st, ev_start, ev_stop, 0, adv_x, table, \
-                        R, idx, idx2, idx_bstride, S, H, W, s_per_block, nd, out)
-    if (G == 4 && nt) DP_LAUNCH_FWD_CH(4, true);
-    else if (G == 4) DP_LAUNCH_FWD_CH(4, false);
-    else if (nt) DP_LAUNCH_FWD_CH(7, true);
-    else DP_LAUNCH_FWD_CH(7, false);
-#undef DP_LAUNCH_FWD_CH
-    return launch_status();
-  }
-  DP_REQUIRE(G == 1 || G == 2 || G == 4);
-  const int tiles = cdiv(P4, kBlock * G);
-  // >= ~2048 workgroups (8 per CU) so the store stream covers all 8 XCDs evenly
-  int nchunk = cdiv(2048, tiles * B);
-  if (variant & 32) nchunk = S;            // kbench sweep: one sample per workgroup (short-lived workgroups)
-  if (variant & 64) nchunk = cdiv(S, 4);   // kbench sweep: 4 samples per workgroup
-  if (nchunk < 1) nchunk = 1;
-  if (nchunk > S) nchunk = S;
-  const int s_per_block = cdiv(S, nchunk);
-  nchunk = cdiv(S, s_per_block);
-  DP_REQUIRE(nchunk <= 65535);
-  // launch order: the 3-D grid (tile fastest: the launch writes the output as ONE ascending stream; default) or, with
-  // DP_DEBUG_APPLY_ORDER = 1, a unit's chunks adjacent on one XCD.  Measured at 64 x 32 x 224^2 (round 4,
-  // profiles/r04a_kbench_apply_order.txt + the bench's PMC pass): the XCD walk cuts the HBM traffic from 1.156 x to
-  // 1.039 x the algorithmic bytes (each source tile fetched once) and is 19 % SLOWER (0.238 vs 0.200 ms): the workgroups
-  // of an XCD then write 4 KiB pieces 602 KB apart, and the write stream's locality matters more than 190 MB of reads.
-  const long units = (long)tiles * B;
-  const long linear = ((units + 7) / 8) * 8 * nchunk;
-  const bool xcd_walk = g_apply_order == 1 && nchunk > 1 && linear <= 0x7fffffffL;
-  const dim3 grid = xcd_walk ? dim3((unsigned)linear, 1, 1) : dim3(tiles, nchunk, B), block(kBlock);
-  const int xcd_units = xcd_walk ? (int)units : 0;
-  const NormDev nd = make_norm(norm);
-  hipStream_t st = as_stream(stream);
-  // hipExtLaunchKernelGGL stamps the events with the kernel's own begin / end (what rocprofv3 reports),
-  // not with the position of a marker packet in the queue
-#define DP_LAUNCH_FWD(G_, NT_)                                                                    \
-  hipExtLaunchKernelGGL((k_apply_fwd<G_, NT_>), grid, block, 0, st, ev_start, ev_stop, 0, adv_x,   \
-                        table, R, idx, idx2, idx_bstride, S, H, W, s_per_block, nd, out, xcd_units)
-  if (G == 1 && nt) DP_LAUNCH_FWD(1, true);
-  else if (G == 1) DP_LAUNCH_FWD(1, false);
-  else if (G == 2 && nt) DP_LAUNCH_FWD(2, true);
-  else if (G == 2) DP_LAUNCH_FWD(2, false);
-  else if (nt) DP_LAUNCH_FWD(4, true);
-  else DP_LAUNCH_FWD(4, false);
-#undef DP_LAUNCH_FWD
-  return launch_status();
-}
-
-
-#endif             // ---------------------------------------------------------------- part 1 pauses (shared conv helpers follow)
-// ----------------------------------------------------------------------------
-// a-8 (round 4): the backbone's 3 x 3 / stride 1 / pad 1 convolutions on the matrix cores.
-// MIOpen runs them as fp32 Winograd on the VALUs (64 -> 64 @56^2, N = 512: 1.09 ms = 108 TFLOP/s effective); this is
-// the direct implicit GEMM on v_mfma_f32_32x32x2_f32 (exact f32, an fmaf chain over K — no Winograd rounding):
-//     D[oc][pixel] += sum_k  A[oc][k] * B[k][pixel],     k = (input channel, kh, kw),  K = 9 C
-//   A (weights)  lane l holds A[i = l & 31][k = l >> 5];   B (pixels)  lane l holds B[k = l >> 5][j = l & 31];
-//   D            lane l, register v:  oc = (v & 3) + 8 (v >> 2) + 4 (l >> 5),  pixel = l & 31
-// so a store instruction writes 2 output-channel rows x 32 consecutive pixels (128 B runs).
-// Workgroup = 448 consecutive pixels of the batch (n, h, w in row-major order: 8 rows of a 56 x 56 plane, 16 rows of
-// 28 x 28, 2.3 planes of 14 x 14, 9.1 planes of 7 x 7 — a tile may span images) x 64 output channels (grid.y = O / 64);
-// wave w owns channel fragment w & 1 and the 7 pixel fragments (w >> 1) + 2 q: 7 accumulators of 16 VGPRs.
-// K walks in chunks of 8 input channels.  The chunk's input rows go to LDS as a stack of rows with a zero row between
-// images and above / below the tile ("virtual row" n (S + 1) + h: the zero row is the bottom padding of image n AND the top
-// padding of image n + 1), zero columns left and right (pitch >= S + 2, column 0 at X0 so that global vectors land on
-// aligned LDS vectors: float4 for S = 56 / 28, float2 for 14, scalars for 7), so every tap of every pixel is
-// lane base + compile-time immediate; the chunk's pre-packed weights wt[oc group][chunk][t = (channel pair, kh, kw)][half][oc]
-// (frozen: packed once by the host) follow.  Both are double-buffered: the loads of chunk i + 1 are in flight during the
-// 252 MFMAs of chunk i and are stored to the other buffer half-way through them, one barrier per chunk.  A k-step pairs
-// channels (2 cp, 2 cp + 1) of the same tap: the lane's half selects the channel.
-// LDS <= 2 x 40.3 KB -> 2 workgroups per CU = 2 waves per SIMD.
-typedef float f16v __attribute__((ext_vector_type(16)));
-
-// relu(x * a + b) on four values, the multiply and the add as PACKED fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 with
-// op_sel broadcasting a / b out of the coefficient pair): the same two roundings per value as dp_gn_relu_fwd's scalar
-// expression, 8 instead of 12 VALU instructions in the wave's in-order stream between two MFMA groups (hipcc splits a
-// float2 multiply into scalar ones on gfx950, hence the asm; the 4 v_cndmask this kernel used to spend per item on
-// pixel-less lanes were worth 4 - 5 % of the plain kernel: profiles/r05r_*).
-__device__ __forceinline__ void gn_apply4(f4 &v, f2 ab) {
-#ifdef HIPEMU_HOST
-  v.x = fmaxf(v.x * ab.x + ab.y, 0.f);
-  v.y = fmaxf(v.y * ab.x + ab.y, 0.f);
-  v.z = fmaxf(v.z * ab.x + ab.y, 0.f);
-  v.w = fmaxf(v.w * ab.x + ab.y, 0.f);
-#else
-  f2 lo = f2{v.x, v.y}, hi = f2{v.z, v.w};
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(lo) : "v"(lo), "v"(ab));
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(hi) : "v"(hi), "v"(ab));
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(lo) : "v"(lo), "v"(ab));
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(hi) : "v"(hi), "v"(ab));
-  // (fmaxf on an asm result would first canonicalise it — a second v_max_f32 per value; v_max_f32 itself is fmaxf)
-  asm("v_max_f32 %0, 0, %1" : "=v"(v.x) : "v"(lo.x));
-  asm("v_max_f32 %0, 0, %1" : "=v"(v.y) : "v"(lo.y));
-  asm("v_max_f32 %0, 0, %1" : "=v"(v.z) : "v"(hi.x));
-  asm("v_max_f32 %0, 0, %1" : "=v"(v.w) : "v"(hi.y));
-#endif
-}
-
-
-constexpr int kCvO = 64;                               // output channels per workgroup
-constexpr int kCvPix = 448, kCvFrags = kCvPix / 32;    // pixels per workgroup (14 fragments)
-constexpr int kCvCh = 8;                               // input channels per K-chunk
-constexpr int kCvSteps = kCvCh / 2 * 9;                // 36 MFMA k-steps per chunk
-constexpr int kCvWtFloats = kCvSteps * 2 * kCvO;       // 4608 floats per (oc group, chunk)
-constexpr int kCvWtF4 = kCvWtFloats / 4, kCvWtIt = (kCvWtF4 + kBlock - 1) / kBlock;
-
-template <int S>
-struct CvGeom {
-  static constexpr int VW = (S % 4 == 0) ? 4 : (S % 2 == 0) ? 2 : 1;      // floats per staging load
-  static constexpr int X0 = VW;                                            // LDS column of image column 0
-  static constexpr int PITCH = ((S + X0 + 1 + VW - 1) / VW) * VW;         // 64 / 36 / 18 / 9
-  // rows of a tile (448 / S: tiles start at row starts since 448 % S == 0) + one zero row per image boundary it can cross
-  // + the rows above and below: 8 + 0 + 2 (56 % 8 == 0: never crosses) / 16 + 1 + 2 / 32 + 3 + 2 / 64 + 10 + 2
-  static constexpr int ROWS = S == 56 ? 10 : S == 28 ? 19 : S == 14 ? 37 : 76;
-  static constexpr int CHS = ROWS * PITCH;                                 // floats per channel
-  static constexpr int IN = kCvCh * CHS;                                   // floats per chunk
-  static constexpr int BUF = IN + kCvWtFloats;
-  static constexpr int VPR = S / VW;                                       // staging vectors per row
-  static constexpr int NV = kCvCh * ROWS * VPR, IT = (NV + kBlock - 1) / kBlock;
-};
-
-template <int VW> struct CvVec;
-template <> struct CvVec<4> { typedef f4 T; };
-template <> struct CvVec<2> { typedef float T __attribute__((ext_vector_type(2))); };
-template <> struct CvVec<1> { typedef float T; };
-
-#if DP_HAS(2)      // ---------------------------------------------------------------- part 2 begins
-// FOLD (round 5): x is the RAW input of a GroupNorm + ReLU; max(x * a + b, 0) with the (N, C, 2) coefficients `ab` that
-// dp_gn_stats wrote is applied between the global load and the LDS store (dp_gn_relu_fwd's own expression: bit-identical
-// to normalising first).  Halo rows / the rows between images stay exactly zero (their coefficients are (0, 0)): the
-// convolution pads the NORMALISED activation.
-template <int S, bool FOLD>
-__global__ __launch_bounds__(kBlock, 2) void k_conv3x3_mfma(const float *__restrict__ x, const float *__restrict__ wt,
-                                                            float *__restrict__ y, int N, int C, int O,
-                                                            const float *__restrict__ ab) {
-  typedef CvGeom<S> G;
-  typedef typename CvVec<G::VW>::T vec_t;
-  __shared__ __attribute__((aligned(16))) float lds[2 * G::BUF];
-  constexpr int HW = S * S;
-  const int NCH = C / kCvCh;
-  const int total = N * HW;                                  // < 2^31 (checked by the launcher)
-  const int g0 = blockIdx.x * kCvPix;                        // first pixel of the tile (batch-linear)
-  const int n0 = g0 / HW, h0 = (g0 - n0 * HW) / S;
-  const int vr0 = n0 * (S + 1) + h0 - 1;                     // virtual row of LDS row 0 (the zero / halo row above the tile)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, l32 = lane & 31;
-  const int ocf = wave & 1, pf0 = wave >> 1;
-  const float *wtg = wt + (size_t)blockIdx.y * NCH * kCvWtFloats;
-
-  // zero columns (never written again) of both buffers: [X0 - 1] and [X0 + S] of every row
-  for (int i = tid; i < 2 * kCvCh * G::ROWS * 2; i += kBlock) {
-    const int buf = i / (kCvCh * G::ROWS * 2), r = i - buf * (kCvCh * G::ROWS * 2);
-    lds[buf * G::BUF + (r >> 1) * G::PITCH + ((r & 1) ? (G::X0 + S) : (G::X0 - 1))] = 0.f;
-  }
-
-  vec_t pin[G::IT];
-  f2 pab[FOLD ? G::IT : 1];
-  f4 pwt[kCvWtIt];
-  // (For the planes below 56 x 56, fetch / stash re-derive their element decode from a LAUNDERED copy of the thread index
-  // every time: left alone, hipcc keeps the per-iteration global and LDS offsets — 2 x IT values, loop-invariant — alive
-  // across the whole MFMA loop, which with IT = 9 / 17 (14 x 14 / 7 x 7) spilled 136 / 572 B per lane; the decode is ~10
-  // integer ops per element.  Measured, N = 512: 28 x 28 0.964 -> 0.907 ms, 14 x 14 1.085 -> 1.039, 7 x 7 1.506 -> 1.161 —
-  // but 56 x 56 0.880 -> 0.927 (the 256-VGPR schedule with its 8 B of scratch is the faster one there), so not for S = 56.)
-  auto fetch = [&](int chunk) {          // global -> registers
-    int tl = tid;
-    if (S != 56 || FOLD) DP_LAUNDER(tl);
-#pragma unroll
-    for (int it = 0; it < G::IT; ++it) {
-      const int i = tl + it * kBlock;
-      const int ch = i / (G::ROWS * G::VPR), rem = i - ch * (G::ROWS * G::VPR);
-      const int row = rem / G::VPR, q = rem - row * G::VPR;
-      const int vr = vr0 + row;
-      const int n = vr / (S + 1), h = vr - n * (S + 1);
-      vec_t v = {};
-      const bool ok = i < G::NV && vr >= 0 && h < S && n < N;
-      if (ok)
-        v = *reinterpret_cast<const vec_t *>(x + (((size_t)n * C + chunk * kCvCh + ch) * S + h) * S + q * G::VW);
-      pin[it] = v;
-      if (FOLD) {       // unconditional load (entry 0 is always there), zero coefficients where there is no pixel
-        f2 c = *reinterpret_cast<const f2 *>(ab + 2 * (ok ? (size_t)n * C + chunk * kCvCh + ch : (size_t)0));
-        if (!ok) c = f2{0.f, 0.f};
-        pab[it] = c;
-      }
-    }
-    const f4 *wsrc = reinterpret_cast<const f4 *>(wtg + (size_t)chunk * kCvWtFloats);
-#pragma unroll
-    for (int it = 0; it < kCvWtIt; ++it) {
-      const int i = tid + it * kBlock;
-      pwt[it] = wsrc[i < kCvWtF4 ? i : 0];
-    }
-  };
-  auto stash = [&](int buf) {            // registers -> LDS
-    float *dst = lds + buf * G::BUF;
-    int tl = tid;
-    if (S != 56 || FOLD) DP_LAUNDER(tl);
-#pragma unroll
-    for (int it = 0; it < G::IT; ++it) {
-      const int i = tl + it * kBlock;
-      const int ch = i / (G::ROWS * G::VPR), rem = i - ch * (G::ROWS * G::VPR);
-      const int row = rem / G::VPR, q = rem - row * G::VPR;
-      vec_t v = pin[it];
-      if (FOLD) {
-        if constexpr (G::VW == 4) {
-          gn_apply4(*reinterpret_cast<f4 *>(&v), pab[it]);
-        } else {
-          const float a = pab[it].x, b = pab[it].y;
-          float *e = reinterpret_cast<float *>(&v);
-#pragma unroll
-          for (int k = 0; k < G::VW; ++k) e[k] = fmaxf(e[k] * a + b, 0.f);
-        }
-      }
-      if (i < G::NV) *reinterpret_cast<vec_t *>(dst + ch * G::CHS + row * G::PITCH + G::X0 + q * G::VW) = v;
-    }
-#pragma unroll
-    for (int it = 0; it < kCvWtIt; ++it) {
-      const int i = tid + it * kBlock;
-      if (i < kCvWtF4) *reinterpret_cast<f4 *>(dst + G::IN + 4 * i) = pwt[it];
-    }
-  };
-
-  // lane bases: A = weights [t][half][oc]; B = the lane's pixel of each of its 7 fragments, channel parity = half.
-  // A pixel past the end of the batch (last tile only) reads the tile's first pixel and is never stored.
-  const int abase = G::IN + half * kCvO + ocf * 32 + l32;
-  int boff[7];
-#pragma unroll
-  for (int q = 0; q < 7; ++q) {
-    int g = g0 + (pf0 + 2 * q) * 32 + l32;
-    if (g >= total) g = g0;
-    const int n = g / HW, p = g - n * HW;
-    const int h = p / S, w = p - h * S;
-    boff[q] = half * G::CHS + (n * (S + 1) + h - vr0 - 1) * G::PITCH + w + (G::X0 - 1);
-  }
-  f16v acc[7];
-#pragma unroll
-  for (int q = 0; q < 7; ++q)
-#pragma unroll
-    for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
-
-  fetch(0);
-  stash(0);
-  __syncthreads();
-  for (int chunk = 0; chunk < NCH; ++chunk) {
-    if (chunk + 1 < NCH) fetch(chunk + 1);
-    const float *cur = lds + (chunk & 1) * G::BUF;
-    // Explicit software pipeline over the k-steps: the 8 operands of step t + 1 are requested BEFORE the 7 MFMAs of step t
-    // (448 cycles of matrix pipe: more than an LDS round trip), and scheduling barriers keep the compiler from undoing it.
-    // Left to itself hipcc hoisted whole groups of steps' reads until all 256 VGPRs were taken and then had to issue
-    // read -> s_waitcnt lgkmcnt(0) -> MFMA back to back at the group seams: SQ counters 78 % MFMA-busy, 19 % of wave
-    // cycles parked, 125.7 TFLOP/s; with the pipeline 134.5 (profiles/r04c_ / r04e_sq_counters_conv3x3.txt).
-    auto operands = [&](int t, float &a, float (&bv)[7]) {
-      const int cp = t / 9, kh = (t % 9) / 3, kw = t % 3;
-      const int koff = cp * 2 * G::CHS + kh * G::PITCH + kw;
-      a = cur[abase + t * 2 * kCvO];
-#pragma unroll
-      for (int q = 0; q < 7; ++q) bv[q] = cur[boff[q] + koff];
-    };
-    float a0, b0[7], a1, b1[7];
-    operands(0, a0, b0);
-#pragma unroll
-    for (int t = 0; t < kCvSteps; t += 2) {
-      operands(t + 1, a1, b1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[q], acc[q], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      // the next chunk goes to the OTHER buffer (nobody reads it during this chunk) half-way through: its global loads
-      // have landed by then, the LDS stores hide behind the remaining MFMAs, and every wave reaches the barrier with
-      // nothing left to do but its last MFMAs
-      if (t == kCvSteps / 2 && chunk + 1 < NCH) stash((chunk + 1) & 1);
-      if (t + 2 < kCvSteps) operands(t + 2, a0, b0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[q], acc[q], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();
-  }
-
-  const int oc0 = blockIdx.y * kCvO + ocf * 32 + 4 * half;
-#pragma unroll
-  for (int q = 0; q < 7; ++q) {
-    const int g = g0 + (pf0 + 2 * q) * 32 + l32;
-    if (g >= total) continue;
-    const int n = g / HW, p = g - n * HW;
-    float *yq = y + ((size_t)n * O + oc0) * HW + p;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) yq[(size_t)((v & 3) + 8 * (v >> 2)) * HW] = acc[q][v];
-  }
-}
-
-// ----------------------------------------------------------------------------
-// a-8 (round 5): the backbone's three 3 x 3 / STRIDE 2 / pad 1 convolutions (the second convolution of
-// the first bottleneck of stages 2-4: 128 @56^2 -> 28^2, 256 @28^2 -> 14^2, 512 @14^2 -> 7^2) on the matrix cores, NCHW in
-// place.  MIOpen runs them as NHWC implicit GEMMs wrapped in batched_transpose_* / SubTensorOpWithScalar1d kernels, and the
-// first one as a stride-2 Winograd at 51 TFLOP/s (profiles/r05b_kernel_stats_timed_fold.txt: 2.32 ms per 512 samples).
-// Same MFMA walk, tile (448 batch-linear OUTPUT pixels x 64 output channels) and packed weights as k_conv3x3_mfma.  What
-// differs is the LDS image of the input: an output pixel (h, w) reads input rows 2h - 1 .. 2h + 1 and columns 2w - 1 ..
-// 2w + 1, so the input is stored DE-INTERLEAVED — per channel and per output row h four sub-rows (row parity pr, column
-// parity pc): sub-row 2 pr + pc holds x[2h + pr][2w + pc] at column X0 + w.  Tap (kh, kw) of pixel (h, w) is then the lane's
-// base + (2 (kh - 1) + (kw != 1)) PITCH - (kw == 0): a compile-time immediate, consecutive lanes on consecutive words.
-// Padding: only above and to the left (2 S - 1 is the last input row / column): the zero row between images of the
-// "virtual row" stack n (S + 1) + h is the top padding of image n + 1, column X0 - 1 of every sub-row is zero.
-// The input of a tile is 4 x its output pixels, so a K-chunk is ONE channel pair (2 channels x <= 3000 floats + 1152
-// weights: 2 buffers x <= 32 KB, 2 workgroups per CU) = the 9 taps = 63 MFMAs per wave and barrier; staging as in
-// k_conv1x1_mfma: chunk c + 1 goes from registers to the other buffer one item per MFMA group during chunk c while chunk
-// c + 2 is requested into the registers this frees (a whole chunk in flight), branch-free, barrier on LDS traffic only and
-// placed before the last group's MFMAs.  FOLD as in k_conv3x3_mfma (the GroupNorm + ReLU in front of conv2 never written).
-constexpr int kCv2Ch = 2;                               // input channels per K-chunk (one channel pair)
-constexpr int kCv2Steps = 9;                            // MFMA k-steps per chunk: the 9 taps
-constexpr int kCv2WtFloats = kCv2Steps * 2 * kCvO;      // 1152 floats of packed weights per (oc group, chunk)
-constexpr int kCv2WtF4 = kCv2WtFloats / 4;              // 288 float4
-constexpr int kCv2WtIt = (kCv2WtF4 + kBlock - 1) / kBlock;   // 2 per thread; the LDS region is padded to 2 x kBlock float4
-
-// NQ (round 6): pixel fragments per wave — the tile is 64 NQ OUTPUT pixels (7: the round-5 tile of 448, which starts at a row
-// start on all three sides; 2 / 1: 128 / 64 pixels for the batches at which 448-pixel tiles leave the chip idle — 512 -> 512
-// @14 -> 7 at 64 samples: 7 tiles x 8 channel groups = 56 workgroups, 0.58 ms for 14.8 GFLOP).  Same k-walk, same bits.
-template <int SO, int NQ = 7>
-struct Cv2Geom {
-  static constexpr int PIX = 64 * NQ;                                      // output pixels per workgroup
-  static constexpr int SI = 2 * SO;                                        // input side
-  static constexpr int VW = (SI % 4 == 0) ? 4 : 2;                         // floats per staging load
-  static constexpr int X0 = 2;                                             // LDS column of output column 0 (even: aligned f2)
-  static constexpr int PITCH = ((X0 + SO + 1) / 2) * 2;                    // 30 / 16 / 10
-  // output rows of a tile (448 / SO) + one zero row per image boundary it can cross + the row above
-  // (a tile that may start anywhere: the row above + the rows PIX pixels can touch + one zero row per image boundary crossed)
-  static constexpr int ROWS = NQ == 7 ? (SO == 28 ? 18 : SO == 14 ? 36 : 75)
-                                      : 1 + (SO + PIX - 2) / SO + 1 + (SO * SO + PIX - 2) / (SO * SO);
-  static constexpr int CHS = ROWS * 4 * PITCH;                             // floats per channel
-  static constexpr int IN = kCv2Ch * CHS;
-  static constexpr int BUF = IN + kCv2WtIt * kBlock * 4;
-  static constexpr int VPR = SI / VW;                                      // staging vectors per input row
-  static constexpr int NV = kCv2Ch * ROWS * 2 * VPR, IT = (NV + kBlock - 1) / kBlock;     // 4 / 4 / 9 items per thread
-  static_assert(IT <= 16 && IN % 4 == 0, "item schedule / float4 alignment of the weights");
-};
-
-template <int SO, bool FOLD, int NQ = 7>
-__global__ __launch_bounds__(kBlock, (NQ >= 6 ? 2 : 4)) void k_conv3x3s2_mfma(const float *__restrict__ x, const float *__restrict__ wt,
-                                                              float *__restrict__ y, int N, int C, int O,
-                                                              const float *__restrict__ ab) {
-  typedef Cv2Geom<SO, NQ> G;
-  typedef typename CvVec<G::VW>::T vec_t;
-  __shared__ __attribute__((aligned(16))) float lds[2 * G::BUF];
-  constexpr int HW = SO * SO, SI = G::SI;
-  const int NCH = C / kCv2Ch;
-  const int total = N * HW;                                  // < 2^31 (checked by the launcher)
-  const int g0 = blockIdx.x * G::PIX;                        // first OUTPUT pixel of the tile (batch-linear)
-  const int n0 = g0 / HW, h0 = (g0 - n0 * HW) / SO;
-  const int vr0 = n0 * (SO + 1) + h0 - 1;                    // virtual row of LDS row 0 (the row above the tile)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, l32 = lane & 31;
-  const int ocf = wave & 1, pf0 = wave >> 1;
-  const float *wtg = wt + (size_t)blockIdx.y * NCH * kCv2WtFloats;
-
-  // zero column X0 - 1 of every sub-row of both buffers (never written again; item stores of lanes without an item write
-  // zeros over word 0 / 1 of sub-rows 0 / 1, which keeps it zero)
-  for (int i = tid; i < 2 * kCv2Ch * G::ROWS * 4; i += kBlock) {
-    const int buf = i / (kCv2Ch * G::ROWS * 4), r = i - buf * (kCv2Ch * G::ROWS * 4);
-    lds[buf * G::BUF + r * G::PITCH + G::X0 - 1] = 0.f;
-  }
-
-  // staging items: (channel, LDS row, input-row parity, vector of the input row) -> element offset at chunk 0 (-1: zeros),
-  // LDS offset of the even-column half (the odd-column half is one PITCH further), coefficient index
-  int gofs[G::IT], lofs[G::IT], aofs[FOLD ? G::IT : 1];
-#pragma unroll
-  for (int it = 0; it < G::IT; ++it) {
-    const int i = tid + it * kBlock;
-    const int ch = i / (G::ROWS * 2 * G::VPR), rem = i - ch * (G::ROWS * 2 * G::VPR);
-    const int row = rem / (2 * G::VPR), rem2 = rem - row * (2 * G::VPR);
-    const int pr = rem2 / G::VPR, q = rem2 - pr * G::VPR;
-    const int vr = vr0 + row;
-    const int n = vr / (SO + 1), h = vr - n * (SO + 1);
-    const bool ok = i < G::NV && vr >= 0 && h < SO && n < N;
-    gofs[it] = ok ? ((n * C + ch) * SI + 2 * h + pr) * SI + q * G::VW : -1;
-    lofs[it] = i < G::NV ? ch * G::CHS + (row * 4 + pr * 2) * G::PITCH + G::X0 + q * (G::VW / 2) : 0;
-    if (FOLD) aofs[it] = ok ? n * C + ch : 0;
-  }
-
-  vec_t pin[G::IT];
-  f2 pab[FOLD ? G::IT : 1];
-  f4 pwt[kCv2WtIt];
-  auto fetch_item = [&](int chunk, int it) {     // global -> registers; every load is issued unconditionally
-    pin[it] = *reinterpret_cast<const vec_t *>(x + (size_t)chunk * (kCv2Ch * SI * SI) + (gofs[it] < 0 ? 0 : gofs[it]));
-    if (FOLD) pab[it] = *reinterpret_cast<const f2 *>(ab + 2 * ((size_t)chunk * kCv2Ch + aofs[it]));
-  };
-  auto fetch_w = [&](int chunk, int k) {
-    const int i = tid + k * kBlock;
-    pwt[k] = *reinterpret_cast<const f4 *>(wtg + (size_t)chunk * kCv2WtFloats + 4 * (i < kCv2WtF4 ? i : 0));
-  };
-  auto stash_item = [&](int buf, int it) {       // registers -> LDS, de-interleaving the columns
-    vec_t v = pin[it];
-    float *e = reinterpret_cast<float *>(&v);
-    if (FOLD) {                                  // dp_gn_relu_fwd's own expression: x * a + b (not fused), max 0
-      if constexpr (G::VW == 4) {
-        gn_apply4(*reinterpret_cast<f4 *>(&v), pab[it]);
-      } else {
-        const float a = pab[it].x, b = pab[it].y;
-#pragma unroll
-        for (int k = 0; k < G::VW; ++k) e[k] = fmaxf(e[k] * a + b, 0.f);
-      }
-    }
-    if (gofs[it] < 0) {
-#pragma unroll
-      for (int k = 0; k < G::VW; ++k) e[k] = 0.f;
-    }
-    float *dst = lds + buf * G::BUF + lofs[it];
-    if (G::VW == 4) {
-      *reinterpret_cast<f2 *>(dst) = f2{e[0], e[2]};
-      *reinterpret_cast<f2 *>(dst + G::PITCH) = f2{e[1], e[3]};
-    } else {
-      dst[0] = e[0];
-      dst[G::PITCH] = e[1];
-    }
-  };
-  auto stash_w = [&](int buf, int k) {
-    *reinterpret_cast<f4 *>(lds + buf * G::BUF + G::IN + 4 * (tid + k * kBlock)) = pwt[k];
-  };
-  auto fetch = [&](int chunk) {        // items, then weights: the order the loop requests them in (below)
-#pragma unroll
-    for (int it = 0; it < G::IT; ++it) fetch_item(chunk, it);
-#pragma unroll
-    for (int k = 0; k < kCv2WtIt; ++k) fetch_w(chunk, k);
-  };
-  auto stash = [&](int buf) {
-#pragma unroll
-    for (int it = 0; it < G::IT; ++it) stash_item(buf, it);
-#pragma unroll
-    for (int k = 0; k < kCv2WtIt; ++k) stash_w(buf, k);
-  };
-
-  // lane bases: A = weights [tap][half][oc]; B = sub-row 0, column X0 + w of the lane's pixel, channel parity = half.
-  // A pixel past the end of the batch (last tile only) reads the tile's first pixel and is never stored.
-  const int abase = G::IN + half * kCvO + ocf * 32 + l32;
-  int boff[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    int g = g0 + (pf0 + 2 * q) * 32 + l32;
-    if (g >= total) g = g0;
-    const int n = g / HW, p = g - n * HW;
-    const int h = p / SO, w = p - h * SO;
-    boff[q] = half * G::CHS + (n * (SO + 1) + h - vr0) * 4 * G::PITCH + G::X0 + w;
-  }
-  f16v acc[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q)
-#pragma unroll
-    for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
-
-  auto operands = [&](const float *cur, int t, float &a, float (&bv)[NQ]) {
-    const int kh = t / 3, kw = t - 3 * kh;
-    const int koff = (2 * (kh - 1) + (kw != 1 ? 1 : 0)) * G::PITCH - (kw == 0 ? 1 : 0);
-    a = cur[abase + t * 2 * kCvO];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) bv[q] = cur[boff[q] + koff];
-  };
-
-  fetch(0);
-  stash(0);
-  fetch(NCH > 1 ? 1 : 0);
-  DP_BARRIER_LDS();
-  float an, bn[NQ];                    // step 0 of the next chunk, requested behind the chunk's barrier
-  operands(lds, 0, an, bn);
-  const int last = NCH - 1;
-  for (int chunk = 0; chunk < NCH; ++chunk) {
-    const float *cur = lds + (chunk & 1) * G::BUF;
-    const int nb = (chunk + 1) & 1;
-    const int c2 = chunk + 2 < NCH ? chunk + 2 : last;    // past the end of K the staging repeats the last chunk (branch-free)
-    float a[2], b[2][NQ];
-    a[0] = an;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) b[0][q] = bn[q];
-#pragma unroll
-    for (int t = 0; t < kCv2Steps; ++t) {
-      if (t + 1 < kCv2Steps) {
-        operands(cur, t + 1, a[(t + 1) & 1], b[(t + 1) & 1]);
-      } else {
-        // every read of this buffer has been issued and every wave's stores of the next chunk are done
-        DP_BARRIER_LDS();
-        operands(lds + nb * G::BUF, 0, an, bn);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t & 1], b[t & 1][q], acc[q], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < kCv2Steps) {
-        // after MFMA group t (0..7): slot i of the chunk's IT + WIT staging items (the activation items, then the weights) goes
-        // after group i * 8 / (IT + WIT) — to LDS for chunk c + 1, requested again for chunk c + 2.  Items before weights, in
-        // the prologue and here alike: the wait-count pass merges both request queues at the loop head, and with another
-        // order in the loop (weights after the first items) every chunk's first store waited for nearly the whole queue
-        // (s_waitcnt vmcnt(1 - 2) instead of the 5 - 9 of a FIFO of in-flight items).
-        constexpr int NI = G::IT + kCv2WtIt;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          if (i * (kCv2Steps - 1) / NI != t) continue;
-          if (i < G::IT) {
-            stash_item(nb, i);
-            fetch_item(c2, i);
-          } else {
-            stash_w(nb, i - G::IT);
-            fetch_w(c2, i - G::IT);
-          }
-        }
-      }
-    }
-  }
-
-  const int oc0 = blockIdx.y * kCvO + ocf * 32 + 4 * half;
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int g = g0 + (pf0 + 2 * q) * 32 + l32;
-    if (g >= total) continue;
-    const int n = g / HW, p = g - n * HW;
-    float *yq = y + ((size_t)n * O + oc0) * HW + p;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) yq[(size_t)((v & 3) + 8 * (v >> 2)) * HW] = acc[q][v];
-  }
-}
-
-#endif             // ---------------------------------------------------------------- part 2 pauses
-// ----------------------------------------------------------------------------
-// a-8 (round 5, VERDICT r4 items 1 + 2): the backbone's 1 x 1 / stride 1 convolutions on the matrix cores — 33 of
-// ResNetV2-50's 53 convolutions, 17.4 of the 33.5 TFLOP of a configs[1] step, until now Tensile / MIOpen NHWC kernels.
-//     forward         y[n]  (O x HW) = W   (O x C) x[n]  (C x HW)
-//     input gradient  dx[n] (C x HW) = W^T (C x O) dy[n] (O x HW)        — the same kernel on the transposed weights
-// on the NCHW tensors as they lie (a 1 x 1 convolution has no halo: the B operand of channel k is a run of pixels).  Same
-// MFMA walk as k_conv3x3_mfma (v_mfma_f32_32x32x2_f32, weights = A operand, D lanes along pixels, exact f32 fmaf chain
-// over the channels in ascending order: deterministic by construction), one tap instead of nine:
-//   workgroup = 448 batch-linear pixels x 64 output channels, wave w = channel fragment w & 1 x pixel fragments (w >> 1) + 2 q;
-//   K walks in chunks of 16 input channels = 8 k-steps = 56 MFMAs per wave and barrier; the chunk's activations
-//   [channel][448 pixels] and pre-packed weights [channel][64 oc] are double-buffered in LDS (2 x 32 KB: 2 workgroups
-//   per CU), fetched to registers during the previous chunk's MFMAs and stored half-way through them.
-// Staging is a flat copy in both layouts: item j = (float4 j of the chunk's LDS image) <-> one 16-byte global load.
-//   row mode  (HW % 4 == 0): tile = 448 consecutive batch-linear pixels (may span images: a float4 never does),
-//             item j = (channel j / 112, pixel quad j % 112);
-//   flat mode (FHW = 49: the 7 x 7 planes, whose rows are not 16-byte multiples): tile = 9 whole images (441 pixels, 7 idle
-//             lanes), LDS image [image][16 channels x 49] = what lies contiguously in memory (16 x 49 x 4 B = 196 float4 per
-//             image and chunk), the k-step stride is 49 floats.
-// FOLD: the input is the RAW tensor a GroupNorm + ReLU would have normalised; the affine + ReLU is
-// applied between the global load and the LDS store, with the per-(sample, channel) coefficients a = rstd * gamma,
-// b = beta - mean * a that dp_gn_relu_fwd's statistics pass wrote ((N, C, 2) table `ab`), by the same expression
-// (x * a + b, un-fused, then max 0): the normalised activation is never written to or re-read from HBM.
-// RES: y = conv + res (res may be y itself): the bottleneck's residual add / the accumulation of the downsample branch's
-// gradient in the epilogue.
-// Workgroup ids are decoded XCD-aware (block b runs on XCD b % 8): the O / 64 channel groups of one pixel tile are
-// consecutive workgroups of ONE XCD, so a tile of x is fetched from HBM once and re-read from that XCD's L2.
-constexpr int kC1O = 64;                               // output channels per workgroup
-constexpr int kC1Pix = 448;                            // pixels per workgroup of the full-size tile (14 fragments)
-constexpr int kC1Ch = 16;                              // input channels per K-chunk
-constexpr int kC1Steps = kC1Ch / 2;                    // 8 MFMA k-steps per chunk
-constexpr int kC1Wt = kC1Ch * kC1O;                    // 1024 floats of packed weights per (oc group, chunk): one f4 per thread
-static_assert(kC1Wt == 4 * kBlock, "one weight float4 per thread");
-// Round 6: the pixel tile is a template parameter.  A wave holds NQ fragments of 32 pixels (NQ
-// accumulators), the workgroup 64 NQ pixels: 448 (NQ = 7, the round-5 kernel), 256, 128 or 64.  The k-walk of an output
-// element — channels ascending, one fmaf chain — does not depend on the tile, so every tile size gives THE SAME BITS;
-// the launcher picks the largest tile that still fills the chip (64 samples on a 14 x 14 plane are 28 tiles of 448 pixels:
-// 112 workgroups for 512 slots at O = 256).  A chunk's staging is NQ float4 items per thread (one per pixel fragment).
-template <int NQ>
-struct C1Geom {
-  static constexpr int PIX = 64 * NQ;                  // pixels per workgroup
-  static constexpr int IN = kC1Ch * PIX;               // floats of activations per chunk
-  static constexpr int BUF = IN + kC1Wt;               // one LDS buffer (NQ = 7: 32 KB)
-  static constexpr int IT = NQ;                        // staging float4 per thread and chunk
-  static constexpr int MW = NQ >= 6 ? 2 : NQ >= 3 ? 3 : 4;     // workgroups per CU the register budget is set for
-  static_assert(IT * 4 * kBlock == IN, "NQ activation float4 per thread");
-};
-
-// Which pixel tile runs a problem (round 6).  Every tile gives the same bits, so this is a pure scheduling decision.
-// Model, fitted to the measured sweeps (profiles/r06b_kbench_conv1x1_tiles_n{32..512}.txt, r06c_kbench_conv3x3_tiles_*):
-// a workgroup's time is proportional to its NQ MFMAs per k-step (whatever its idle lanes), the 256 CUs share the
-// workgroups evenly, so   cost(NQ) = ceil(workgroups(NQ) / 256) * NQ * penalty(NQ)   — e.g. 1024 -> 256 @14x14, N = 64:
-// 112 workgroups of 448 pixels cost 1 * 7, 392 of 128 pixels 2 * 2 (measured 55 vs 96 TFLOP/s); 2048 -> 512 @7x7,
-// N = 512: 456 x 7 -> 14 against 824 x 4 -> 16 (116 vs 103).  The penalties are what is left at large grids: the 448-pixel
-// tile is 4 - 8 % ahead for plain / residual launches (fewer barriers and weight re-reads per flop).  Launches with the
-// GroupNorm fold in the staging run FASTER stand-alone with 64-pixel tiles (8 workgroups per CU hide the apply's VALU + the
-// extra request: 1024 -> 512 120 vs 108, 512 -> 128 116 vs 105 TFLOP/s at N = 512; the one-stream step 375.9 -> 373.1 ms) —
-// but 8 workgroups of 4 waves are ALL 32 wave slots of a CU, so nothing of the step's other stream runs beside them: the
-// two-stream step (the product's) went 357.8 -> 363.5 ms (profiles/r06f_bench_*.json, 3 interleaved runs each).  At large
-// grids the fold therefore keeps the 448-pixel tile as well; ties go to the larger tile.
-// Once the largest tile already fills the chip (>= 512 workgroups) the small tiles pay for their occupancy as well: 8 (64-pixel)
-// or 5 - 6 (128-pixel) workgroups per CU take most of the CU's 32 wave slots, and the step's other stream stops running beside
-// them — 1024 -> 256 @14x14 at N = 512 wins 8 % on 64-pixel tiles alone (3.5 rounds of 448-pixel tiles become 24.5 of 64) and
-// the two-stream step loses 0.7 % (325.3 / 327.7 vs 329.2 / 328.1 ms, profiles/r06m_bench_s2*.json).
-static int pick_tile(const int *cand, const float *pen, int n, const long *wgs) {
-  int best = cand[0];
-  float best_cost = 0.f;
-  const bool filled = wgs[0] >= 512;
-  for (int i = 0; i < n; ++i) {
-    float cost = (float)((wgs[i] + 255) / 256) * (float)cand[i] * pen[i];
-    if (filled && cand[i] <= 2) cost *= cand[i] == 1 ? 1.12f : 1.05f;
-    if (i == 0 || cost < best_cost * 0.999f) best = cand[i], best_cost = cost;
-  }
-  return best;
-}
-#if DP_HAS(3)      // ---------------------------------------------------------------- part 3 begins
-struct C1Args {
-  const float *x, *wt;
-  const float *ab;      // FOLD: (N, C, 2) coefficients of the fused GroupNorm + ReLU on the input
-  const float *res;     // RES: added to the result (layout of y; may alias y)
-  float *y;
-  int N, C, O, HW;
-  int tiles;            // pixel tiles
-  int og;               // O / 64
-  int spt;              // flat mode: images per tile (448 / HW)
-  int map;              // workgroup id -> (tile, oc group): 0 XCD-aware (product), 1 oc group fastest, 2 tile fastest (A/B knob)
-  int nt;               // non-temporal result stores (A/B knob)
-};
-
-template <int NQ, int FHW, bool FOLD, bool RES, bool SPREAD>
-__global__ __launch_bounds__(kBlock, C1Geom<NQ>::MW) void k_conv1x1_mfma(C1Args A) {
-  typedef C1Geom<NQ> G;
-  constexpr int kC1Pix = G::PIX, kC1In = G::IN, kC1Buf = G::BUF, kC1It = G::IT;      // (shadow the full-size tile's constant)
-  __shared__ __attribute__((aligned(16))) float lds[2 * kC1Buf];
-  constexpr bool FLAT = FHW != 0;
-  constexpr int FD = FLAT ? FHW : 1;                         // divisor of the flat-mode decodes (dead code in row mode)
-  int tile, og;
-  {
-    const int wg = blockIdx.x;
-    if (A.map == 0) {
-      const int xcd = wg & 7, slot = wg >> 3, tl = slot / A.og;
-      og = slot - tl * A.og;
-      tile = tl * 8 + xcd;
-    } else if (A.map == 1) {
-      tile = wg / A.og;
-      og = wg - tile * A.og;
-    } else {
-      const int tp = (A.tiles + 7) / 8 * 8;
-      og = wg / tp;
-      tile = wg - og * tp;
-    }
-  }
-  if (tile >= A.tiles) return;                               // grid padded to a multiple of 8 tiles
-  const int HW = FLAT ? FHW : A.HW;
-  const int CHS = FLAT ? FHW : kC1Pix;                       // LDS stride between channels
-  const int NCH = A.C / kC1Ch;
-  const int total = A.N * HW;                                // < 2^31 (checked by the launcher)
-  const int g0 = FLAT ? 0 : tile * kC1Pix;                   // row mode: first pixel of the tile (batch-linear)
-  const int n0 = FLAT ? tile * A.spt : 0;                    // flat mode: first image of the tile
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, l32 = lane & 31;
-  const int ocf = wave & 1, pf0 = wave >> 1;
-  const float *wtg = A.wt + (size_t)og * NCH * kC1Wt + 4 * tid;
-
-  // staging items: element offset of the item's float4 at chunk 0 (-1: nothing to load) and, FOLD, of its coefficients
-  int xoff[kC1It], aoff[kC1It];
-#pragma unroll
-  for (int it = 0; it < kC1It; ++it) {
-    const int j = tid + it * kBlock;
-    if (!FLAT) {
-      const int ch = j / (kC1Pix / 4), quad = j - ch * (kC1Pix / 4);
-      const int g = g0 + 4 * quad;
-      const bool ok = g < total;
-      const int n = ok ? g / HW : 0, p = ok ? g - n * HW : 0;
-      xoff[it] = ok ? (n * A.C + ch) * HW + p : -1;
-      aoff[it] = n * A.C + ch;
-    } else {
-      const int s = j / (kC1Ch / 4 * FD), f = j - s * (kC1Ch / 4 * FD);
-      const bool ok = s < A.spt && n0 + s < A.N;
-      xoff[it] = ok ? (n0 + s) * A.C * FHW + 4 * f : -1;
-      aoff[it] = 0;
-    }
-  }
-
-  f4 pin[kC1It], pwt;
-  f2 pab[FOLD ? kC1It : 1];
-  auto fetch_item = [&](int chunk, int it) {     // global -> registers; every load is issued unconditionally
-    pin[it] = *reinterpret_cast<const f4 *>(A.x + (size_t)chunk * kC1Ch * HW + (xoff[it] < 0 ? 0 : xoff[it]));
-    if (FOLD) pab[it] = *reinterpret_cast<const f2 *>(A.ab + (size_t)chunk * kC1Ch * 2 + 2 * (size_t)aoff[it]);
-  };
-  auto fetch_w = [&](int chunk) { pwt = *reinterpret_cast<const f4 *>(wtg + (size_t)chunk * kC1Wt); };
-  // The prologue requests a chunk in the SAME order as the loop does (item 0, weights, items 1 .. 6): the wait-count pass
-  // merges the prologue's and the loop's queue of outstanding loads at the loop head, and with the weights last in one and
-  // third in the other it put s_waitcnt vmcnt(0) in front of the weights' LDS store in the FOLD instantiations — every chunk
-  // drained the loads issued one MFMA group earlier (the whole 12 - 25 % the fold cost on the deep shapes, r05b).
-  auto fetch = [&](int chunk) {
-    fetch_item(chunk, 0);
-    fetch_w(chunk);
-    __builtin_amdgcn_sched_barrier(0);        // ... and the scheduler must not re-order the requests either
-#pragma unroll
-    for (int it = 1; it < kC1It; ++it) {
-      fetch_item(chunk, it);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  auto stash_item = [&](int buf, int it) {   // registers -> LDS (flat copy), with the fused GroupNorm-apply + ReLU
-    f4 v = pin[it];
-    if (FOLD) gn_apply4(v, pab[it]);     // dp_gn_relu_fwd's own expression: x * a + b (not fused), max 0
-    // (an item without a pixel — past the end of the batch / of the tile's images — holds whatever lies at offset 0: it feeds
-    // only the D columns of lanes that never store, a 1 x 1 convolution has no neighbours)
-    *reinterpret_cast<f4 *>(lds + buf * kC1Buf + 4 * (tid + it * kBlock)) = v;
-  };
-  auto stash_w = [&](int buf) { *reinterpret_cast<f4 *>(lds + buf * kC1Buf + kC1In + 4 * tid) = pwt; };
-  auto stash = [&](int buf) {
-#pragma unroll
-    for (int it = 0; it < kC1It; ++it) stash_item(buf, it);
-    stash_w(buf);
-  };
-
-  // lane bases: A = weights [channel][oc]; B = the lane's pixel of each of its 7 fragments, channel parity = half.
-  // Lanes without a pixel (past the end of the batch / of the tile's images) read a valid LDS word and never store.
-  const int abase = kC1In + half * kC1O + ocf * 32 + l32;
-  int boff[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int gl = (pf0 + 2 * q) * 32 + l32;
-    if (!FLAT) {
-      boff[q] = half * kC1Pix + gl;
-    } else {
-      int s = gl / FD, p = gl - s * FD;
-      if (s >= A.spt) s = 0, p = 0;
-      boff[q] = s * (kC1Ch * FHW) + half * FHW + p;
-    }
-  }
-  f16v acc[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q)
-#pragma unroll
-    for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
-
-  // Pipeline of one chunk (8 k-steps = 8 groups of 7 MFMAs per wave):
-  //   * step t + 1's 8 operands are requested before step t's MFMAs (the k-step pipeline of k_conv3x3_mfma);
-  //   * chunk c + 1 goes from the staging registers to the other LDS buffer DURING chunk c, and chunk c + 2 is requested from
-  //     global memory into the registers this frees — SPREAD: one float4 item (its GroupNorm-apply, its LDS store, the load
-  //     that refills its register) after each of the MFMA groups 0..6, so that neither the LDS stores nor the issue of the
-  //     global loads (8 - 15 wave-wide requests per chunk through the CU's one texture-address unit, from all 8 waves at
-  //     once) ever sit between two MFMA groups in one lump; else all of it after group 4 / after the barrier.  Every load has
-  //     a whole chunk (~3 us) to land: requested half a chunk ahead, 512 -> 128 @28^2 ran 13 % and 1024 -> 512 @14^2 15 %
-  //     slower (profiles/r05b_kbench_conv1x1_variants.txt: variants 16 / 24).  The loads stay in flight across the chunk's
-  //     barrier, which therefore waits for LDS traffic only (DP_BARRIER_LDS);
-  //   * the chunk's barrier sits BEFORE the last group's MFMAs: every read of this buffer has been issued by then (the last
-  //     step's operands are in a1 / b1, and the barrier waits for them) and every wave's store of the next chunk is done, so
-  //     the next chunk's first operands are requested right after it and land during those 7 MFMAs.
-  // What the loop structure alone reaches on this GPU (tools/kbench mfma_probe: the same walk without global memory):
-  // 146 - 152 TFLOP/s = 93 - 97 % of the fp32 matrix peak (profiles/r05c_kbench_mfma_probe.txt).
-  fetch(0);
-  stash(0);
-  fetch(NCH > 1 ? 1 : 0);
-  DP_BARRIER_LDS();
-  auto operands = [&](const float *cur, int t, float &a, float (&bv)[NQ]) {
-    a = cur[abase + t * 2 * kC1O];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) bv[q] = cur[boff[q] + t * 2 * CHS];
-  };
-  float a0, b0[NQ], a1, b1[NQ];
-  operands(lds, 0, a0, b0);
-  // The loop body is BRANCH-FREE: past the end of K the staging simply repeats the last chunk (loads of valid memory, stores
-  // into the LDS buffer nobody reads any more).  With `if (chunk + 2 < NCH)` around the loads hipcc's wait-count pass merged
-  // the paths conservatively and put s_waitcnt vmcnt(0) in front of every item's store — i.e. it waited for the load issued
-  // one MFMA group earlier; straight-line code gets the exact vmcnt(6 / 7) of a FIFO of in-flight items.
-  const int last = NCH - 1;
-  for (int chunk = 0; chunk < NCH; ++chunk) {
-    const float *cur = lds + (chunk & 1) * kC1Buf;
-    const int nb = (chunk + 1) & 1;
-    const int c2 = chunk + 2 < NCH ? chunk + 2 : last;
-    auto piece = [&](int g) {            // after MFMA group g (0..6): item g of chunk c + 1 to LDS, item g of chunk c + 2 requested
-      if (g >= NQ) return;
-      stash_item(nb, g);
-      if (g == 0) stash_w(nb);
-      fetch_item(c2, g);
-      if (g == 0) fetch_w(c2);
-    };
-#pragma unroll
-    for (int t = 0; t < kC1Steps; t += 2) {
-      operands(cur, t + 1, a1, b1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[q], acc[q], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (SPREAD) {
-        piece(t);
-      } else if (t == kC1Steps / 2) {
-        stash(nb);
-      }
-      if (t + 2 < kC1Steps) {
-        operands(cur, t + 2, a0, b0);
-      } else {
-        DP_BARRIER_LDS();
-        operands(lds + nb * kC1Buf, 0, a0, b0);
-        if (!SPREAD) fetch(c2);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[q], acc[q], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (SPREAD && t + 2 < kC1Steps) piece(t + 1);
-    }
-  }
-
-  const int oc0 = og * kC1O + ocf * 32 + 4 * half;
-  // fragment q -> element offset of its first output row (row (v & 3) + 8 (v >> 2) is that many planes further), -1: no pixel
-  auto out_offset = [&](int q) -> long {
-    const int gl = (pf0 + 2 * q) * 32 + l32;
-    int n, p;
-    bool ok;
-    if (!FLAT) {
-      const int g = g0 + gl;
-      ok = g < total;
-      n = g / HW, p = g - n * HW;
-    } else {
-      const int s = gl / FD;
-      p = gl - s * FD, n = n0 + s;
-      ok = s < A.spt && n < A.N;
-    }
-    return ok ? (long)(((size_t)n * A.O + oc0) * HW + p) : -1L;
-  };
-  // RES: the residual of fragment q + 1 is requested BEFORE fragment q is stored (res may be y itself: a store to y could
-  // alias the next loads for all the compiler knows, so left alone every fragment waited for its own 16 loads — seven
-  // memory round trips in a row per workgroup; the fragments' elements are disjoint, so the order is free)
-  float r[2][16];
-  long o_next = out_offset(0);
-  if (RES) {
-#pragma unroll
-    for (int v = 0; v < 16; ++v) r[0][v] = A.res[(o_next < 0 ? 0 : o_next) + (size_t)((v & 3) + 8 * (v >> 2)) * HW];
-  }
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const long o = o_next;
-    if (q + 1 < NQ) {
-      o_next = out_offset(q + 1);
-      if (RES) {
-#pragma unroll
-        for (int v = 0; v < 16; ++v)
-          r[(q + 1) & 1][v] = A.res[(o_next < 0 ? 0 : o_next) + (size_t)((v & 3) + 8 * (v >> 2)) * HW];
-      }
-    }
-    if (RES) {
-#pragma unroll
-      for (int v = 0; v < 16; ++v) acc[q][v] += r[q & 1][v];
-    }
-    if (o < 0) continue;
-    float *yq = A.y + o;
-    if (A.nt) {
-#pragma unroll
-      for (int v = 0; v < 16; ++v) __builtin_nontemporal_store(acc[q][v], yq + (size_t)((v & 3) + 8 * (v >> 2)) * HW);
-    } else {
-#pragma unroll
-      for (int v = 0; v < 16; ++v) yq[(size_t)((v & 3) + 8 * (v >> 2)) * HW] = acc[q][v];
-    }
-  }
-}
-
-// DP_DEBUG_CONV1X1_VARIANT bits 4-6 force a tile for A/B runs (1: 448, 2: 256, 3: 128, 4: 64).
-static long conv1x1_tiles(long N, int HW, bool flat, int nq) {
-  const int pix = 64 * nq;
-  return flat ? (N + pix / HW - 1) / (pix / HW) : (N * HW + pix - 1) / pix;
-}
-static int conv1x1_tile_nq(long N, int C, int HW, int og, bool flat, bool fold, bool res) {
-  const int force = (g_conv1x1_variant >> 4) & 7;
-  if (force) return force == 1 ? 7 : force == 2 ? 4 : force == 3 ? 2 : 1;
-  static const int cand[4] = {7, 4, 2, 1};
-  static const float pen_plain[4] = {1.00f, 1.07f, 1.08f, 1.08f}, pen_fold[4] = {1.00f, 1.03f, 1.04f, 1.03f},
-                     pen_res[4] = {1.00f, 1.07f, 1.07f, 1.04f}, pen_flat[4] = {1.00f, 1.00f, 1.04f, 1.06f};
-  long wgs[4];
-  for (int i = 0; i < 4; ++i) wgs[i] = conv1x1_tiles(N, HW, flat, cand[i]) * og;
-  if (!flat && C <= 64 && og == 1 && wgs[0] < 1024) return 1;   // 64 -> 64 on a small grid: four chunks of K against a whole epilogue
-  if (!flat && fold && (g_conv1x1_variant & 0x180)) {             // A/B knob (bits 7-8): the fold prefers the 256- / 128- / 64-pixel tile
-    static const float pen_a[4] = {1.00f, 0.94f, 1.04f, 1.03f}, pen_b[4] = {1.00f, 1.03f, 0.94f, 1.03f}, pen_c[4] = {1.05f, 1.02f, 1.03f, 1.00f};
-    const int k = (g_conv1x1_variant >> 7) & 3;
-    return pick_tile(cand, k == 1 ? pen_a : k == 2 ? pen_b : pen_c, 4, wgs);
-  }
-  return pick_tile(cand, flat ? pen_flat : fold ? pen_fold : res ? pen_res : pen_plain, 4, wgs);
-}
-
-int launch_conv1x1(C1Args A, bool flat, hipStream_t st) {
-  const int nq = conv1x1_tile_nq(A.N, A.C, A.HW, A.og, flat, A.ab != nullptr, A.res != nullptr);
-  A.spt = flat ? 64 * nq / A.HW : 0;
-  const long tiles = conv1x1_tiles(A.N, A.HW, flat, nq);
-  if ((tiles + 7) / 8 * 8 * A.og >= (1L << 31)) return hipErrorInvalidValue;
-  A.tiles = (int)tiles;
-  const dim3 grid((unsigned)(cdiv(A.tiles, 8) * 8 * A.og)), block(kBlock);
-  const bool fold = A.ab != nullptr, res = A.res != nullptr;
-  A.map = g_conv1x1_variant & 3;
-  A.nt = (g_conv1x1_variant >> 2) & 1;
-  const bool spread = !(g_conv1x1_variant & 8);
-#define DP_LAUNCH_C1Q(NQ_, FHW_, FOLD_, RES_) hipLaunchKernelGGL((k_conv1x1_mfma<NQ_, FHW_, FOLD_, RES_, true>), grid, block, 0, st, A)
-#define DP_LAUNCH_C1(FHW_, FOLD_, RES_)                                                                      \
-  do {                                                                                                       \
-    if (nq == 7) {                                                                                           \
-      if (spread) DP_LAUNCH_C1Q(7, FHW_, FOLD_, RES_);                                                       \
-      else hipLaunchKernelGGL((k_conv1x1_mfma<7, FHW_, FOLD_, RES_, false>), grid, block, 0, st, A);         \
-    } else if (nq == 4) DP_LAUNCH_C1Q(4, FHW_, FOLD_, RES_);                                                 \
-    else if (nq == 2) DP_LAUNCH_C1Q(2, FHW_, FOLD_, RES_);                                                   \
-    else DP_LAUNCH_C1Q(1, FHW_, FOLD_, RES_);                                                                \
-  } while (0)
-  if (flat) {
-    if (res) DP_LAUNCH_C1(49, false, true);
-    else DP_LAUNCH_C1(49, false, false);
-  } else if (fold) {
-    if (res) DP_LAUNCH_C1(0, true, true);
-    else DP_LAUNCH_C1(0, true, false);
-  } else {
-    if (res) DP_LAUNCH_C1(0, false, true);
-    else DP_LAUNCH_C1(0, false, false);
-  }
-#undef DP_LAUNCH_C1
-#undef DP_LAUNCH_C1Q
-  return launch_status();
-}
-
-#endif             // ---------------------------------------------------------------- part 3 pauses
-#if DP_HAS(2)      // ---------------------------------------------------------------- part 2 resumes
-// ----------------------------------------------------------------------------
-// a-8 (round 5): the 3 x 3 MFMA walk over a FLAT LDS image with MASKED taps.
-// k_conv3x3_mfma lays the input rows out in LDS with explicit zero rows / columns, which ties it to planes that tile 448
-// pixels (56 / 28 / 14 / 7) and costs the small planes their staging (float2 / scalar items, 9 - 17 per lane and chunk,
-// a dozen integer operations of decode each: 113 / 102 TFLOP/s at 14^2 / 7^2 against 134 at 56^2).  Here the LDS image of a
-// K-chunk is what lies in memory: per channel the tile's 448 batch-linear pixels plus HL pixels before and HR after
-// (row mode, any plane with H*W % 4 == 0: float4 items, one division per item, done once), or whole images
-// [image][channel][49] (the 7 x 7 planes, as k_conv1x1_mfma's flat mode).  A tap (dh, dw) of a pixel is then the word
-// dh S + dw further on — a compile-time immediate — and is WRONG exactly where the convolution pads: in row 0 / S - 1 for
-// dh = -1 / +1, in column 0 / S - 1 for dw = -1 / +1 (the flat neighbour is the previous / next row's pixel, or another
-// image's).  Those lanes take 0 instead (one v_cndmask per operand on per-fragment lane masks): the result is the zero-
-// padded convolution, bit for bit what k_conv3x3_mfma computes (same k-walk: channels ascending, taps row-major).
-// The same walk with other tap sets is the INPUT GRADIENT of the three stride-2 3 x 3 convolutions (until now MIOpen's
-// NHWC implicit GEMM between batched_transpose_* kernels): dx[2a + pr][2b + pc] depends on dy[a + dh][b + dw] with
-//   pr = 0: (dh, kh) = (0, 1);   pr = 1: (0, 2), (+1, 0);   the same for columns —
-// four parity classes with 1 / 2 / 2 / 4 taps over the dy plane (9 per 4 input pixels: the forward's flops), each a masked
-// flat walk with K = (dy channel, tap) whose result is scattered to its parity positions.  K-chunks hold 16 / T channels,
-// so every class runs 8 k-steps = 56 MFMAs per wave and barrier (k_conv1x1_mfma's rhythm) on 1024 packed weights.
-// Pipeline as k_conv3x3s2_mfma: a whole chunk in flight in registers, one staging item per MFMA group, branch-free, the
-// barrier on LDS traffic only and before the last group's MFMAs.  The masks are applied to step t's operands after step
-// t - 1's MFMAs have been issued (the loads have had a whole group to land), before step t + 1's operands are requested.
-struct TapsS1 {                  // stride 1: t = 3 kh + kw, (dh, dw) = (kh - 1, kw - 1), offsets counted from (h - 1, w - 1)
-  static constexpr int T = 9;
-  static constexpr int dh(int t) { return t / 3 - 1; }
-  static constexpr int dw(int t) { return t % 3 - 1; }
-};
-template <int PR, int PC>
-struct TapsS2 {                  // class (PR, PC) of the stride-2 input gradient: t = th (1 + PC) + tw, (dh, dw) = (th, tw)
-  static constexpr int T = (1 + PR) * (1 + PC);
-  static constexpr int dh(int t) { return t / (1 + PC); }
-  static constexpr int dw(int t) { return t % (1 + PC); }
-};
-
-// NQ_ (round 6, VERDICT r5 items 1 + 6): pixel fragments per wave — the workgroup's tile is 64 NQ pixels (7: the round-5
-// tile of 448; 4 / 2 / 1: 256 / 128 / 64 pixels, for batches whose planes give too few 448-pixel tiles to fill 512 slots).
-// The k-walk of an output element does not depend on it: every tile gives the same bits.
-template <int S_, int T_, int CH_, int BACK_, int FWD_, int NQ_ = 7>
-struct CfGeom {
-  static constexpr int S = S_, HW = S_ * S_, T = T_, CH = CH_, NQ = NQ_, PIX = 64 * NQ_;
-  static constexpr bool FLAT = (HW % 4) != 0;                              // 7 x 7: whole-image tiles
-  static constexpr int KS = CH / 2 * T;                                    // MFMA k-steps per chunk
-  static constexpr int BACK = BACK_;                                       // words a tap reaches back / forward from its pixel
-  static constexpr int HL = FLAT ? 0 : (BACK_ + 3) / 4 * 4, HR = FLAT ? 0 : (FWD_ + 3) / 4 * 4;
-  static constexpr int RL = HL + PIX + HR;                                 // row mode: floats per channel
-  static constexpr int SPT = FLAT ? PIX / HW : 1;                          // flat mode: images per tile
-  static constexpr int CHS = FLAT ? HW : RL;                               // LDS stride between channels
-  static constexpr int NV = FLAT ? SPT * CH * HW / 4 : CH * RL / 4;        // float4 items per chunk
-  static constexpr int IT = (NV + kBlock - 1) / kBlock;
-  static constexpr int PAD = FLAT ? (BACK_ + 3) / 4 * 4 : 0;               // in front of buffer 0 (flat mode: image 0 reaches back)
-  static constexpr int DUMMY = NV * 4;                                     // where the idle lanes of the last item store
-  static constexpr int WOFF = NV * 4 + 4;                                  // packed weights of the chunk
-  static constexpr int WT = KS * 2 * kCvO, WF4 = WT / 4, WIT = (WF4 + kBlock - 1) / kBlock;
-  static constexpr int WDUMMY = WOFF + WT;
-  static constexpr int BUF = WOFF + WT + 4;
-  static constexpr int LDS = PAD + 2 * BUF + (FLAT ? (FWD_ + 3) / 4 * 4 : 0);
-  static_assert(!FLAT || (CH * HW) % 4 == 0, "flat mode: an image's chunk is a whole number of float4");
-  static_assert(KS >= 2 && IT + WIT <= 2 * (KS - 1), "staging items fit the MFMA groups of a chunk");
-};
-
-struct CfArgs {
-  const float *x, *wt;
-  const float *ab;      // FOLD: (N, C, 2) coefficients of the fused GroupNorm + ReLU on the input
-  float *y;
-  int N, C, O;          // C channels of x (the K dimension), O channels of y
-  int tiles, og;        // pixel tiles, O / 64
-};
-
-// MODE 0: y (N, O, S, S) plain;  MODE 1: y (N, O, 2S, 2S), the tile's pixel (a, b) goes to (2a + PR, 2b + PC)
-template <class G, class TAPS, bool FOLD, int MODE, int PR, int PC>
-__device__ __forceinline__ void cf_body(float *lds, const CfArgs &A, const float *wtg, int tile, int og) {
-  constexpr int S = G::S, HW = G::HW, KS = G::KS, T = G::T, NQ = G::NQ;
-  static_assert(!(FOLD && G::FLAT), "the GroupNorm fold needs H*W % 4 == 0");
-  const int NCH = A.C / G::CH;
-  const int total = A.N * HW;                                  // < 2^31 (checked by the launcher)
-  const int g0 = G::FLAT ? 0 : tile * G::PIX;                  // row mode: first pixel of the tile (batch-linear)
-  const int n0 = G::FLAT ? tile * G::SPT : 0;                  // flat mode: first image of the tile
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, l32 = lane & 31;
-  const int ocf = wave & 1, pf0 = wave >> 1;
-  wtg += (size_t)og * NCH * G::WT;
-
-  // staging items: element offset of the item's float4 at chunk 0 (-1: zeros) and, FOLD, of its coefficients
-  int xoff[G::IT], aoff[FOLD ? G::IT : 1];
-#pragma unroll
-  for (int it = 0; it < G::IT; ++it) {
-    const int j = tid + it * kBlock;
-    if (!G::FLAT) {
-      const int ch = j / (G::RL / 4), quad = j - ch * (G::RL / 4);
-      const int g = g0 - G::HL + 4 * quad;
-      const bool ok = j < G::NV && g >= 0 && g < total;
-      const int n = ok ? g / HW : 0, p = ok ? g - n * HW : 0;
-      xoff[it] = ok ? (n * A.C + ch) * HW + p : -1;
-      if (FOLD) aoff[it] = n * A.C + (ok ? ch : 0);
-    } else {
-      const int s = j / (G::CH * HW / 4), f = j - s * (G::CH * HW / 4);
-      const bool ok = j < G::NV && n0 + s < A.N;
-      xoff[it] = ok ? (n0 + s) * A.C * HW + 4 * f : -1;
-    }
-  }
-
-  f4 pin[G::IT], pwt[G::WIT];
-  f2 pab[FOLD ? G::IT : 1];
-  auto fetch_item = [&](int chunk, int it) {     // global -> registers; every load is issued unconditionally
-    pin[it] = *reinterpret_cast<const f4 *>(A.x + (size_t)chunk * (G::CH * HW) + (xoff[it] < 0 ? 0 : xoff[it]));
-    if (FOLD) pab[it] = *reinterpret_cast<const f2 *>(A.ab + (size_t)chunk * (G::CH * 2) + 2 * (size_t)aoff[it]);
-  };
-  auto fetch_w = [&](int chunk, int k) {
-    const int i = tid + k * kBlock;
-    pwt[k] = *reinterpret_cast<const f4 *>(wtg + (size_t)chunk * G::WT + 4 * (i < G::WF4 ? i : 0));
-  };
-  auto stash_item = [&](float *buf, int it) {    // registers -> LDS (flat copy), with the fused GroupNorm-apply + ReLU
-    f4 v = pin[it];
-    if (FOLD) {                                  // dp_gn_relu_fwd's own expression: x * a + b (not fused), max 0
-      const float a = pab[it].x, b = pab[it].y;    // (scalar here: with gn_apply4's register pairs <14, true> starts to spill)
-      v.x = fmaxf(v.x * a + b, 0.f);
-      v.y = fmaxf(v.y * a + b, 0.f);
-      v.z = fmaxf(v.z * a + b, 0.f);
-      v.w = fmaxf(v.w * a + b, 0.f);
-    }
-    if (xoff[it] < 0) v = f4{0.f, 0.f, 0.f, 0.f};
-    const int j = tid + it * kBlock;
-    *reinterpret_cast<f4 *>(buf + ((it + 1) * kBlock <= G::NV || j < G::NV ? 4 * j : G::DUMMY)) = v;
-  };
-  auto stash_w = [&](float *buf, int k) {
-    const int i = tid + k * kBlock;
-    *reinterpret_cast<f4 *>(buf + ((k + 1) * kBlock <= G::WF4 || i < G::WF4 ? G::WOFF + 4 * i : G::WDUMMY)) = pwt[k];
-  };
-  // slot i of a chunk's IT + WIT staging items goes after MFMA group i (KS - 1) / (IT + WIT)
-  constexpr int NI = G::IT + G::WIT;
-  auto piece = [&](float *buf, int c2, int t) {
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      if (i * (KS - 1) / NI != t) continue;
-      if (i < G::IT) {
-        stash_item(buf, i);
-        fetch_item(c2, i);
-      } else {
-        stash_w(buf, i - G::IT);
-        fetch_w(c2, i - G::IT);
-      }
-    }
-  };
-
-  // lane bases: A = weights [k-step][half][oc]; B = word `BACK` before the lane's pixel of each of its 7 fragments, channel
-  // parity = half.  Lanes without a pixel (past the end of the batch / of the tile's images) read valid LDS and never store.
-  // Masks: the lane's pixel is not in the first / last row / column of its plane.
-  const int abase = G::WOFF + half * kCvO + ocf * 32 + l32;
-  int boff[NQ];
-  bool mT[NQ], mB[NQ], mL[NQ], mR[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int gl = (pf0 + 2 * q) * 32 + l32;
-    int p;
-    if (!G::FLAT) {
-      boff[q] = half * G::CHS + G::HL + gl - G::BACK;
-      int g = g0 + gl;
-      if (g >= total) g = g0;
-      p = g % HW;
-    } else {
-      int s = gl / HW;
-      p = gl - s * HW;
-      if (s >= G::SPT) s = 0, p = 0;
-      boff[q] = s * (G::CH * HW) + half * HW + p - G::BACK;
-    }
-    const int a = p / S, b = p - a * S;
-    mT[q] = a > 0, mB[q] = a < S - 1, mL[q] = b > 0, mR[q] = b < S - 1;
-  }
-  f16v acc[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q)
-#pragma unroll
-    for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
-
-  auto operands = [&](const float *cur, int t, float &a, float (&bv)[NQ]) {
-    const int cp = t / T, tap = t - cp * T;
-    const int koff = cp * 2 * G::CHS + G::BACK + TAPS::dh(tap) * S + TAPS::dw(tap);
-    a = cur[abase + t * 2 * kCvO];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) bv[q] = cur[boff[q] + koff];
-  };
-  auto masked = [&](int t, float (&bv)[NQ]) {
-    const int tap = t % T;
-    const int dh = TAPS::dh(tap), dw = TAPS::dw(tap);
-    if (dh == 0 && dw == 0) return;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      bool m = true;
-      if (dh < 0) m = m && mT[q];
-      if (dh > 0) m = m && mB[q];
-      if (dw < 0) m = m && mL[q];
-      if (dw > 0) m = m && mR[q];
-      bv[q] = m ? bv[q] : 0.f;
-    }
-  };
-
-  float *buf0 = lds + G::PAD, *buf1 = buf0 + G::BUF;
-#pragma unroll
-  for (int it = 0; it < G::IT; ++it) fetch_item(0, it);
-#pragma unroll
-  for (int k = 0; k < G::WIT; ++k) fetch_w(0, k);
-#pragma unroll
-  for (int it = 0; it < G::IT; ++it) stash_item(buf0, it);
-#pragma unroll
-  for (int k = 0; k < G::WIT; ++k) stash_w(buf0, k);
-  const int c1 = NCH > 1 ? 1 : 0;
-#pragma unroll
-  for (int it = 0; it < G::IT; ++it) fetch_item(c1, it);
-#pragma unroll
-  for (int k = 0; k < G::WIT; ++k) fetch_w(c1, k);
-  DP_BARRIER_LDS();
-  float an, bn[NQ];                    // step 0 of the next chunk, requested behind the chunk's barrier
-  operands(buf0, 0, an, bn);
-  const int last = NCH - 1;
-  for (int chunk = 0; chunk < NCH; ++chunk) {
-    const float *cur = (chunk & 1) ? buf1 : buf0;
-    float *nxt = (chunk & 1) ? buf0 : buf1;
-    const int c2 = chunk + 2 < NCH ? chunk + 2 : last;    // past the end of K the staging repeats the last chunk (branch-free)
-    float a[2], b[2][NQ];
-    a[0] = an;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) b[0][q] = bn[q];
-#pragma unroll
-    for (int t = 0; t < KS; ++t) {
-      masked(t, b[t & 1]);
-      if (t + 1 < KS) {
-        operands(cur, t + 1, a[(t + 1) & 1], b[(t + 1) & 1]);
-      } else {
-        // every read of this buffer has been issued and every wave's stores of the next chunk are done
-        DP_BARRIER_LDS();
-        operands(nxt, 0, an, bn);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t & 1], b[t & 1][q], acc[q], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < KS) piece(nxt, c2, t);
-    }
-  }
-
-  const int oc0 = og * kCvO + ocf * 32 + 4 * half;
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int gl = (pf0 + 2 * q) * 32 + l32;
-    int n, p;
-    bool ok;
-    if (!G::FLAT) {
-      const int g = g0 + gl;
-      ok = g < total;
-      n = g / HW, p = g - n * HW;
-    } else {
-      const int s = gl / HW;
-      p = gl - s * HW, n = n0 + s;
-      ok = s < G::SPT && n < A.N;
-    }
-    if (!ok) continue;
-    if (MODE == 0) {
-      float *yq = A.y + ((size_t)n * A.O + oc0) * HW + p;
-#pragma unroll
-      for (int v = 0; v < 16; ++v) yq[(size_t)((v & 3) + 8 * (v >> 2)) * HW] = acc[q][v];
-    } else {
-      const int a = p / S, b = p - a * S;
-      float *yq = A.y + ((size_t)n * A.O + oc0) * (4 * HW) + (2 * a + PR) * (2 * S) + 2 * b + PC;
-#pragma unroll
-      for (int v = 0; v < 16; ++v) yq[(size_t)((v & 3) + 8 * (v >> 2)) * (4 * HW)] = acc[q][v];
-    }
-  }
-}
-
-// workgroup id -> (pixel tile, channel group): block b runs on XCD b % 8; the O / 64 channel groups of one pixel tile are
-// consecutive workgroups of ONE XCD (k_conv1x1_mfma's map), so a tile of x is fetched from HBM once
-__device__ __forceinline__ void cf_decode(int slot, int xcd, int ogs, int &tile, int &og) {
-  const int tl = slot / ogs;
-  og = slot - tl * ogs;
-  tile = tl * 8 + xcd;
-}
-
-template <int S, bool FOLD, int NQ = 7>
-__global__ __launch_bounds__(kBlock, (NQ >= 6 ? 2 : NQ >= 3 ? 3 : NQ == 2 ? 4 : 6)) void k_conv3x3_flat(CfArgs A) {
-  // the small tiles walk K in chunks of 4 channels (half a packed 8-channel chunk: [chunk][channel pair][tap][half][oc] is
-  // contiguous per channel pair, same k order, same bits): 9 KB of weights per buffer instead of 18, so that 6 - 7
-  // workgroups fit a CU's LDS instead of 3
-  typedef CfGeom<S, 9, (NQ >= 4 ? kCvCh : kCvCh / 2), S + 1, S + 1, NQ> G;
-  __shared__ __attribute__((aligned(16))) float lds[G::LDS];
-  int tile, og;
-  cf_decode(blockIdx.x >> 3, blockIdx.x & 7, A.og, tile, og);
-  if (tile >= A.tiles) return;                               // grid padded to a multiple of 8 tiles
-  cf_body<G, TapsS1, FOLD, 0, 0, 0>(lds, A, A.wt, tile, og);
-}
-
-// The four parity classes in ONE launch, heaviest first within every group of four consecutive slots of an XCD: the
-// classes of a (tile, channel group) run at the same time on the same XCD, so the 4-byte stores of classes (pr, 0) and
-// (pr, 1) — the even and odd words of the same rows — meet in that XCD's L2 before they go to memory.
-// A.wt = the four packed classes back to back in the order 11, 01, 10, 00 (pack_conv3x3s2_dgrad_weights).
-template <int S>
-struct CfS2 {
-  typedef CfGeom<S, 4, 4, 0, S + 1> G11;
-  typedef CfGeom<S, 2, 8, 0, 1> G01;
-  typedef CfGeom<S, 2, 8, 0, S> G10;
-  typedef CfGeom<S, 1, 16, 0, 0> G00;
-  static constexpr int m2(int a, int b) { return a > b ? a : b; }
-  static constexpr int LDS = m2(m2(G11::LDS, G01::LDS), m2(G10::LDS, G00::LDS));
-};
-
-template <int S>
-__global__ __launch_bounds__(kBlock, 2) void k_conv3x3s2_dgrad(CfArgs A) {
-  typedef CfS2<S> K;
-  __shared__ __attribute__((aligned(16))) float lds[K::LDS];
-  const int slot = blockIdx.x >> 3, cls = slot & 3;
-  int tile, og;
-  cf_decode(slot >> 2, blockIdx.x & 7, A.og, tile, og);
-  if (tile >= A.tiles) return;
-  const size_t per_tap = (size_t)A.C * A.O;                  // floats of one tap's (dy channel, dx channel) matrix
-  if (cls == 0) cf_body<typename K::G11, TapsS2<1, 1>, false, 1, 1, 1>(lds, A, A.wt, tile, og);
-  else if (cls == 1) cf_body<typename K::G01, TapsS2<0, 1>, false, 1, 0, 1>(lds, A, A.wt + 4 * per_tap, tile, og);
-  else if (cls == 2) cf_body<typename K::G10, TapsS2<1, 0>, false, 1, 1, 0>(lds, A, A.wt + 6 * per_tap, tile, og);
-  else cf_body<typename K::G00, TapsS2<0, 0>, false, 1, 0, 0>(lds, A, A.wt + 8 * per_tap, tile, og);
-}
-
-// The same input gradient with the two COLUMN classes of a row parity in one workgroup (round 5, second form).  The four-class
-// launch above stores 4-byte words 8 bytes apart (74 TFLOP/s at N = 512, no better than MIOpen: profiles/r05j_*): class
-// (pr, 0) and (pr, 1) interleave in memory.  Here a workgroup owns 256 dy pixels x 64 dx channels x BOTH pc: a wave holds
-// 4 pixel fragments x 2 classes (8 accumulators), per (channel pair, th) it reads the operands dy[a + th][b] and
-// dy[a + th][b + 1] once and issues 12 MFMAs — class 0: w[kh][1] x dy[b]; class 1: w[kh][2] x dy[b], then w[kh][0] x dy[b + 1]
-// (each class's own k-walk order: bit-identical to the four-class kernel) — and the epilogue stores (class 0, class 1) of
-// a pixel as ONE 8-byte word: 32 lanes = 256 contiguous bytes.  K-chunks of 8 dy channels = 4 (pr = 0) / 8 (pr = 1) steps of
-// 12 MFMAs; weights packed [og][chunk][cp][th][j][half][c'], j = (kw 1, kw 2, kw 0).
-constexpr int kC2Pix = 256;                            // dy pixels per workgroup (8 fragments)
-
-template <int S_, int PR_>
-struct Cf2Geom {
-  static constexpr int S = S_, HW = S_ * S_, PR = PR_, CH = 8;
-  static constexpr bool FLAT = (HW % 4) != 0;
-  static constexpr int NS = CH / 2 * (1 + PR);                             // steps (channel pair, th) per chunk
-  static constexpr int HR = FLAT ? 0 : (PR * S + 1 + 3) / 4 * 4;
-  static constexpr int RL = kC2Pix + HR;
-  static constexpr int SPT = FLAT ? kC2Pix / HW : 1;
-  static constexpr int CHS = FLAT ? HW : RL;
-  static constexpr int NV = FLAT ? SPT * CH * HW / 4 : CH * RL / 4;
-  static constexpr int IT = (NV + kBlock - 1) / kBlock;
-  static constexpr int DUMMY = NV * 4, WOFF = NV * 4 + 4;
-  static constexpr int WT = NS * 3 * 2 * kCvO, WF4 = WT / 4, WIT = (WF4 + kBlock - 1) / kBlock;
-  static constexpr int WDUMMY = WOFF + WT;
-  static constexpr int BUF = WOFF + WT + 4;
-  static constexpr int LDS = 2 * BUF + (FLAT ? (PR * S + 1 + 3) / 4 * 4 : 0);
-  static_assert(IT + WIT <= 2 * (NS - 1), "staging items fit the MFMA groups of a chunk");
-};
-
-template <class G>
-__device__ __forceinline__ void cf2_body(float *lds, const CfArgs &A, const float *wtg, int tile, int og) {
-  constexpr int S = G::S, HW = G::HW, NS = G::NS, PR = G::PR;
-  const int NCH = A.C / G::CH;
-  const int total = A.N * HW;
-  const int g0 = G::FLAT ? 0 : tile * kC2Pix;
-  const int n0 = G::FLAT ? tile * G::SPT : 0;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, l32 = lane & 31;
-  const int ocf = wave & 1, pf0 = wave >> 1;
-  wtg += (size_t)og * NCH * G::WT;
-
-  int xoff[G::IT];
-#pragma unroll
-  for (int it = 0; it < G::IT; ++it) {
-    const int j = tid + it * kBlock;
-    if (!G::FLAT) {
-      const int ch = j / (G::RL / 4), quad = j - ch * (G::RL / 4);
-      const int g = g0 + 4 * quad;
-      const bool ok = j < G::NV && g < total;
-      const int n = ok ? g / HW : 0, p = ok ? g - n * HW : 0;
-      xoff[it] = ok ? (n * A.C + ch) * HW + p : -1;
-    } else {
-      const int s = j / (G::CH * HW / 4), f = j - s * (G::CH * HW / 4);
-      const bool ok = j < G::NV && n0 + s < A.N;
-      xoff[it] = ok ? (n0 + s) * A.C * HW + 4 * f : -1;
-    }
-  }
-  f4 pin[G::IT], pwt[G::WIT];
-  auto fetch_item = [&](int chunk, int it) {
-    pin[it] = *reinterpret_cast<const f4 *>(A.x + (size_t)chunk * (G::CH * HW) + (xoff[it] < 0 ? 0 : xoff[it]));
-  };
-  auto fetch_w = [&](int chunk, int k) {
-    const int i = tid + k * kBlock;
-    pwt[k] = *reinterpret_cast<const f4 *>(wtg + (size_t)chunk * G::WT + 4 * (i < G::WF4 ? i : 0));
-  };
-  auto stash_item = [&](float *buf, int it) {
-    f4 v = pin[it];
-    if (xoff[it] < 0) v = f4{0.f, 0.f, 0.f, 0.f};
-    const int j = tid + it * kBlock;
-    *reinterpret_cast<f4 *>(buf + ((it + 1) * kBlock <= G::NV || j < G::NV ? 4 * j : G::DUMMY)) = v;
-  };
-  auto stash_w = [&](float *buf, int k) {
-    const int i = tid + k * kBlock;
-    *reinterpret_cast<f4 *>(buf + ((k + 1) * kBlock <= G::WF4 || i < G::WF4 ? G::WOFF + 4 * i : G::WDUMMY)) = pwt[k];
-  };
-  constexpr int NI = G::IT + G::WIT;
-  auto piece = [&](float *buf, int c2, int t) {
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      if (i * (NS - 1) / NI != t) continue;
-      if (i < G::IT) {
-        stash_item(buf, i);
-        fetch_item(c2, i);
-      } else {
-        stash_w(buf, i - G::IT);
-        fetch_w(c2, i - G::IT);
-      }
-    }
-  };
-
-  const int abase = G::WOFF + half * kCvO + ocf * 32 + l32;
-  int boff[4];
-  bool mB[4], mR[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int gl = (pf0 + 2 * q) * 32 + l32;
-    int p;
-    if (!G::FLAT) {
-      boff[q] = half * G::CHS + gl;
-      int g = g0 + gl;
-      if (g >= total) g = g0;
-      p = g % HW;
-    } else {
-      int s = gl / HW;
-      p = gl - s * HW;
-      if (s >= G::SPT) s = 0, p = 0;
-      boff[q] = s * (G::CH * HW) + half * HW + p;
-    }
-    const int a = p / S, b = p - a * S;
-    mB[q] = a < S - 1, mR[q] = b < S - 1;
-  }
-  f16v acc[2][4];
-#pragma unroll
-  for (int c = 0; c < 2; ++c)
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) acc[c][q][v] = 0.f;
-
-  struct Ops {
-    float a[3], b0[4], b1[4];
-  };
-  auto operands = [&](const float *cur, int t, Ops &o) {       // step t = (cp, th)
-    const int cp = t / (1 + PR), th = t - cp * (1 + PR);
-    const int koff = cp * 2 * G::CHS + th * S;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) o.a[j] = cur[abase + (t * 3 + j) * 2 * kCvO];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      o.b0[q] = cur[boff[q] + koff];
-      o.b1[q] = cur[boff[q] + koff + 1];
-    }
-  };
-  auto masked = [&](int t, Ops &o) {
-    const int th = t % (1 + PR);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (th) o.b0[q] = mB[q] ? o.b0[q] : 0.f;
-      o.b1[q] = (mR[q] && (!th || mB[q])) ? o.b1[q] : 0.f;
-    }
-  };
-
-  float *buf0 = lds, *buf1 = buf0 + G::BUF;
-#pragma unroll
-  for (int it = 0; it < G::IT; ++it) fetch_item(0, it);
-#pragma unroll
-  for (int k = 0; k < G::WIT; ++k) fetch_w(0, k);
-#pragma unroll
-  for (int it = 0; it < G::IT; ++it) stash_item(buf0, it);
-#pragma unroll
-  for (int k = 0; k < G::WIT; ++k) stash_w(buf0, k);
-  const int c1 = NCH > 1 ? 1 : 0;
-#pragma unroll
-  for (int it = 0; it < G::IT; ++it) fetch_item(c1, it);
-#pragma unroll
-  for (int k = 0; k < G::WIT; ++k) fetch_w(c1, k);
-  DP_BARRIER_LDS();
-  Ops nx;
-  operands(buf0, 0, nx);
-  const int last = NCH - 1;
-  for (int chunk = 0; chunk < NCH; ++chunk) {
-    const float *cur = (chunk & 1) ? buf1 : buf0;
-    float *nxt = (chunk & 1) ? buf0 : buf1;
-    const int c2 = chunk + 2 < NCH ? chunk + 2 : last;
-    Ops o[2];
-    o[0] = nx;
-#pragma unroll
-    for (int t = 0; t < NS; ++t) {
-      masked(t, o[t & 1]);
-      if (t + 1 < NS) {
-        operands(cur, t + 1, o[(t + 1) & 1]);
-      } else {
-        DP_BARRIER_LDS();
-        operands(nxt, 0, nx);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const Ops &c = o[t & 1];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.a[0], c.b0[q], acc[0][q], 0, 0, 0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.a[1], c.b0[q], acc[1][q], 0, 0, 0);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.a[2], c.b1[q], acc[1][q], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < NS) piece(nxt, c2, t);
-    }
-  }
-
-  const int oc0 = og * kCvO + ocf * 32 + 4 * half;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int gl = (pf0 + 2 * q) * 32 + l32;
-    int n, p;
-    bool ok;
-    if (!G::FLAT) {
-      const int g = g0 + gl;
-      ok = g < total;
-      n = g / HW, p = g - n * HW;
-    } else {
-      const int s = gl / HW;
-      p = gl - s * HW, n = n0 + s;
-      ok = s < G::SPT && n < A.N;
-    }
-    if (!ok) continue;
-    const int a = p / S, b = p - a * S;
-    float *yq = A.y + ((size_t)n * A.O + oc0) * (4 * HW) + (2 * a + PR) * (2 * S) + 2 * b;
-#pragma unroll
-    for (int v = 0; v < 16; ++v)
-      *reinterpret_cast<f2 *>(yq + (size_t)((v & 3) + 8 * (v >> 2)) * (4 * HW)) = f2{acc[0][q][v], acc[1][q][v]};
-  }
-}
-
-// A.wt = the row class pr = 1 (all of its chunks) followed by pr = 0 (pack_conv3x3s2_dgrad_weights(..., pairs=True))
-template <int S>
-__global__ __launch_bounds__(kBlock, 2) void k_conv3x3s2_dgrad2(CfArgs A) {
-  typedef Cf2Geom<S, 1> G1;
-  typedef Cf2Geom<S, 0> G0;
-  __shared__ __attribute__((aligned(16))) float lds[G1::LDS > G0::LDS ? G1::LDS : G0::LDS];
-  const int slot = blockIdx.x >> 3;
-  int tile, og;
-  cf_decode(slot >> 1, blockIdx.x & 7, A.og, tile, og);
-  if (tile >= A.tiles) return;
-  if ((slot & 1) == 0) cf2_body<G1>(lds, A, A.wt, tile, og);
-  else cf2_body<G0>(lds, A, A.wt + 6 * (size_t)A.C * A.O, tile, og);
-}
-
-#endif             // ---------------------------------------------------------------- part 2 pauses
-#if DP_HAS(1)      // ---------------------------------------------------------------- part 1 resumes
-// ----------------------------------------------------------------------------
-// a-8 (round 5): the STEM convolution (3 -> 64 channels, 7 x 7 / stride 2 / pad 3, 224 -> 112) on the matrix cores.
-// MIOpen runs it as a stride-2 Winograd (miopenSp3AsmConv_v30_3_1_gfx9_fp32_f3x2_stride2: 2.31 ms per 512 images = 52
-// TFLOP/s, 9.3 ms of a configs[1] step: profiles/r05i_kernel_stats_timed_headline_streams1.txt).  K = 3 x 7 x 7 = 147 is
-// small enough that a workgroup's whole operand set lives in LDS at once — no K loop over chunks:
-//   tile   = 4 output rows of one image (4 x 112 = 448 pixels, 14 fragments) x all 64 output channels;
-//   input  = the 13 input rows 2 h0 - 3 .. 2 h0 + 9 of the 3 channels, DE-INTERLEAVED by column parity as in
-//            k_conv3x3s2_mfma: sub-row ((row, channel), pc) holds x[row][2 (i - 2) + pc] at word i (2 zero words left, 2 right),
-//            rows above / below the image are zero rows;  with the channel INSIDE the row, flattening (kh, c) -> r = 3 kh + c
-//            makes every tap row r of a pixel the sub-row pair 2 PITCH r further on, so the two k of an MFMA k-step are the
-//            rows (2 j, 2 j + 1) of the same kw: the lane's half adds a constant — 11 row pairs (r = 21 is padding: zero
-//            weights) x 7 kw = 77 k-steps x 7 MFMAs per wave, 95 % of them useful;
-//   weights = all 77 x 2 x 64 of them (39 KB), packed by the host in that order.
-// LDS 75.6 KB -> 2 workgroups per CU: one stages (19 16-byte loads per lane) while the other multiplies.  Exact f32, fixed
-// order: deterministic.
-constexpr int kStW = 224, kStWo = kStW / 2;                       // input / output width
-constexpr int kStPitch = kStWo + 4;                               // 116 words per sub-row
-constexpr int kStRows = 13;                                       // input rows of a tile
-constexpr int kStIn = kStRows * 3 * 2 * kStPitch;                 // 9048 floats
-constexpr int kStSteps = 11 * 7;                                  // 77 k-steps
-constexpr int kStWt = kStSteps * 2 * kCvO;                        // 9856 floats
-constexpr int kStIt = (kStRows * 3 * (kStW / 4) + kBlock - 1) / kBlock;      // 9 input float4 per lane
-constexpr int kStWIt = (kStWt / 4 + kBlock - 1) / kBlock;         // 10 weight float4 per lane
-static_assert(kCvPix == 4 * kStWo, "a tile is 4 output rows");
-
-__global__ __launch_bounds__(kBlock, 2) void k_stem_conv_mfma(const float *__restrict__ x, const float *__restrict__ wt,
-                                                              float *__restrict__ y, int N, int H, int tpi) {
-  __shared__ __attribute__((aligned(16))) float lds[kStIn + kStWt];
-  const int Ho = H / 2;
-  const int n = blockIdx.x / tpi, h0 = (blockIdx.x - n * tpi) * 4;       // first output row of the tile
-  const int r0 = 2 * h0 - 3;                                             // input row of LDS row 0
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, l32 = lane & 31;
-  const int ocf = wave & 1, pf0 = wave >> 1;
-
-  // the 4 pad words of every sub-row
-  for (int i = tid; i < kStRows * 3 * 2 * 4; i += kBlock) {
-    const int sub = i >> 2, k = i & 3;
-    lds[sub * kStPitch + (k < 2 ? k : kStWo + k)] = 0.f;
-  }
-  f4 pin[kStIt], pwt[kStWIt];
-#pragma unroll
-  for (int it = 0; it < kStIt; ++it) {
-    const int j = tid + it * kBlock;                         // (row, channel, float4 of the row)
-    const int rc = j / (kStW / 4), q = j - rc * (kStW / 4);
-    const int row = rc / 3, c = rc - row * 3;
-    const int r = r0 + row;
-    const bool ok = j < kStRows * 3 * (kStW / 4) && r >= 0 && r < H;
-    pin[it] = *reinterpret_cast<const f4 *>(x + (ok ? (((size_t)n * 3 + c) * H + r) * kStW + 4 * q : (size_t)0));
-    if (!ok) pin[it] = f4{0.f, 0.f, 0.f, 0.f};
-  }
-#pragma unroll
-  for (int k = 0; k < kStWIt; ++k) {
-    const int i = tid + k * kBlock;
-    pwt[k] = *reinterpret_cast<const f4 *>(wt + 4 * (i < kStWt / 4 ? i : 0));
-  }
-#pragma unroll
-  for (int it = 0; it < kStIt; ++it) {
-    const int j = tid + it * kBlock;
-    if (j < kStRows * 3 * (kStW / 4)) {
-      const int rc = j / (kStW / 4), q = j - rc * (kStW / 4);
-      float *dst = lds + rc * 2 * kStPitch + 2 + 2 * q;      // columns 4 q .. 4 q + 3 -> words 2 q, 2 q + 1 of both parities
-      *reinterpret_cast<f2 *>(dst) = f2{pin[it].x, pin[it].z};
-      *reinterpret_cast<f2 *>(dst + kStPitch) = f2{pin[it].y, pin[it].w};
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < kStWIt; ++k) {
-    const int i = tid + k * kBlock;
-    if (i < kStWt / 4) *reinterpret_cast<f4 *>(lds + kStIn + 4 * i) = pwt[k];
-  }
-  // (the padding row pair r = 21 of the tile's last output row reads the first words of the weights: finite, times zero)
-
-  const int abase = kStIn + half * kCvO + ocf * 32 + l32;
-  int boff[7];
-#pragma unroll
-  for (int q = 0; q < 7; ++q) {
-    const int gl = (pf0 + 2 * q) * 32 + l32;
-    const int hl = gl / kStWo, w = gl - hl * kStWo;
-    boff[q] = (2 * hl * 3 + half) * 2 * kStPitch + w;
-  }
-  f16v acc[7];
-#pragma unroll
-  for (int q = 0; q < 7; ++q)
-#pragma unroll
-    for (int v = 0; v < 16; ++v) acc[q][v] = 0.f;
-  __syncthreads();
-
-  // k-step t = 7 j + kw: rows (2 j, 2 j + 1) of tap column kw; word offset of kw within the sub-row pair:
-  //   kw 0 -> (odd, -2), 1 -> (even, -1), 2 -> (odd, -1), 3 -> (even, 0), 4 -> (odd, 0), 5 -> (even, +1), 6 -> (odd, +1)
-  auto operands = [&](int t, float &a, float (&bv)[7]) {
-    const int j = t / 7, kw = t - 7 * j;
-    const int koff = 2 * j * 2 * kStPitch + ((kw & 1) ? 0 : kStPitch) + (kw + 1) / 2;      // + 2 (left pad) - 2 (kw 0 / -3 columns)
-    a = lds[abase + t * 2 * kCvO];
-#pragma unroll
-    for (int q = 0; q < 7; ++q) bv[q] = lds[boff[q] + koff];
-  };
-  float a[2], b[2][7];
-  operands(0, a[0], b[0]);
-#pragma unroll
-  for (int t = 0; t < kStSteps; ++t) {
-    if (t + 1 < kStSteps) operands(t + 1, a[(t + 1) & 1], b[(t + 1) & 1]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < 7; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t & 1], b[t & 1][q], acc[q], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-
-  const int oc0 = ocf * 32 + 4 * half;
-  const size_t plane = (size_t)Ho * kStWo;
-#pragma unroll
-  for (int q = 0; q < 7; ++q) {
-    const int gl = (pf0 + 2 * q) * 32 + l32;
-    const int hl = gl / kStWo;
-    if (h0 + hl >= Ho) continue;
-    float *yq = y + ((size_t)n * kCvO + oc0) * plane + (size_t)h0 * kStWo + gl;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) yq[(size_t)((v & 3) + 8 * (v >> 2)) * plane] = acc[q][v];
-  }
-}
-
-// variant 0: fp32 VALU gather, 2 quads per thread (shipped); 2: the same with 4 quads per thread (measured slower, see
-// k_stem_dgrad); 1: matrix cores (k_stem_dgrad_mfma; needs K % 4 == 0, else the default is used; measured slower)
-constexpr int kStemDefaultVariant = 0;
-
-int launch_stem_dgrad(int variant, const float *dy, const float *w, int N, int K, int Ho, int Wo, float *dx,
-                      hipStream_t st) {
-  if (variant == 1 && (K & 3) == 0) {
-    hipLaunchKernelGGL(k_stem_dgrad_mfma, dim3(cdiv(Wo, kMT), cdiv(Ho, kMT), N), dim3(256), 0, st, dy, w, K, Ho, Wo, dx);
-    return launch_status();
-  }
-  if (variant == 0) hipLaunchKernelGGL(k_stem_dgrad<2>, dim3(cdiv(Wo, SQ), cdiv(Ho, 16), N), dim3(kStemBlock), 0, st, dy, w, K, Ho, Wo, dx);
-  else hipLaunchKernelGGL(k_stem_dgrad<4>, dim3(cdiv(Wo, SQ), cdiv(Ho, 32), N), dim3(kStemBlock), 0, st, dy, w, K, Ho, Wo, dx);
-  return launch_status();
-}
-
-#endif             // ---------------------------------------------------------------- part 1 pauses
-#if DP_HAS(4)
-#include "conv3x3_wino.inc"      // round 6: Winograd F(2x2, 3x3) on the matrix cores (its own file: VERDICT r5 item 8)
-#endif
-
 }  // namespace
 
-// ============================================================================
-// C ABI
-// ============================================================================
+// The kernel families, each with its launchers and its extern "C" entry points.
+#include "conv_common.inc"    // shared by the convolution families (the stem convolution in stem.inc included)
+#if DP_HAS(1)
+#include "apply.inc"          // clip + blend, occlusion apply (+ the affine extension), slab sums
+#include "update.inc"         // CW / structural losses, mask statistics, the fused projected update, argmax
+#include "gn.inc"             // GroupNorm + ReLU
+#include "stem.inc"           // pad + max-pool, stem convolution and its input gradient, subsampling
+#endif
+#if DP_HAS(2) || DP_HAS(5)
+#include "conv3x3.inc"        // direct 3x3, stride 1 (entry points in part 2 only) + the flat-image walk the stride-2 input gradient shares
+#endif
+#if DP_HAS(5)
+#include "conv3x3s2.inc"      // direct 3x3, stride 2, and its input gradient
+#endif
+#if DP_HAS(3)
+#include "conv1x1.inc"        // k_conv1x1_mfma
+#endif
+#if DP_HAS(4)
+#include "conv3x3_wino.inc"   // Winograd F(2x2, 3x3) on the matrix cores
+#endif
 
-extern "C" {
+// ============================================================================
+// C ABI: version, errors, debug knobs, events (every other entry point sits with its kernels)
+// ============================================================================
 
 #if DP_HAS(1)
+extern "C" {
+
 int dp_abi_version(void) { return DP_ABI_VERSION; }
 
 const char *dp_error_string(int err) { return hipGetErrorString((hipError_t)err); }
@@ -4719,646 +178,6 @@ int dp_debug_set(int knob, int value) {
   }
 }
 
-int dp_sumsq_nchunk(int P) { return P > 0 ? cdiv(P, kSumsqPixPerBlock) : 0; }
-
-int dp_sumsq_partials(const float *mask, const float *pattern, const float *x, int B, int P,
-                      float *partials, dp_stream_t stream) {
-  DP_REQUIRE(mask && pattern && x && partials);
-  DP_REQUIRE(B > 0 && P > 0 && (P & 3) == 0);
-  DP_REQUIRE(aligned16(mask) && aligned16(pattern) && aligned16(x));
-  const int nchunk = dp_sumsq_nchunk(P);
-  hipLaunchKernelGGL(k_sumsq_partials, dim3(nchunk, B), dim3(kBlock), 0, as_stream(stream), mask,
-                     pattern, x, P, nchunk, partials);
-  return launch_status();
-}
-
-int dp_blend(const float *mask, const float *pattern, const float *x, const float *partials,
-             float eps, int B, int P, int add_x, float *adv_x, float *scale, float *l2,
-             dp_stream_t stream) {
-  DP_REQUIRE(mask && pattern && x && partials && adv_x && scale && l2);
-  DP_REQUIRE(B > 0 && P > 0 && (P & 3) == 0);
-  DP_REQUIRE(aligned16(mask) && aligned16(pattern) && aligned16(x) && aligned16(adv_x));
-  const int nchunk = dp_sumsq_nchunk(P);
-  hipLaunchKernelGGL(k_blend, dim3(cdiv(P >> 2, kBlock), B), dim3(kBlock), 0, as_stream(stream),
-                     mask, pattern, x, partials, nchunk, eps, P, add_x, adv_x, scale, l2);
-  return launch_status();
-}
-
-static int check_occlusion_args(const int32_t *table, int R, const int32_t *idx, int idx_bstride,
-                                int B, int S, int H, int W, const dp_norm_t *norm) {
-  DP_REQUIRE(table && idx && norm);
-  DP_REQUIRE(R >= 1 && R <= DP_MAX_RECTS);
-  DP_REQUIRE(B > 0 && B <= 65535 && S > 0 && H > 0 && W > 0 && (W & 3) == 0);
-  DP_REQUIRE(idx_bstride == 0 || idx_bstride >= S);
-  if (norm->enable) {
-    for (int c = 0; c < 3; ++c) DP_REQUIRE(norm->std[c] != 0.f);
-  }
-  return 0;
-}
-
-int dp_apply_fwd(const float *adv_x, const int32_t *table, int R, const int32_t *idx,
-                 const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
-                 const dp_norm_t *norm, float *out, dp_stream_t stream) {
-  DP_REQUIRE(adv_x && out && aligned16(adv_x) && aligned16(out));
-  const int rc = check_occlusion_args(table, R, idx, idx_bstride, B, S, H, W, norm);
-  if (rc) return rc;
-  return launch_apply_fwd(kApplyFwdDefaultVariant, adv_x, table, R, idx, idx2, idx_bstride, B, S, H, W,
-                          norm, out, stream);
-}
-
-// S-slab partition shared by dp_apply_bwd, dp_stem_dgrad_reduce and dp_apply_affine_bwd (so that they sum in the
-// same order): enough slabs for ~4096 workgroups (the fused stem kernel runs 2-wave workgroups for a whole slab of
-// samples x 64 channels each: with fewer it is latency-bound — 1568 workgroups measured 1.8x slower than the two
-// separate kernels), at least 2 samples per slab.
-static int bwd_s_per_slab(int B, int S, int P) {
-  const int tiles = cdiv(P >> 2, kBlock);
-  int nslab = cdiv(4096, tiles * B);
-  const int max_slab = S >= 4 ? S / 2 : 1;
-  if (nslab > max_slab) nslab = max_slab;
-  if (nslab < 1) nslab = 1;
-  return cdiv(S, nslab);
-}
-
-int dp_apply_bwd_nslab(int B, int S, int P) {
-  if (B <= 0 || S <= 0 || P <= 0) return 0;
-  return cdiv(S, bwd_s_per_slab(B, S, P));
-}
-
-int dp_apply_bwd(const float *G, const int32_t *table, int R, const int32_t *idx,
-                 const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
-                 const dp_norm_t *norm, float *slabs, dp_stream_t stream) {
-  DP_REQUIRE(G && slabs && aligned16(G) && aligned16(slabs));
-  const int rc = check_occlusion_args(table, R, idx, idx_bstride, B, S, H, W, norm);
-  if (rc) return rc;
-  const int P = H * W;
-  const int s_per_slab = bwd_s_per_slab(B, S, P);
-  const int nslab = cdiv(S, s_per_slab);
-  DP_REQUIRE(nslab <= 65535);
-  hipLaunchKernelGGL(k_apply_bwd, dim3(cdiv(P >> 2, kBlock), nslab, B), dim3(kBlock), 0,
-                     as_stream(stream), G, table, R, idx, idx2, idx_bstride, B, S, H, W,
-                     s_per_slab, make_norm(norm), slabs);
-  return launch_status();
-}
-
-// samples one forward workgroup walks (software-pipelined footprint loads); tools/kbench overrides it to sweep
-constexpr int kAffSamplesPerBlock = 8;
-
-static int launch_apply_affine_fwd(const float *x, const float *delta, const float *theta, const int32_t *table, int R,
-                                   const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
-                                   const dp_norm_t *norm, float *out, dp_stream_t stream, hipEvent_t ev_start,
-                                   hipEvent_t ev_stop) {
-  DP_REQUIRE(x && delta && theta && out && aligned16(x) && aligned16(out) && aligned16(delta));   // b128 buffer loads of delta
-  const int rc = check_occlusion_args(table, R, idx, idx_bstride, B, S, H, W, norm);
-  if (rc) return rc;
-  const int tiles_x = cdiv(W, kAffT), tiles_y = cdiv(H, kAffT);
-  DP_REQUIRE((long)H * W * 12 < (1l << 31) && H < (1 << 22) && W < (1 << 22));   // 32-bit byte offsets, 24-bit multiplies
-  int spb = kAffSamplesPerBlock;   // ... unless that leaves fewer than ~4 workgroups per CU slot (small B)
-  while (spb > 1 && (long)tiles_x * tiles_y * B * cdiv(S, spb) < 4096) spb >>= 1;
-  if (g_aff_samples_per_block > 0) spb = g_aff_samples_per_block;   // dp_debug_set / tools/kbench
-  spb = min(spb, 64);   // one lane of a wave per sample of the chunk
-  DP_REQUIRE(cdiv(S, spb) <= 65535);
-  hipExtLaunchKernelGGL(k_apply_affine_fwd, dim3(tiles_x * tiles_y, cdiv(S, spb), B), dim3(kBlock), 0, as_stream(stream),
-                        ev_start, ev_stop, 0, x, delta, theta, table, R, idx, idx2, idx_bstride, S, H, W, tiles_x, spb,
-                        make_norm(norm), out);
-  return launch_status();
-}
-
-int dp_apply_affine_fwd(const float *x, const float *delta, const float *theta, const int32_t *table, int R,
-                        const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
-                        const dp_norm_t *norm, float *out, dp_stream_t stream) {
-  return launch_apply_affine_fwd(x, delta, theta, table, R, idx, idx2, idx_bstride, B, S, H, W, norm, out, stream,
-                                 nullptr, nullptr);
-}
-
-int dp_apply_affine_fwd_timed(const float *x, const float *delta, const float *theta, const int32_t *table, int R,
-                              const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
-                              const dp_norm_t *norm, float *out, dp_stream_t stream, dp_event_t start, dp_event_t stop) {
-  DP_REQUIRE(start && stop);
-  return launch_apply_affine_fwd(x, delta, theta, table, R, idx, idx2, idx_bstride, B, S, H, W, norm, out, stream,
-                                 (hipEvent_t)start, (hipEvent_t)stop);
-}
-
-static int g_aff_bwd_cap = 0;   // tools/kbench: 2048 selects the 48 KiB variant
-
-int dp_apply_affine_bwd(const float *G, const float *theta, const float *theta_inv, const int32_t *table, int R,
-                        const int32_t *idx, const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
-                        const dp_norm_t *norm, float *slabs, dp_stream_t stream) {
-  DP_REQUIRE(G && theta && theta_inv && slabs && aligned16(G));   // affine_region_load reads G as float4
-  const int rc = check_occlusion_args(table, R, idx, idx_bstride, B, S, H, W, norm);
-  if (rc) return rc;
-  DP_REQUIRE(H < (1 << 22) && W < (1 << 22));   // 24-bit multiplies in the region addressing
-  const int P = H * W;
-  const int s_per_slab = bwd_s_per_slab(B, S, P);
-  const int nslab = cdiv(S, s_per_slab);
-  DP_REQUIRE(nslab <= 65535);
-  const int tiles_x = cdiv(W, kAffT), tiles_y = cdiv(H, kAffTB);
-  if (g_aff_bwd_cap == 2048)
-    hipLaunchKernelGGL(k_apply_affine_bwd<2048>, dim3(tiles_x * tiles_y, nslab, B), dim3(kBlock), 0, as_stream(stream), G,
-                       theta, theta_inv, table, R, idx, idx2, idx_bstride, B, S, H, W, tiles_x, s_per_slab,
-                       make_norm(norm), slabs, g_aff_gather);
-  else
-    hipLaunchKernelGGL(k_apply_affine_bwd<kAffCapB>, dim3(tiles_x * tiles_y, nslab, B), dim3(kBlock), 0, as_stream(stream),
-                       G, theta, theta_inv, table, R, idx, idx2, idx_bstride, B, S, H, W, tiles_x, s_per_slab,
-                       make_norm(norm), slabs, g_aff_gather);
-  return launch_status();
-}
-
-int dp_sum_slabs(const float *slabs, int nslab, int64_t n, float *out, int accumulate,
-                 dp_stream_t stream) {
-  DP_REQUIRE(slabs && out && nslab >= 1 && n > 0 && (n & 3) == 0);
-  DP_REQUIRE(aligned16(slabs) && aligned16(out));
-  const int64_t n4 = n >> 2;
-  const int64_t blocks = (n4 + kBlock - 1) / kBlock;
-  DP_REQUIRE(blocks <= 0x7fffffff);
-  hipLaunchKernelGGL(k_sum_slabs, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream),
-                     slabs, nslab, n4, out, accumulate);
-  return launch_status();
-}
-
-int dp_cw_loss(const float *logits, const int64_t *y, const int32_t *targeted, int N, int C,
-               int S, float confidence, float upstream, float *loss, float *dlogits,
-               int32_t *pred, dp_stream_t stream) {
-  DP_REQUIRE(logits && y && targeted && loss);
-  DP_REQUIRE(N > 0 && C > 1 && S > 0);
-  hipLaunchKernelGGL(k_cw_loss, dim3(cdiv(N, kBlock / 64)), dim3(kBlock), 0, as_stream(stream),
-                     logits, y, targeted, N, C, S, confidence, upstream, loss, dlogits, pred);
-  return launch_status();
-}
-
-int dp_local_variance(const float *x, int B, int H, int W, float *lv, dp_stream_t stream) {
-  DP_REQUIRE(x && lv && B > 0 && B <= 65535 && H > 0 && W > 0);
-  hipLaunchKernelGGL(k_local_variance, dim3(cdiv(W, TW), cdiv(H, TH), B), dim3(kBlock), 0,
-                     as_stream(stream), x, H, W, lv);
-  return launch_status();
-}
-
-int dp_struct_ntile(int H, int W) { return (H > 0 && W > 0) ? cdiv(W, TW) * cdiv(H, TH) : 0; }
-
-int dp_struct_loss(const float *adv_x, const float *lv_x, int B, int H, int W, float *partials,
-                   dp_stream_t stream) {
-  DP_REQUIRE(adv_x && lv_x && partials && B > 0 && B <= 65535 && H > 0 && W > 0);
-  hipLaunchKernelGGL(k_struct_loss, dim3(cdiv(W, TW), cdiv(H, TH), B), dim3(kBlock), 0,
-                     as_stream(stream), adv_x, lv_x, H, W, partials);
-  return launch_status();
-}
-
-int dp_reduce_rows(const float *in, int B, int n, float scale, float *out, dp_stream_t stream) {
-  DP_REQUIRE(in && out && B > 0 && n > 0);
-  hipLaunchKernelGGL(k_reduce_rows, dim3(cdiv(B, kBlock / 64)), dim3(kBlock), 0,
-                     as_stream(stream), in, B, n, scale, out);
-  return launch_status();
-}
-
-int dp_mask_stats(const float *mask, int B, int H, int W, int unit, int win, float *cell_sumsq,
-                  float *win_sum, float *group_lasso, float *density, dp_stream_t stream) {
-  DP_REQUIRE(mask && cell_sumsq && win_sum && group_lasso && density);
-  DP_REQUIRE(B > 0 && H > 0 && W > 0 && unit > 0 && win > 0 && unit <= H && unit <= W &&
-             win <= H && win <= W);
-  const int ncy = (H - unit) / unit + 1, ncx = (W - unit) / unit + 1;
-  const int nwy = (H - win) / win + 1, nwx = (W - win) / win + 1;
-  DP_REQUIRE(nwy * nwx >= 2 && B <= 65535);
-  DP_REQUIRE((W & 3) == 0 && aligned16(mask));
-  const size_t lds = (size_t)unit * W * sizeof(float);
-  DP_REQUIRE(lds <= 64 * 1024);
-  hipLaunchKernelGGL(k_mask_bands, dim3(ncy + nwy, B), dim3(kBlock), lds, as_stream(stream), mask, H, W,
-                     unit, win, ncy, ncx, nwy, nwx, cell_sumsq, win_sum);
-  hipLaunchKernelGGL(k_mask_finish, dim3(B), dim3(kBlock), 0, as_stream(stream), cell_sumsq, win_sum,
-                     unit, ncy * ncx, nwy * nwx, group_lasso, density);
-  return launch_status();
-}
-
-int dp_project_update(const dp_update_cfg_t *cfg, const float *x, const float *adv_x,
-                      const float *lv_x, const float *g_adv, const float *scale,
-                      const float *structured, const float *coeff_gl, const float *lr,
-                      const float *cell_sumsq, const float *win_sum, const int32_t *save_best,
-                      float *pattern, float *mask, float *best_pattern, float *best_mask,
-                      float *g_pattern_out, float *g_mask_out, dp_stream_t stream) {
-  DP_REQUIRE(cfg && x && adv_x && lv_x && g_adv && scale && structured && pattern && mask);
-  DP_REQUIRE(cfg->B > 0 && cfg->B <= 65535 && cfg->H > 0 && cfg->W > 0);
-  DP_REQUIRE(cfg->stage == 0 || cfg->stage == 1);
-  DP_REQUIRE(!cfg->do_update || lr);
-  DP_REQUIRE(!save_best || (best_pattern && (cfg->stage == 1 || best_mask)));
-  UpdateArgs A;
-  A.x = x; A.adv_x = adv_x; A.lv_x = lv_x; A.g_adv = g_adv;
-  A.scale = scale; A.structured = structured; A.coeff_gl = coeff_gl; A.lr = lr;
-  A.cell_sumsq = cell_sumsq; A.win_sum = win_sum; A.save_best = save_best;
-  A.pattern = pattern; A.mask = mask; A.best_pattern = best_pattern; A.best_mask = best_mask;
-  A.g_pattern_out = g_pattern_out; A.g_mask_out = g_mask_out;
-  A.H = cfg->H; A.W = cfg->W; A.stage = cfg->stage; A.unit = cfg->unit; A.win = cfg->win;
-  A.ncy = A.ncx = A.nwy = A.nwx = 1;
-  A.do_update = cfg->do_update; A.density = cfg->density;
-  A.clip_min = cfg->clip_min; A.clip_max = cfg->clip_max;
-  if (cfg->stage == 0) {
-    DP_REQUIRE(coeff_gl && cell_sumsq && win_sum);
-    DP_REQUIRE(cfg->unit > 0 && cfg->win > 0 && cfg->unit <= cfg->H && cfg->unit <= cfg->W &&
-               cfg->win <= cfg->H && cfg->win <= cfg->W);
-    A.ncy = (cfg->H - cfg->unit) / cfg->unit + 1;
-    A.ncx = (cfg->W - cfg->unit) / cfg->unit + 1;
-    A.nwy = (cfg->H - cfg->win) / cfg->win + 1;
-    A.nwx = (cfg->W - cfg->win) / cfg->win + 1;
-    DP_REQUIRE(A.nwy * A.nwx >= 2);
-  }
-  const bool wide = (cfg->W & 3) == 0 && g_update_variant != 1 && aligned16(x) && aligned16(adv_x) && aligned16(lv_x) &&
-                    aligned16(g_adv) && aligned16(pattern) && aligned16(mask) &&
-                    (!best_pattern || aligned16(best_pattern)) && (!best_mask || aligned16(best_mask)) &&
-                    (!g_pattern_out || aligned16(g_pattern_out)) && (!g_mask_out || aligned16(g_mask_out));
-  if (wide)
-    hipLaunchKernelGGL(k_project_update_v4, dim3(cdiv(cfg->W, UW), cdiv(cfg->H, UH), cfg->B),
-                       dim3(kBlock), 0, as_stream(stream), A);
-  else
-    hipLaunchKernelGGL(k_project_update, dim3(cdiv(cfg->W, TW), cdiv(cfg->H, TH), cfg->B),
-                       dim3(kBlock), 0, as_stream(stream), A);
-  return launch_status();
-}
-
-#endif   // part 1
-#if DP_HAS(2)
-// Which kernel runs a stride-1 3x3 problem of side H: k_conv3x3_mfma (explicit zero rows / columns in LDS; sides 56 / 28 / 14 /
-// 7) or k_conv3x3_flat (flat image, masked taps; any of the sides below).  Same packed weights, same summation order, same
-// bits.  Default: the measured winner per side (profiles/r05j_*); DP_DEBUG_CONV3X3_VARIANT forces one for A/B runs.
-static bool conv3x3_side_rows(int H) { return H == 56 || H == 28 || H == 14 || H == 7; }
-static bool conv3x3_side_flat(int H) { return H == 56 || H == 28 || H == 14 || H == 7 || H == 96 || H == 48 || H == 24 || H == 12; }
-static bool conv3x3_flat_default(int H) { return !conv3x3_side_rows(H) || H == 7; }   // 7 x 7: 1.054 vs 1.169 ms at N = 512 (r05j)
-
-// Pixel tile of k_conv3x3_flat (round 6): 448 (the round-5 tile; on the sides k_conv3x3_mfma takes, that kernel unless the
-// flat one measured faster), 128 or 64 pixels — the 7 x 7 planes: 9 / 2 / 1 whole images.  Same bits from every tile.
-// DP_DEBUG_CONV3X3_VARIANT bits 4-6 force one (1: 448, 3: 128, 4: 64); the rule is the measured one (profiles/r06c_*).
-static long conv3x3_tiles(long N, int H, int nq) {
-  const int pix = 64 * nq;
-  return H == 7 ? (N + pix / 49 - 1) / (pix / 49) : (N * H * H + pix - 1) / pix;
-}
-static int conv3x3_tile_nq(long N, int H, int og, bool fold) {
-  if (H == 56 || H == 96 || H == 48) return 7;       // big planes: plenty of 448-pixel tiles at any batch, halo >= a small tile
-  const int force = (g_conv3x3_variant >> 4) & 7;
-  if (force) return force == 1 ? 7 : force == 3 ? 2 : 1;
-  if (g_conv3x3_variant & 3) return 7;               // the kernel-choice knob reproduces the round-5 launches
-  (void)fold;
-  // pick_tile's model (k_conv1x1_mfma's launcher): cost = ceil(workgroups / 256) * NQ * penalty; the 64-pixel tile pays 8 %
-  // for its halo and weight re-reads (profiles/r06c_kbench_conv3x3_tiles_n512.txt), the 128-pixel one nothing measurable
-  static const int cand[3] = {7, 2, 1};
-  static const float pen[3] = {1.00f, 1.00f, 1.08f};
-  long wgs[3];
-  for (int i = 0; i < 3; ++i) wgs[i] = conv3x3_tiles(N, H, cand[i]) * og;
-  return pick_tile(cand, pen, 3, wgs);
-}
-
-static int conv3x3_launch(const float *x, const float *wt, const float *ab, int N, int C, int O, int H, int W, float *y,
-                          dp_stream_t stream) {
-  DP_REQUIRE(x && wt && y && aligned16(x) && aligned16(wt) && aligned16(y));
-  DP_REQUIRE(N > 0 && C > 0 && C % kCvCh == 0 && O > 0 && O % kCvO == 0 && O / kCvO <= 65535 && H == W);
-  DP_REQUIRE(conv3x3_side_rows(H) || conv3x3_side_flat(H));
-  DP_REQUIRE(!ab || (H != 7 && (reinterpret_cast<uintptr_t>(ab) & 7u) == 0));   // no fold on the 7 x 7 planes (rows are not 16-byte multiples)
-  DP_REQUIRE((long)N * H * W + kCvPix < (1L << 31));      // 32-bit pixel arithmetic in the kernel
-  hipStream_t st = as_stream(stream);
-  const int kvar = g_conv3x3_variant & 3;
-  const int nq = conv3x3_tile_nq(N, H, O / kCvO, ab != nullptr);
-  const bool flat = nq != 7 || (kvar == 2 ? conv3x3_side_flat(H) : kvar == 1 ? !conv3x3_side_rows(H) : conv3x3_flat_default(H));
-  if (flat) {
-    DP_REQUIRE((long)N * C * H * W < (1L << 31));         // 32-bit element offsets in the kernel
-    CfArgs A;
-    A.x = x; A.wt = wt; A.ab = ab; A.y = y;
-    A.N = N; A.C = C; A.O = O; A.og = O / kCvO;
-    const long tiles = conv3x3_tiles(N, H, nq);
-    DP_REQUIRE((tiles + 7) / 8 * 8 * A.og < (1L << 31));
-    A.tiles = (int)tiles;
-    const dim3 grid((unsigned)((tiles + 7) / 8 * 8 * A.og)), block(kBlock);
-#define DP_LAUNCH_CFQ(S_, NQ_)                                                                 \
-  do {                                                                                         \
-    if (ab) hipLaunchKernelGGL((k_conv3x3_flat<S_, true, NQ_>), grid, block, 0, st, A);        \
-    else hipLaunchKernelGGL((k_conv3x3_flat<S_, false, NQ_>), grid, block, 0, st, A);          \
-  } while (0)
-#define DP_LAUNCH_CF(S_)                                                                       \
-  do {                                                                                         \
-    if (nq == 7) DP_LAUNCH_CFQ(S_, 7);                                                         \
-    else if (nq == 2) DP_LAUNCH_CFQ(S_, 2);                                                    \
-    else DP_LAUNCH_CFQ(S_, 1);                                                                 \
-  } while (0)
-    switch (H) {
-      case 7:
-        if (nq == 7) hipLaunchKernelGGL((k_conv3x3_flat<7, false, 7>), grid, block, 0, st, A);
-        else if (nq == 2) hipLaunchKernelGGL((k_conv3x3_flat<7, false, 2>), grid, block, 0, st, A);
-        else hipLaunchKernelGGL((k_conv3x3_flat<7, false, 1>), grid, block, 0, st, A);
-        break;
-      case 14: DP_LAUNCH_CF(14); break;
-      case 28: DP_LAUNCH_CF(28); break;
-      case 56: DP_LAUNCH_CFQ(56, 7); break;
-      case 12: DP_LAUNCH_CF(12); break;
-      case 24: DP_LAUNCH_CF(24); break;
-      case 48: DP_LAUNCH_CFQ(48, 7); break;
-      default: DP_LAUNCH_CFQ(96, 7); break;
-    }
-#undef DP_LAUNCH_CF
-#undef DP_LAUNCH_CFQ
-    return launch_status();
-  }
-  const long tiles = ((long)N * H * W + kCvPix - 1) / kCvPix;
-  const dim3 grid((unsigned)tiles, O / kCvO), block(kBlock);
-  if (ab) {
-    if (H == 56) hipLaunchKernelGGL((k_conv3x3_mfma<56, true>), grid, block, 0, st, x, wt, y, N, C, O, ab);
-    else if (H == 28) hipLaunchKernelGGL((k_conv3x3_mfma<28, true>), grid, block, 0, st, x, wt, y, N, C, O, ab);
-    else hipLaunchKernelGGL((k_conv3x3_mfma<14, true>), grid, block, 0, st, x, wt, y, N, C, O, ab);
-    return launch_status();
-  }
-  if (H == 56) hipLaunchKernelGGL((k_conv3x3_mfma<56, false>), grid, block, 0, st, x, wt, y, N, C, O, ab);
-  else if (H == 28) hipLaunchKernelGGL((k_conv3x3_mfma<28, false>), grid, block, 0, st, x, wt, y, N, C, O, ab);
-  else if (H == 14) hipLaunchKernelGGL((k_conv3x3_mfma<14, false>), grid, block, 0, st, x, wt, y, N, C, O, ab);
-  else hipLaunchKernelGGL((k_conv3x3_mfma<7, false>), grid, block, 0, st, x, wt, y, N, C, O, ab);
-  return launch_status();
-}
-
-int dp_conv3x3_fwd(const float *x, const float *wt, int N, int C, int O, int H, int W, float *y, dp_stream_t stream) {
-  return conv3x3_launch(x, wt, nullptr, N, C, O, H, W, y, stream);
-}
-
-int dp_conv3x3_gn_fwd(const float *x, const float *wt, const float *ab, int N, int C, int O, int H, int W, float *y,
-                      dp_stream_t stream) {
-  DP_REQUIRE(ab);
-  return conv3x3_launch(x, wt, ab, N, C, O, H, W, y, stream);
-}
-
-#endif   // part 2
-#if DP_HAS(4)
-int dp_conv3x3_wino_fwd(const float *x, const float *wt, const float *ab, int N, int C, int O, int H, int W, float *y,
-                        dp_stream_t stream) {
-  DP_REQUIRE(x && wt && y && aligned16(x) && aligned16(wt) && aligned16(y));
-  DP_REQUIRE(N > 0 && C > 0 && C % (2 * kWnCh) == 0 && O > 0 && O % kWnO == 0 && H == W);     // an even number of K-chunks
-  DP_REQUIRE(H == 56 || H == 28 || H == 14 || H == 7 || H == 96 || H == 48 || H == 24 || H == 12);
-  DP_REQUIRE(!ab || (reinterpret_cast<uintptr_t>(ab) & 7u) == 0);
-  DP_REQUIRE((long)N * C * H * W < (1L << 31) && (long)N * O * H * W < (1L << 31));      // 32-bit element offsets in the kernel
-  return launch_conv3x3_wino(x, wt, ab, N, C, O, H, y, as_stream(stream));
-}
-
-#endif   // part 4
-#if DP_HAS(2)
-int dp_conv3x3s2_fwd(const float *x, const float *wt, const float *ab, int N, int C, int O, int H, int W, float *y,
-                     dp_stream_t stream) {
-  DP_REQUIRE(x && wt && y && aligned16(x) && aligned16(wt) && aligned16(y));
-  DP_REQUIRE(N > 0 && C > 0 && C % kCvCh == 0 && O > 0 && O % kCvO == 0 && O / kCvO <= 65535 && H == W);
-  DP_REQUIRE(H == 56 || H == 28 || H == 14);                          // INPUT side; the output is (H / 2) x (H / 2)
-  DP_REQUIRE(!ab || (reinterpret_cast<uintptr_t>(ab) & 7u) == 0);
-  DP_REQUIRE((long)N * C * H * W < (1L << 31));                       // 32-bit element offsets in the kernel
-  const int SO = H / 2;
-  // pixel tile by pick_tile's model (k_conv1x1_mfma's launcher); DP_DEBUG_CONV3X3_VARIANT bits 4-6 force one
-  int nq;
-  {
-    static const int cand[3] = {7, 2, 1};
-    static const float pen[3] = {1.00f, 1.03f, 1.10f};
-    long wgs[3];
-    for (int i = 0; i < 3; ++i) wgs[i] = (((long)N * SO * SO + 64 * cand[i] - 1) / (64 * cand[i])) * (O / kCvO);
-    const int force = (g_conv3x3_variant >> 4) & 7;
-    nq = force ? (force == 1 ? 7 : force == 3 ? 2 : 1) : (g_conv3x3_variant & 3) ? 7 : pick_tile(cand, pen, 3, wgs);
-  }
-  const long tiles = ((long)N * SO * SO + 64 * nq - 1) / (64 * nq);
-  DP_REQUIRE(tiles < (1L << 31));
-  const dim3 grid((unsigned)tiles, O / kCvO), block(kBlock);
-  hipStream_t st = as_stream(stream);
-#define DP_LAUNCH_CV2Q(SO_, NQ_)                                                                                       \
-  do {                                                                                                                 \
-    if (ab) hipLaunchKernelGGL((k_conv3x3s2_mfma<SO_, true, NQ_>), grid, block, 0, st, x, wt, y, N, C, O, ab);        \
-    else hipLaunchKernelGGL((k_conv3x3s2_mfma<SO_, false, NQ_>), grid, block, 0, st, x, wt, y, N, C, O, ab);          \
-  } while (0)
-#define DP_LAUNCH_CV2(SO_)                                                                                             \
-  do {                                                                                                                 \
-    if (nq == 7) DP_LAUNCH_CV2Q(SO_, 7);                                                                               \
-    else if (nq == 2) DP_LAUNCH_CV2Q(SO_, 2);                                                                          \
-    else DP_LAUNCH_CV2Q(SO_, 1);                                                                                       \
-  } while (0)
-  if (SO == 28) DP_LAUNCH_CV2(28);
-  else if (SO == 14) DP_LAUNCH_CV2(14);
-  else DP_LAUNCH_CV2(7);
-#undef DP_LAUNCH_CV2
-#undef DP_LAUNCH_CV2Q
-  return launch_status();
-}
-
-int dp_conv3x3s2_bwd(const float *dy, const float *wt, int N, int O, int C, int Ho, int Wo, float *dx, int form,
-                     dp_stream_t stream) {
-  DP_REQUIRE(dy && wt && dx && aligned16(dy) && aligned16(wt) && aligned16(dx));
-  DP_REQUIRE(N > 0 && O > 0 && O % 16 == 0 && C > 0 && C % kCvO == 0 && Ho == Wo);
-  DP_REQUIRE(Ho == 28 || Ho == 14 || Ho == 7 || Ho == 48 || Ho == 24 || Ho == 12);      // side of dy; dx is (2 Ho) x (2 Ho)
-  DP_REQUIRE(form == DP_S2BWD_PAIRS || form == DP_S2BWD_CLASSES);
-  DP_REQUIRE((long)N * O * Ho * Wo < (1L << 31) && (long)N * C * Ho * Wo * 4 < (1L << 31));   // 32-bit element offsets
-  DP_REQUIRE((long)N * Ho * Wo + kCvPix < (1L << 31));
-  CfArgs A;
-  A.x = dy; A.wt = wt; A.ab = nullptr; A.y = dx;
-  A.N = N; A.C = O; A.O = C; A.og = C / kCvO;
-  hipStream_t st = as_stream(stream);
-  const dim3 block(kBlock);
-  if (form == DP_S2BWD_PAIRS) {       // 256-pixel tiles (5 whole images of 7 x 7), two row classes
-    const long tiles = Ho == 7 ? ((long)N + 4) / 5 : ((long)N * Ho * Wo + kC2Pix - 1) / kC2Pix;
-    DP_REQUIRE((tiles + 7) / 8 * 8 * A.og * 2 < (1L << 31));
-    A.tiles = (int)tiles;
-    const dim3 grid((unsigned)((tiles + 7) / 8 * 8 * A.og * 2));
-    switch (Ho) {
-      case 28: hipLaunchKernelGGL((k_conv3x3s2_dgrad2<28>), grid, block, 0, st, A); break;
-      case 14: hipLaunchKernelGGL((k_conv3x3s2_dgrad2<14>), grid, block, 0, st, A); break;
-      case 7: hipLaunchKernelGGL((k_conv3x3s2_dgrad2<7>), grid, block, 0, st, A); break;
-      case 48: hipLaunchKernelGGL((k_conv3x3s2_dgrad2<48>), grid, block, 0, st, A); break;
-      case 24: hipLaunchKernelGGL((k_conv3x3s2_dgrad2<24>), grid, block, 0, st, A); break;
-      default: hipLaunchKernelGGL((k_conv3x3s2_dgrad2<12>), grid, block, 0, st, A); break;
-    }
-    return launch_status();
-  }
-  const long tiles = Ho == 7 ? ((long)N + 8) / 9 : ((long)N * Ho * Wo + kCvPix - 1) / kCvPix;
-  DP_REQUIRE((tiles + 7) / 8 * 8 * A.og * 4 < (1L << 31));
-  A.tiles = (int)tiles;
-  const dim3 grid((unsigned)((tiles + 7) / 8 * 8 * A.og * 4));
-  switch (Ho) {
-    case 28: hipLaunchKernelGGL((k_conv3x3s2_dgrad<28>), grid, block, 0, st, A); break;
-    case 14: hipLaunchKernelGGL((k_conv3x3s2_dgrad<14>), grid, block, 0, st, A); break;
-    case 7: hipLaunchKernelGGL((k_conv3x3s2_dgrad<7>), grid, block, 0, st, A); break;
-    case 48: hipLaunchKernelGGL((k_conv3x3s2_dgrad<48>), grid, block, 0, st, A); break;
-    case 24: hipLaunchKernelGGL((k_conv3x3s2_dgrad<24>), grid, block, 0, st, A); break;
-    default: hipLaunchKernelGGL((k_conv3x3s2_dgrad<12>), grid, block, 0, st, A); break;
-  }
-  return launch_status();
-}
-
-#endif   // part 2
-#if DP_HAS(1)
-int dp_stem_conv_fwd(const float *x, const float *wt, int N, int H, int W, float *y, dp_stream_t stream) {
-  DP_REQUIRE(x && wt && y && aligned16(x) && aligned16(wt) && aligned16(y));
-  DP_REQUIRE(N > 0 && W == kStW && H > 0 && H % 2 == 0);
-  const int tpi = (H / 2 + 3) / 4;
-  DP_REQUIRE((long)N * tpi < (1L << 31) && (long)N * 3 * H * W < (1L << 31));
-  hipLaunchKernelGGL(k_stem_conv_mfma, dim3((unsigned)(N * tpi)), dim3(kBlock), 0, as_stream(stream), x, wt, y, N, H, tpi);
-  return launch_status();
-}
-
-#endif   // part 1
-#if DP_HAS(3)
-int dp_conv1x1_fwd(const float *x, const float *wt, const float *ab, const float *res, int N, int C, int O, int HW,
-                   float *y, dp_stream_t stream) {
-  DP_REQUIRE(x && wt && y && aligned16(x) && aligned16(wt) && aligned16(y));
-  DP_REQUIRE(N > 0 && HW > 0 && C > 0 && C % kC1Ch == 0 && O > 0 && O % kC1O == 0);
-  DP_REQUIRE((long)N * C * HW < (1L << 31) && (long)N * HW + kC1Pix < (1L << 31));   // 32-bit element offsets in the kernel
-  DP_REQUIRE(!ab || (reinterpret_cast<uintptr_t>(ab) & 7u) == 0);
-  const bool flat = (HW & 3) != 0;
-  DP_REQUIRE(!flat || (HW == 49 && !ab));     // 7 x 7 planes: whole-image tiles; the GroupNorm fold needs HW % 4 == 0
-  C1Args A;
-  A.x = x; A.wt = wt; A.ab = ab; A.res = res; A.y = y;
-  A.N = N; A.C = C; A.O = O; A.HW = HW;
-  A.og = O / kC1O;
-  DP_REQUIRE((((long)N * (flat ? 64 : HW) + 63) / 64 + 7) / 8 * 8 * A.og < (1L << 31));     // the grid of the smallest tile
-  A.spt = 0, A.tiles = 0;        // set by launch_conv1x1 for the tile it picks
-  return launch_conv1x1(A, flat, as_stream(stream));
-}
-
-#endif   // part 3
-#if DP_HAS(1)
-int dp_argmax(const float *logits, int N, int C, int32_t *pred, dp_stream_t stream) {
-  DP_REQUIRE(logits && pred && N > 0 && C > 0);
-  hipLaunchKernelGGL(k_argmax, dim3(cdiv(N, kBlock / 64)), dim3(kBlock), 0, as_stream(stream),
-                     logits, N, C, pred);
-  return launch_status();
-}
-
-static int gn_check(const float *x, const float *gamma, const float *beta, int N, int C, int HW,
-                    int G, GnArgs &A, float eps) {
-  DP_REQUIRE(x && gamma && beta && aligned16(x));
-  DP_REQUIRE(N > 0 && C > 0 && HW > 0 && G > 0 && C % G == 0);
-  const long L = (long)(C / G) * HW;
-  DP_REQUIRE((L & 3) == 0 && L < (1L << 20));  // float4 lanes; chan_of() exactness bound
-  DP_REQUIRE((long)N * G <= 0x7fffffffL);
-  A.x = x; A.gamma = gamma; A.beta = beta;
-  A.res = nullptr; A.sum_out = nullptr; A.dres = nullptr; A.ab = nullptr;
-  A.smap = nullptr; A.tab_rows = 0;
-  for (int k = 0; k < kGnMaxTabs; ++k) A.xtab[k] = nullptr;
-  A.C = C; A.HW = HW; A.Cg = C / G;
-  A.eps = eps; A.inv_hw = 1.f / (float)HW;
-  return 0;
-}
-
-int dp_gn_relu_fwd(const float *x, const float *res, float *sum_out, const float *gamma,
-                   const float *beta, int N, int C, int HW, int G, float eps, float *y, float *mean,
-                   float *rstd, dp_stream_t stream) {
-  GnArgs A;
-  const int rc = gn_check(x, gamma, beta, N, C, HW, G, A, eps);
-  if (rc) return rc;
-  DP_REQUIRE(y && mean && rstd && aligned16(y));
-  DP_REQUIRE(!res || (sum_out && aligned16(res) && aligned16(sum_out)));
-  A.res = res;
-  A.sum_out = res ? sum_out : nullptr;
-  return launch_gn_fwd(kGnDefaultVariant, A, N, y, mean, rstd, as_stream(stream));
-}
-
-int dp_gn_stats(const float *x, const float *res, float *sum_out, const float *gamma, const float *beta, int N, int C,
-                int HW, int G, float eps, float *mean, float *rstd, float *ab, dp_stream_t stream) {
-  GnArgs A;
-  const int rc = gn_check(x, gamma, beta, N, C, HW, G, A, eps);
-  if (rc) return rc;
-  DP_REQUIRE(mean && rstd && ab && (reinterpret_cast<uintptr_t>(ab) & 7u) == 0);
-  DP_REQUIRE(!res || (sum_out && aligned16(res) && aligned16(sum_out)));
-  A.res = res;
-  A.sum_out = res ? sum_out : nullptr;
-  A.ab = ab;
-  return launch_gn_fwd(kGnDefaultVariant, A, N, nullptr, mean, rstd, as_stream(stream));
-}
-
-int dp_gn_relu_bwd(const float *dy, const float *dres, const float *x, const float *gamma,
-                   const float *beta, const float *mean, const float *rstd, int N, int C, int HW,
-                   int G, float *dx, dp_stream_t stream) {
-  GnArgs A;
-  const int rc = gn_check(x, gamma, beta, N, C, HW, G, A, 0.f);
-  if (rc) return rc;
-  DP_REQUIRE(dy && mean && rstd && dx && aligned16(dy) && aligned16(dx));
-  DP_REQUIRE(!dres || aligned16(dres));
-  A.dres = dres;
-  return launch_gn_bwd(kGnDefaultVariant, A, N, dy, mean, rstd, dx, as_stream(stream));
-}
-
-int dp_gn_relu_bwd_gather(const float *dy, const float *dres, const float *const *x_tabs, int n_tabs,
-                          int tab_rows, const int *smap, const float *gamma, const float *beta,
-                          const float *mean, const float *rstd, int M, int C, int HW, int G, float *dx,
-                          dp_stream_t stream) {
-  DP_REQUIRE(x_tabs && smap && n_tabs >= 1 && n_tabs <= kGnMaxTabs && tab_rows > 0);
-  GnArgs A;
-  const int rc = gn_check(x_tabs[0], gamma, beta, M, C, HW, G, A, 0.f);
-  if (rc) return rc;
-  DP_REQUIRE(dy && mean && rstd && dx && aligned16(dy) && aligned16(dx));
-  DP_REQUIRE(!dres || aligned16(dres));
-  DP_REQUIRE((long)n_tabs * tab_rows * G <= 0x7fffffffL);
-  for (int k = 0; k < n_tabs; ++k) {
-    DP_REQUIRE(x_tabs[k] && aligned16(x_tabs[k]));
-    A.xtab[k] = x_tabs[k];
-  }
-  A.smap = smap;
-  A.tab_rows = tab_rows;
-  A.dres = dres;
-  return launch_gn_bwd(kGnDefaultVariant, A, M, dy, mean, rstd, dx, as_stream(stream));
-}
-
-int dp_pad_maxpool_fwd(const float *x, int64_t NC, int Hin, int Win, float *y, uint8_t *code,
-                       dp_stream_t stream) {
-  DP_REQUIRE(x && y && code && aligned16(x) && aligned16(y) && aligned16(code));
-  DP_REQUIRE(NC > 0 && Hin >= 2 && Win >= 8 && (Hin & 1) == 0 && (Win & 7) == 0);
-  DP_REQUIRE(NC <= 0x7fffffffL);
-  return launch_pad_maxpool_fwd(kPoolDefaultMode, x, NC, Hin, Win, y, reinterpret_cast<uint32_t *>(code), as_stream(stream));
-}
-
-int dp_pad_maxpool_bwd(const float *dy, const uint8_t *code, int64_t NC, int Hin, int Win, float *dx,
-                       dp_stream_t stream) {
-  DP_REQUIRE(dy && dx && code && aligned16(dx) && aligned16(dy) && (reinterpret_cast<uintptr_t>(code) & 3u) == 0);
-  DP_REQUIRE(NC > 0 && Hin >= 2 && Win >= 8 && (Hin & 1) == 0 && (Win & 7) == 0);
-  DP_REQUIRE(NC <= 0x7fffffffL);
-  return launch_pad_maxpool_bwd(kPoolBwdDefaultMode, dy, code, NC, Hin, Win, dx, as_stream(stream));
-}
-
-int dp_stem_dgrad(const float *dy, const float *w, int N, int K, int Ho, int Wo, float *dx,
-                  dp_stream_t stream) {
-  DP_REQUIRE(dy && w && dx && N > 0 && N <= 65535 && K > 0 && Ho > 0 && Wo > 0);
-  DP_REQUIRE((reinterpret_cast<uintptr_t>(dx) & 7u) == 0);
-  return launch_stem_dgrad(kStemDefaultVariant, dy, w, N, K, Ho, Wo, dx, as_stream(stream));
-}
-
-int dp_stem_dgrad_reduce(const float *dy, const float *w, const int32_t *table, int R, const int32_t *idx,
-                         const int32_t *idx2, int idx_bstride, int B, int S, int K, int Ho, int Wo,
-                         const dp_norm_t *norm, float *slabs, dp_stream_t stream) {
-  DP_REQUIRE(dy && w && slabs && K > 0 && Ho > 0 && Wo > 0);
-  DP_REQUIRE((reinterpret_cast<uintptr_t>(slabs) & 7u) == 0);
-  const int rc = check_occlusion_args(table, R, idx, idx_bstride, B, S, 2 * Ho, 2 * Wo, norm);
-  if (rc) return rc;
-  const int s_per_slab = bwd_s_per_slab(B, S, 4 * Ho * Wo);  // the partition dp_apply_bwd uses: identical sums
-  const int nslab = cdiv(S, s_per_slab);
-  DP_REQUIRE((long)B * nslab <= 65535);
-  hipLaunchKernelGGL(k_stem_dgrad_reduce, dim3(cdiv(Wo, SQ), cdiv(Ho, SQ), B * nslab), dim3(kStemBlock), 0,
-                     as_stream(stream), dy, w, table, R, idx, idx2, idx_bstride, B, S, s_per_slab, K, Ho, Wo,
-                     make_norm(norm), slabs);
-  return launch_status();
-}
-
-static int subsample_geometry(int64_t NC, int H, int W, bool &wide, long &total) {
-  DP_REQUIRE(NC > 0 && H >= 2 && W >= 2 && (H & 1) == 0 && (W & 1) == 0);
-  wide = (W & 3) == 0;
-  total = NC * (H >> 1) * (wide ? (W >> 2) : (W >> 1));
-  DP_REQUIRE((total + kBlock - 1) / kBlock <= 0x7fffffffL);
-  return 0;
-}
-
-int dp_subsample2(const float *x, int64_t NC, int H, int W, float *y, dp_stream_t stream) {
-  DP_REQUIRE(x && y && aligned16(x) && (reinterpret_cast<uintptr_t>(y) & 7u) == 0);
-  bool wide;
-  long total;
-  const int rc = subsample_geometry(NC, H, W, wide, total);
-  if (rc) return rc;
-  const dim3 grid((unsigned)((total + kBlock - 1) / kBlock));
-  if (wide) hipLaunchKernelGGL((k_subsample2<true>), grid, dim3(kBlock), 0, as_stream(stream), x, H, W, total, y);
-  else hipLaunchKernelGGL((k_subsample2<false>), grid, dim3(kBlock), 0, as_stream(stream), x, H, W, total, y);
-  return launch_status();
-}
-
-int dp_subsample2_add(const float *dy, int64_t NC, int H, int W, float *g, dp_stream_t stream) {
-  DP_REQUIRE(dy && g && aligned16(g) && (reinterpret_cast<uintptr_t>(dy) & 7u) == 0);
-  bool wide;
-  long total;
-  const int rc = subsample_geometry(NC, H, W, wide, total);
-  if (rc) return rc;
-  const dim3 grid((unsigned)((total + kBlock - 1) / kBlock));
-  if (wide) hipLaunchKernelGGL((k_subsample2_add<true>), grid, dim3(kBlock), 0, as_stream(stream), dy, H, W, total, g);
-  else hipLaunchKernelGGL((k_subsample2_add<false>), grid, dim3(kBlock), 0, as_stream(stream), dy, H, W, total, g);
-  return launch_status();
-}
-
 /* ---- measurement support: kernel-precise timing of the dominant kernel (bench.py roofline) ---- */
 int dp_event_create(dp_event_t *ev) {
   DP_REQUIRE(ev);
@@ -5380,17 +199,5 @@ int dp_event_elapsed_ms(dp_event_t start, dp_event_t stop, float *ms) {
   return (int)hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
 }
 
-int dp_apply_fwd_timed(const float *adv_x, const int32_t *table, int R, const int32_t *idx,
-                       const int32_t *idx2, int idx_bstride, int B, int S, int H, int W,
-                       const dp_norm_t *norm, float *out, dp_stream_t stream, dp_event_t start,
-                       dp_event_t stop) {
-  DP_REQUIRE(adv_x && out && aligned16(adv_x) && aligned16(out) && start && stop);
-  const int rc = check_occlusion_args(table, R, idx, idx_bstride, B, S, H, W, norm);
-  if (rc) return rc;
-  return launch_apply_fwd(kApplyFwdDefaultVariant, adv_x, table, R, idx, idx2, idx_bstride, B, S, H, W,
-                          norm, out, stream, (hipEvent_t)start, (hipEvent_t)stop);
-}
-
-#endif   // part 1
-
 }  // extern "C"
+#endif   // part 1

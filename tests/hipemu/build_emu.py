@@ -18,9 +18,11 @@ SRC = os.path.join(ROOT, "dorpatch_amd", "csrc", "dorpatch_hip.hip")
 SANITIZE = os.environ.get("DORPATCH_EMU_SANITIZE", "0") == "1"      # AddressSanitizer build (tests/test_kernels_asan.py)
 OUT = os.path.join(HERE, "libdorpatch_emu_asan.so" if SANITIZE else "libdorpatch_emu.so")
 GEN = os.path.join(HERE, "_dorpatch_emu_asan_gen.cpp" if SANITIZE else "_dorpatch_emu_gen.cpp")
-DEPS = [SRC, os.path.join(os.path.dirname(SRC), "conv3x3_wino.inc"), os.path.join(ROOT, "include", "dorpatch_hip.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
-        os.path.abspath(__file__)]
+CSRC = os.path.dirname(SRC)
+DEPS = sorted(os.path.join(CSRC, n) for n in os.listdir(CSRC) if n.endswith((".hip", ".inc"))) + [
+    os.path.join(ROOT, "include", "dorpatch_hip.h"), os.path.join(HERE, "hip", "hip_runtime.h"), os.path.abspath(__file__)]
 
+_INC = re.compile(r'^#include "(\w+\.inc)".*$', re.M)
 _DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(\w+)\s+(\w+)\[\];")
 
 
@@ -40,6 +42,12 @@ def build(force=False):
         return OUT
     with open(SRC) as f:
         text = f.read()
+
+    def family(m):      # the kernel families (csrc/*.inc) are spliced in so that the LDS rewrite below reaches them
+        path = os.path.join(CSRC, m.group(1))
+        with open(path) as g:
+            return '#line 1 "%s"\n%s\n#line %d "%s"' % (path, g.read(), text.count("\n", 0, m.end()) + 2, SRC)
+    text = _INC.sub(family, text)
     text = _DYN.sub(lambda m: "%s *%s = static_cast<%s *>(hipemu::dyn_lds_ptr());" % (m.group(1), m.group(2), m.group(1)),
                     text)
     # per-process scratch names: the ranks of a multi-process test may find the library stale at the same moment
