@@ -184,8 +184,8 @@ def prepack(net):
     """Build every packed copy a frozen convolution of ``net`` can ask for, on the CURRENT stream, before the first
     forward.  ``_packed`` builds lazily on whatever stream is current; with micro-batches / sweep forwards round-robin on
     side streams (DorPatch(streams=2)) the first use would sit on side stream A and the second micro-batch, on stream B,
-    would read the cached tensor with nothing ordering it after A's permute + copy.  Called by HotLoop,
-    collect_failure and PatchCleanser before they fork side streams: those wait for the current stream, so every pack is
+    would read the cached tensor with nothing ordering it after A's permute + copy.  Called by HotLoop and
+    collect_failure (the two places that fork side streams; PatchCleanser's sweeps stay on one stream) before they do: those wait for the current stream, so every pack is
     complete for them.  Cheap when the packs exist (a dictionary lookup per filter)."""
     if not isinstance(net, torch.nn.Module):
         return 0
