@@ -107,7 +107,7 @@ def _packed(w, kind, make):
     """``make()`` cached on the weight tensor under ``kind`` (dies with the tensor; invalidated by an in-place update that
     bumps its version or by a move to another device).  Only FROZEN weights are routed here (``requires_grad`` False is
     checked by the callers): a write through ``w.data`` does not bump the version — call ``clear_packs(w)`` after one."""
-    key = (w._version, w.data_ptr(), str(w.device))
+    key = (w._version, w.data_ptr(), w.device)
     cache = getattr(w, "_dp_conv_pack", None)
     if cache is None or cache[0] != key:
         cache = (key, {})

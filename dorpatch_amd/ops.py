@@ -14,8 +14,25 @@ from . import _lib
 from ._lib import DpNorm, DpUpdateCfg
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """The current HIP stream of the current device as a raw handle.  torch's own C entry points where they exist (two C
+    calls) instead of building a ``torch.cuda.Stream`` object per launch: at 32 - 64 rows a step is ~240 launches in
+    9 - 13 ms and the host's time per launch shows in the step (configs[0]: 9.10 - 9.33 -> 8.74 - 8.94 ms with this and
+    the memo in resnetv2._sum_ok, profiles/r06y_host_path_ab.txt)."""
+    if _raw_stream is not None and _cur_device is not None:
+        return ctypes.c_void_p(_raw_stream(_cur_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _numel(dims):
+    n = 1
+    for d in dims:
+        n *= int(d)
+    return n
 
 
 def _chk(t, dtype, name):
@@ -609,7 +626,7 @@ def gn_stats(x, weight, bias, groups, eps, res=None, stats_out=None):
     lib = _lib.load()
     _chk(x, torch.float32, "x"), _chk(weight, torch.float32, "weight"), _chk(bias, torch.float32, "bias")
     N, C = x.shape[0], x.shape[1]
-    HW = int(np.prod(x.shape[2:]))
+    HW = _numel(x.shape[2:])
     if stats_out is None:
         mean = torch.empty((N * groups,), dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
@@ -636,7 +653,7 @@ def gn_relu_supported(x, groups):
     C = x.shape[1]
     if C % groups:
         return False
-    L = (C // groups) * int(np.prod(x.shape[2:]))
+    L = (C // groups) * _numel(x.shape[2:])
     return L % 4 == 0 and L < (1 << 20)
 
 
@@ -647,7 +664,7 @@ def gn_relu_fwd(x, weight, bias, groups, eps, res=None, stats_out=None):
     lib = _lib.load()
     _chk(x, torch.float32, "x"), _chk(weight, torch.float32, "weight"), _chk(bias, torch.float32, "bias")
     N, C = x.shape[0], x.shape[1]
-    HW = int(np.prod(x.shape[2:]))
+    HW = _numel(x.shape[2:])
     y = torch.empty_like(x)
     if stats_out is None:
         mean = torch.empty((N * groups,), dtype=torch.float32, device=x.device)
@@ -674,7 +691,7 @@ def gn_relu_bwd(dy, x, weight, bias, mean, rstd, groups, dres=None):
     if dres is not None:
         _chk(dres, torch.float32, "dres")
     N, C = x.shape[0], x.shape[1]
-    HW = int(np.prod(x.shape[2:]))
+    HW = _numel(x.shape[2:])
     dx = torch.empty_like(x)
     _lib.check(lib.dp_gn_relu_bwd(_p(dy), _p(dres), _p(x), _p(weight), _p(bias), _p(mean), _p(rstd), N, C, HW,
                                   int(groups), _p(dx), _stream()), "dp_gn_relu_bwd")
@@ -696,7 +713,7 @@ def gn_relu_bwd_gather(dy, x_tabs, tab_rows, smap, weight, bias, mean, rstd, gro
         assert t.shape[1:] == dy.shape[1:] and t.shape[0] <= tab_rows
     assert all(t.shape[0] == tab_rows for t in x_tabs[:-1]) and smap.numel() == dy.shape[0]
     M, C = dy.shape[0], dy.shape[1]
-    HW = int(np.prod(dy.shape[2:]))
+    HW = _numel(dy.shape[2:])
     ptrs = (ctypes.c_void_p * len(x_tabs))(*[t.data_ptr() for t in x_tabs])
     dx = torch.empty_like(dy)
     _lib.check(lib.dp_gn_relu_bwd_gather(_p(dy), _p(dres), ptrs, len(x_tabs), int(tab_rows), _p(smap), _p(weight),

@@ -170,20 +170,29 @@ class PreActBottleneck(nn.Module):
                 and all(GroupNormAct.fused and not (n.weight.requires_grad or n.bias.requires_grad)
                         and n.num_channels % n.num_groups == 0 for n in (self.norm2, self.norm3))):
             return False
+        # what follows depends on the input's shape / layout only (the weights' shapes are fixed): decided once per shape —
+        # 16 blocks ask every forward, and at 32 - 64 rows the host's time per step shows (profiles/r06y_host_path_ab.txt)
+        memo = self.__dict__.setdefault("_sum_ok_shapes", {})
+        key = (tuple(x.shape), x.dtype, x.is_cuda, x.is_contiguous())
+        ok = memo.get(key)
+        if ok is not None:
+            return ok
         s = self.conv2.stride[0]
-        small = x[:, :, ::s, ::s]
+        sh, sw = (x.shape[2] + s - 1) // s, (x.shape[3] + s - 1) // s        # the plane after the block's stride
         # the BACKWARD runs the same kernel on the transposed weights: conv1 / conv3 need C % 64 == 0 there —
         # a bottleneck width that is not a multiple of 64 takes forward_pair instead of failing in the backward
-        return (ops.conv1x1_supported(x, self.conv1.weight)
-                and self.conv1.weight.shape[1] % 64 == 0 and self.conv1.weight.shape[0] % 16 == 0
-                and self.conv3.weight.shape[1] % 64 == 0
-                and (self.downsample is None or self.downsample.conv.weight.shape[1] % 64 == 0)
-                and small.shape[0] * self.conv3.weight.shape[0] * small.shape[2] * small.shape[3] < 2 ** 31
-                and self.conv3.weight.shape[1] % 16 == 0 and self.conv3.weight.shape[0] % 64 == 0
-                and ((small.shape[2] * small.shape[3]) % 4 == 0 or small.shape[2] * small.shape[3] == 49)
-                and (self.downsample is None or (self.downsample.conv.stride[0] in (1, 2)
-                                                 and self.downsample.conv.weight.shape[0] % 64 == 0
-                                                 and (s == 1 or ops.subsample2_supported(x)))))
+        ok = bool(ops.conv1x1_supported(x, self.conv1.weight)
+                  and self.conv1.weight.shape[1] % 64 == 0 and self.conv1.weight.shape[0] % 16 == 0
+                  and self.conv3.weight.shape[1] % 64 == 0
+                  and (self.downsample is None or self.downsample.conv.weight.shape[1] % 64 == 0)
+                  and x.shape[0] * self.conv3.weight.shape[0] * sh * sw < 2 ** 31
+                  and self.conv3.weight.shape[1] % 16 == 0 and self.conv3.weight.shape[0] % 64 == 0
+                  and ((sh * sw) % 4 == 0 or sh * sw == 49)
+                  and (self.downsample is None or (self.downsample.conv.stride[0] in (1, 2)
+                                                   and self.downsample.conv.weight.shape[0] % 64 == 0
+                                                   and (s == 1 or ops.subsample2_supported(x)))))
+        memo[key] = ok
+        return ok
 
     def forward_sum(self, x):
         """Folded form: ``x`` is the block's materialised input (the previous block's ``branch + shortcut``, added in that
