@@ -1122,3 +1122,29 @@ def test_stem_dgrad_reduce_equals_stem_dgrad_then_apply_bwd(B, S, K, H, dual):
         want_acc = ops.apply_bwd(G, table, idx, idx2, norm, B=B, out=base.clone(), accumulate=True)
         got_acc = ops.stem_dgrad_reduce(dy, w, table, idx, idx2, norm, B=B, out=base.clone(), accumulate=True)
         assert torch.equal(got_acc, want_acc)
+
+
+def test_launch_stream_handle_is_torchs_current_stream():
+    """ops._stream() takes the raw handle from torch's C entry points (no Stream object per launch): it must be the very
+    stream torch.cuda.current_stream() names — on the default stream, inside a side-stream context, and back outside —
+    and a kernel launched through ops inside the context is ordered with the torch ops of that stream."""
+    if DEV == "cpu":
+        pytest.skip("the emulation has no streams (tests/hipemu/patch.py hands the kernels a null handle)")
+
+    def both():
+        return ops._stream().value or 0, torch.cuda.current_stream().cuda_stream or 0
+    a, b = both()
+    assert a == b
+    x, p, m = _rand(2, 3, 56, 56, seed=1), _rand(2, 3, 56, 56, seed=2), _rand(2, 1, 56, 56, seed=3)
+    want = R.clip(m, p, x, 4.0) + x
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        a, b = both()
+        assert a == b == side.cuda_stream
+        xs = [t.to(DEV, non_blocking=True) * 1.0 for t in (m, p, x)]      # produced ON the side stream
+        adv = ops.blend(xs[0], xs[1], xs[2], 4.0)[0]
+        got = adv.cpu()
+    torch.cuda.current_stream().wait_stream(side)
+    a, b = both()
+    assert a == b
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=1e-7)
