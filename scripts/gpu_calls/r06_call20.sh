@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: records an experiment whose code was NOT kept (the kbench variants / switches it names are described in DESIGN.md section 9 and in the profiles it wrote); it does not run on the committed tree as is.
 # Round 6, GPU call 20: k_conv1x1_mfma A/B on one box — residual fragments requested 2 / 3 ahead of the store (DP_C1_RES_DEPTH
 # 3 / 4 against 2) and the staging's loads past the end of K collapsed onto one cache line (DP_C1_TAIL_COLLAPSE), N = 512.
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: records an experiment whose code was NOT kept (the kbench variants / switches it names are described in DESIGN.md section 9 and in the profiles it wrote); it does not run on the committed tree as is.
 # Round 6, GPU call 23: host time per launch — raw stream handle + memoised _sum_ok against the previous host path
 # (DORPATCH_AB_OLD_HOST=1, experiment switch), interleaved on one box: configs[0], configs[3], 1 x 128, and the headline.
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: records an experiment whose code was NOT kept (the kbench variants / switches it names are described in DESIGN.md section 9 and in the profiles it wrote); it does not run on the committed tree as is.
 # Round 6, GPU call 26 (experiment): do the two workgroups of a CU / the CUs of the chip run k_conv1x1_mfma in lock-step (all in
 # their K loops, then all in their epilogues)?  First-round workgroups start late by a slot-dependent delay; N = 512.
 export TMPDIR=/tmp
