@@ -574,6 +574,31 @@ def test_conv3x3_winograd_on_the_matrix_cores_matches_conv2d(N, C, O, S, small):
         assert torch.equal(ops.conv3x3_wino_fwd(xr, wt, ab=ab), ops.conv3x3_wino_fwd(y, wt))
 
 
+@pytest.mark.parametrize("C,S", [(64, 56), (128, 28), (256, 14), (512, 7)])
+def test_conv3x3_winograd_at_the_bench_size_agrees_with_the_direct_kernel(C, S):
+    """BASELINE configs[1]'s micro-batch (N = 512) on ResNetV2-50's four stride-1 3x3 shapes — sizes no CPU reference finishes
+    in seconds, so through size-independent properties: the Winograd kernel against the direct MFMA kernel (another
+    algorithm, other index arithmetic, the same weights) to 2e-5 of the output scale everywhere; the LAST image against
+    F.conv2d on the CPU (the end of the grid: ragged last block, largest offsets); linearity in the input; same bits twice."""
+    if DEV == "cpu":
+        pytest.skip("bench-sized: GPU only")
+    N = 512
+    g = torch.Generator().manual_seed(S)
+    x = torch.randn(N, C, S, S, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) / (3.0 * C ** 0.5)
+    xd = x.to(DEV)
+    ww, wd = ops.pack_conv3x3_wino_weights(w).to(DEV), ops.pack_conv3x3_weights(w).to(DEV)
+    got = ops.conv3x3_wino_fwd(xd, ww)
+    ref = ops.conv3x3_fwd(xd, wd)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-5 * scale
+    np.testing.assert_allclose(got[-1:].cpu().numpy(), F.conv2d(x[-1:], w, padding=1).numpy(), rtol=0, atol=2e-5 * scale)
+    assert torch.equal(got, ops.conv3x3_wino_fwd(xd, ww))
+    x2 = torch.randn(N, C, S, S, generator=g).to(DEV)
+    lin = ops.conv3x3_wino_fwd((0.5 * xd + x2).contiguous(), ww)
+    assert float((lin - (0.5 * got + ops.conv3x3_wino_fwd(x2, ww))).abs().max()) <= 2e-5 * scale
+
+
 CONV3X3S2_BWD_CASES = [   # (N, O = channels of dy, C = channels of dx, side of dy, emulation-sized)
     (2, 16, 64, 14, True),      # 392 pixels: one ragged tile spanning both images; ONE chunk in class (0,0), 4 in class (1,1)
     (10, 16, 64, 7, True),      # flat mode: 9 whole images + a ragged second tile; 1 - 4 chunks per class
@@ -782,6 +807,29 @@ def test_conv1x1_launch_variants_are_bit_identical():
         ops.debug_set(_lib.DP_DEBUG_CONV1X1_VARIANT, 0)
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+
+
+@pytest.mark.parametrize("C,O,H", [(64, 256, 56), (512, 128, 28), (1024, 256, 14), (2048, 512, 7)])
+def test_conv1x1_at_the_bench_size_agrees_with_the_library(C, O, H):
+    """BASELINE configs[1]'s micro-batch (N = 512) on four of ResNetV2-50's 1x1 shapes (row mode at 56 / 28 / 14, whole-image
+    tiles at 7; K from 64 to 2048): the hand-written kernel against the library's convolution on the same device (an
+    independent implementation) to 3e-5 of the output scale; the LAST image against F.conv2d on the CPU; the epilogue add
+    against a separate add, bit for bit; same bits twice."""
+    if DEV == "cpu":
+        pytest.skip("bench-sized: GPU only")
+    N = 512
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(N, C, H, H, generator=g)
+    w = torch.randn(O, C, 1, 1, generator=g) / C ** 0.5
+    xd, wt = x.to(DEV), ops.pack_conv1x1_weights(w).to(DEV)
+    got = ops.conv1x1_fwd(xd, wt)
+    ref = F.conv2d(xd, w.to(DEV))
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 3e-5 * scale
+    np.testing.assert_allclose(got[-1:].cpu().numpy(), F.conv2d(x[-1:], w).numpy(), rtol=0, atol=3e-5 * scale)
+    assert torch.equal(got, ops.conv1x1_fwd(xd, wt))
+    res = torch.randn(N, O, H, H, generator=g).to(DEV)
+    assert torch.equal(ops.conv1x1_fwd(xd, wt, res=res), got + res)
 
 
 CONV1X1_TILE_CASES = [   # (N, C, O, H, emulation-sized)
