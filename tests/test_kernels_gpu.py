@@ -832,6 +832,51 @@ def test_conv1x1_at_the_bench_size_agrees_with_the_library(C, O, H):
     assert torch.equal(ops.conv1x1_fwd(xd, wt, res=res), got + res)
 
 
+@pytest.mark.parametrize("C,S", [(128, 56), (256, 28), (512, 14)])
+def test_conv3x3_stride2_pair_at_the_bench_size_agrees_with_the_library(C, S):
+    """BASELINE configs[1]'s micro-batch (N = 512) on ResNetV2-50's three stride-2 3x3 convolutions: dp_conv3x3s2_fwd and the
+    input gradient dp_conv3x3s2_bwd against the library on the same device (3e-5 of the scale), the last image against the CPU,
+    same bits twice."""
+    if DEV == "cpu":
+        pytest.skip("bench-sized: GPU only")
+    N = 512
+    g = torch.Generator().manual_seed(C + S)
+    x = torch.randn(N, C, S, S, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) / (3.0 * C ** 0.5)
+    xd, wdv = x.to(DEV), w.to(DEV)
+    got = ops.conv3x3s2_fwd(xd, ops.pack_conv3x3_weights(w).to(DEV))
+    ref = F.conv2d(xd, wdv, stride=2, padding=1)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 3e-5 * scale
+    np.testing.assert_allclose(got[-1:].cpu().numpy(), F.conv2d(x[-1:], w, stride=2, padding=1).numpy(), rtol=0, atol=3e-5 * scale)
+    assert torch.equal(got, ops.conv3x3s2_fwd(xd, ops.pack_conv3x3_weights(w).to(DEV)))
+    dy = torch.randn(N, C, S // 2, S // 2, generator=g).to(DEV)
+    wb = ops.pack_conv3x3s2_dgrad_weights(w).to(DEV)
+    got_dx = ops.conv3x3s2_bwd(dy, wb, C)
+    ref_dx = torch.ops.aten.convolution_backward(dy, xd, wdv, None, (2, 2), (1, 1), (1, 1), False, (0, 0), 1, (True, False, False))[0]
+    sdx = float(ref_dx.abs().max())
+    assert float((got_dx - ref_dx).abs().max()) <= 3e-5 * sdx
+    assert torch.equal(got_dx, ops.conv3x3s2_bwd(dy, wb, C))
+
+
+def test_stem_convolution_and_its_input_gradient_at_the_bench_size_agree_with_the_library():
+    """N = 512 images of 224 x 224 through dp_stem_conv_fwd and dp_stem_dgrad against the library on the same device."""
+    if DEV == "cpu":
+        pytest.skip("bench-sized: GPU only")
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(512, 3, 224, 224, generator=g).to(DEV)
+    w = (torch.randn(64, 3, 7, 7, generator=g) / 12.0)
+    wdv = w.to(DEV)
+    got = ops.stem_conv_fwd(x, ops.pack_stem_weights(w).to(DEV))
+    ref = F.conv2d(x, wdv, stride=2, padding=3)
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert torch.equal(got, ops.stem_conv_fwd(x, ops.pack_stem_weights(w).to(DEV)))
+    dy = torch.randn(512, 64, 112, 112, generator=g).to(DEV)
+    got_dx = ops.stem_dgrad(dy, wdv)
+    ref_dx = torch.ops.aten.convolution_backward(dy, x, wdv, None, (2, 2), (3, 3), (1, 1), False, (0, 0), 1, (True, False, False))[0]
+    assert float((got_dx - ref_dx).abs().max()) <= 3e-5 * float(ref_dx.abs().max())
+
+
 CONV1X1_TILE_CASES = [   # (N, C, O, H, emulation-sized)
     (3, 32, 64, 14, True),      # row mode: tiles of 448 / 256 / 128 / 64 pixels cut 588 pixels at different seams
     (11, 16, 128, 7, True),     # flat mode: 9 / 5 / 2 / 1 whole images per tile
