@@ -1006,6 +1006,33 @@ def test_gn_relu_matches_torch(shape):
     np.testing.assert_allclose(want2.view(N, C, H, W).numpy(), dxr.numpy(), rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("C,H", [(256, 56), (1024, 14)])
+def test_gn_relu_at_the_bench_size_agrees_with_the_library(C, H):
+    """N = 512 samples (BASELINE configs[1]'s micro-batch) through dp_gn_relu_fwd / dp_gn_stats / dp_gn_relu_bwd: forward and
+    input gradient against torch's own GroupNorm + ReLU (autograd) on the same device, the statistics pass against the full
+    kernel bit for bit, the last sample against float64 on the CPU."""
+    if DEV == "cpu":
+        pytest.skip("bench-sized: GPU only")
+    N, G = 512, 32
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(N, C, H, H, generator=g) * 1.5 + 0.3).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), (torch.randn(C, generator=g) * 0.2).to(DEV)
+    dy = torch.randn(N, C, H, H, generator=g).to(DEV)
+    y, mean, rstd, _ = ops.gn_relu_fwd(x, gamma, beta, G, 1e-5)
+    m2, r2, ab, _ = ops.gn_stats(x, gamma, beta, G, 1e-5)
+    assert torch.equal(mean, m2) and torch.equal(rstd, r2)
+    dx = ops.gn_relu_bwd(dy, x, gamma, beta, mean, rstd, G)
+    xr = x.clone().requires_grad_(True)
+    z = F.group_norm(xr, G, gamma, beta, 1e-5)
+    ref = torch.relu(z).detach()
+    assert float((y - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    # the gate of the reference is the kernel's own (|z| < 1e-5: fp32 implementations may legitimately disagree on it)
+    (want,) = torch.autograd.grad(z, xr, dy * (y > 0))
+    assert float((dx - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    z64 = F.group_norm(x[-1:].cpu().double(), G, gamma.cpu().double(), beta.cpu().double(), 1e-5)
+    np.testing.assert_allclose(y[-1:].cpu().numpy(), torch.relu(z64).float().numpy(), rtol=2e-5, atol=2e-6)
+
+
 def test_gn_relu_autograd_function_in_module():
     """GroupNormAct routes frozen GPU inputs through the fused kernels; trainable / CPU stay on torch."""
     from dorpatch_amd.resnetv2 import GroupNormAct
